@@ -1,0 +1,293 @@
+// phl_api.hip -- host side of the C ABI declared in include/phl.h.
+//
+// No CPU fallback lives here on purpose: without a HIP device every entry point that would
+// compute returns PHL_ERR_NO_DEVICE / PHL_ERR_HIP.  The CPU restatement under oracle/ is test
+// infrastructure and is never linked into this library.
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <vector>
+
+#include "phl_internal.h"
+
+namespace {
+thread_local char g_err[512] = "";
+
+struct device_guard {
+    int prev = -1;
+    bool ok = false;
+    explicit device_guard(int dev)
+    {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        ok = (prev == dev) || (hipSetDevice(dev) == hipSuccess);
+    }
+    ~device_guard()
+    {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
+int grow(float **p, int64_t *cap, int64_t need)
+{
+    if (need <= *cap) return PHL_OK;
+    if (*p) PHL_HIP(hipFree(*p));
+    *p = nullptr;
+    *cap = 0;
+    PHL_HIP(hipMalloc((void **)p, sizeof(float) * (size_t)need));
+    *cap = need;
+    return PHL_OK;
+}
+}  // namespace
+
+void phl_set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int phl_hip_fail(hipError_t e, const char *what, const char *file, int line)
+{
+    const char *base = strrchr(file, '/');
+    phl_set_error("HIP error %d (%s) in %s at %s:%d", (int)e, hipGetErrorString(e), what, base ? base + 1 : file, line);
+    (void)hipGetLastError();  // clear sticky state
+    return e == hipErrorNoDevice || e == hipErrorInvalidDevice ? PHL_ERR_NO_DEVICE : PHL_ERR_HIP;
+}
+
+extern "C" {
+
+int phl_version(void) { return PHL_VERSION; }
+const char *phl_last_error(void) { return g_err; }
+
+const char *phl_status_string(int s)
+{
+    switch (s) {
+        case PHL_OK: return "ok";
+        case PHL_ERR_INVALID: return "invalid argument";
+        case PHL_ERR_SHAPE: return "incompatible shapes";
+        case PHL_ERR_HIP: return "HIP runtime error";
+        case PHL_ERR_NO_DEVICE: return "no HIP device";
+        case PHL_ERR_KEY_RANGE: return "lattice key outside int16";
+        case PHL_ERR_TOO_LARGE: return "problem too large for int32 indexing";
+        case PHL_ERR_UNSUPPORTED: return "unsupported";
+        default: return "unknown";
+    }
+}
+
+int phl_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
+int phl_build(phl_lattice **out, const float *ref_dev, int64_t n, int d, int64_t rs, int64_t cs, int device,
+              phl_stream stream)
+{
+    if (!out) { phl_set_error("phl_build: out is NULL"); return PHL_ERR_INVALID; }
+    *out = nullptr;
+    if (n < 0 || d < 1 || (n > 0 && !ref_dev)) { phl_set_error("phl_build: bad arguments (n=%lld d=%d)", (long long)n, d); return PHL_ERR_INVALID; }
+    if (d > PHL_MAX_D) { phl_set_error("phl_build: d=%d exceeds PHL_MAX_D=%d", d, PHL_MAX_D); return PHL_ERR_UNSUPPORTED; }
+    if (n * (int64_t)(d + 1) > (int64_t)1 << 30) { phl_set_error("phl_build: n*(d+1)=%lld exceeds 2^30", (long long)(n * (d + 1))); return PHL_ERR_TOO_LARGE; }
+    if (phl_device_count() <= device || device < 0) { phl_set_error("phl_build: HIP device %d not available (no CPU fallback)", device); return PHL_ERR_NO_DEVICE; }
+    device_guard g(device);
+    if (!g.ok) { phl_set_error("phl_build: cannot select device %d", device); return PHL_ERR_NO_DEVICE; }
+
+    phl_lattice *lat = new phl_lattice();
+    memset(lat, 0, sizeof(*lat));
+    lat->device = device;
+    lat->d = d;
+    lat->n = n;
+    int rc = phl_build_device(lat, ref_dev, rs, cs, (hipStream_t)stream);
+    if (rc != PHL_OK) {
+        phl_destroy(lat);
+        return rc;
+    }
+    *out = lat;
+    return PHL_OK;
+}
+
+int phl_destroy(phl_lattice *lat)
+{
+    if (!lat) return PHL_OK;
+    device_guard g(lat->device);
+    void *ptrs[] = {lat->vkeys, lat->replay, lat->csr_ptr, lat->csr, lat->nbr, lat->buf[0], lat->buf[1], lat->stage_in, lat->stage_out};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    delete lat;
+    return PHL_OK;
+}
+
+int64_t phl_num_pixels(const phl_lattice *lat) { return lat ? lat->n : -1; }
+int64_t phl_num_vertices(const phl_lattice *lat) { return lat ? lat->M : -1; }
+int phl_num_dims(const phl_lattice *lat) { return lat ? lat->d : -1; }
+int phl_device(const phl_lattice *lat) { return lat ? lat->device : -1; }
+int64_t phl_device_bytes(const phl_lattice *lat)
+{
+    if (!lat) return -1;
+    return lat->table_bytes + 2 * lat->buf_elems * (int64_t)sizeof(float) + 2 * lat->stage_elems * (int64_t)sizeof(float);
+}
+
+int phl_reserve(phl_lattice *lat, int vd)
+{
+    if (!lat || vd < 0) { phl_set_error("phl_reserve: bad arguments"); return PHL_ERR_INVALID; }
+    device_guard g(lat->device);
+    const int64_t need = lat->M * (int64_t)vd;
+    if (need <= lat->buf_elems) return PHL_OK;
+    int64_t cap0 = lat->buf_elems, cap1 = lat->buf_elems;
+    int rc = grow(&lat->buf[0], &cap0, need);
+    if (rc) { lat->buf_elems = 0; return rc; }
+    rc = grow(&lat->buf[1], &cap1, need);
+    if (rc) { lat->buf_elems = 0; return rc; }
+    lat->buf_elems = need;
+    return PHL_OK;
+}
+
+int phl_splat(phl_lattice *lat, const float *src, int vd, int64_t src_rs, float *vert, phl_stream st)
+{
+    if (!lat || vd < 0 || (lat->n > 0 && vd > 0 && (!src || !vert))) { phl_set_error("phl_splat: bad arguments"); return PHL_ERR_INVALID; }
+    device_guard g(lat->device);
+    return phl_launch_splat(lat, src, src_rs, vd, vert, (hipStream_t)st);
+}
+
+int phl_blur_axis(phl_lattice *lat, int axis, const float *vin, float *vout, int vd, phl_stream st)
+{
+    if (!lat || axis < 0 || axis > lat->d || vd < 0 || vin == vout) { phl_set_error("phl_blur_axis: bad arguments"); return PHL_ERR_INVALID; }
+    device_guard g(lat->device);
+    return phl_launch_blur(lat, axis, vin, vout, vd, (hipStream_t)st);
+}
+
+int phl_slice(phl_lattice *lat, const float *vert, int vd, float *out, int64_t out_rs, const float *sub, int64_t sub_rs,
+              unsigned flags, phl_stream st)
+{
+    if (!lat || vd < 0) { phl_set_error("phl_slice: bad arguments"); return PHL_ERR_INVALID; }
+    device_guard g(lat->device);
+    return phl_launch_slice(lat, vert, vd, out, out_rs, sub, sub_rs, flags, (hipStream_t)st);
+}
+
+int phl_filter(phl_lattice *lat, const float *src, int vd, int64_t src_rs, int64_t src_cs, float *out, int64_t out_rs,
+               int64_t out_cs, unsigned flags, phl_stream stream)
+{
+    if (!lat || vd < 0) { phl_set_error("phl_filter: bad arguments"); return PHL_ERR_INVALID; }
+    const int64_t n = lat->n;
+    if (n == 0 || vd == 0) return PHL_OK;
+    if (!src || !out) { phl_set_error("phl_filter: NULL src/out"); return PHL_ERR_INVALID; }
+    if (src == out) { phl_set_error("phl_filter: out may not alias src"); return PHL_ERR_INVALID; }
+    hipStream_t st = (hipStream_t)stream;
+    device_guard g(lat->device);
+    int rc = phl_reserve(lat, vd);
+    if (rc) return rc;
+
+    // pixel-major rows are consumed in place; anything else (e.g. the [n,L] view of an NCHW
+    // tensor, gaussian_matrix.py:348) is staged through one coalesced transpose
+    const float *src_eff = src;
+    int64_t src_eff_rs = src_rs;
+    float *out_eff = out;
+    int64_t out_eff_rs = out_rs;
+    const bool stage_src = (src_cs != 1) && vd > 1;
+    const bool stage_dst = (out_cs != 1) && vd > 1;
+    if (stage_src || stage_dst) {
+        const int64_t need = n * (int64_t)vd;
+        if (need > lat->stage_elems) {
+            int64_t c0 = lat->stage_elems, c1 = lat->stage_elems;
+            rc = grow(&lat->stage_in, &c0, need);
+            if (!rc) rc = grow(&lat->stage_out, &c1, need);
+            if (rc) { lat->stage_elems = 0; return rc; }
+            lat->stage_elems = need;
+        }
+    }
+    if (stage_src) {
+        rc = phl_launch_copy2d(src, src_rs, src_cs, lat->stage_in, vd, 1, n, vd, st);
+        if (rc) return rc;
+        src_eff = lat->stage_in;
+        src_eff_rs = vd;
+    }
+    if (stage_dst) {
+        out_eff = lat->stage_out;
+        out_eff_rs = vd;
+    }
+
+    rc = phl_launch_splat(lat, src_eff, src_eff_rs, vd, lat->buf[0], st);
+    if (rc) return rc;
+    int cur = 0;
+    for (int axis = 0; axis <= lat->d; axis++) {  // axis order 0..d, Jacobi ping-pong (:498, :530-532)
+        rc = phl_launch_blur(lat, axis, lat->buf[cur], lat->buf[cur ^ 1], vd, st);
+        if (rc) return rc;
+        cur ^= 1;
+    }
+    const float *sub = (flags & PHL_FILTER_SUBTRACT_INPUT) ? src_eff : nullptr;
+    rc = phl_launch_slice(lat, lat->buf[cur], vd, out_eff, out_eff_rs, sub, src_eff_rs, flags, st);
+    if (rc) return rc;
+    if (stage_dst) rc = phl_launch_copy2d(lat->stage_out, vd, 1, out, out_rs, out_cs, n, vd, st);
+    return rc;
+}
+
+int phl_filter_once(const float *src, int vd, int64_t src_rs, int64_t src_cs, const float *ref, int d, int64_t ref_rs,
+                    int64_t ref_cs, int64_t n, float *out, int64_t out_rs, int64_t out_cs, unsigned flags, int device,
+                    phl_stream stream)
+{
+    phl_lattice *lat = nullptr;
+    int rc = phl_build(&lat, ref, n, d, ref_rs, ref_cs, device, stream);
+    if (rc) return rc;
+    rc = phl_filter(lat, src, vd, src_rs, src_cs, out, out_rs, out_cs, flags, stream);
+    if (rc == PHL_OK) {
+        device_guard g(device);
+        hipError_t e = hipStreamSynchronize((hipStream_t)stream);  // workspace dies with the lattice
+        if (e != hipSuccess) rc = phl_hip_fail(e, "hipStreamSynchronize", __FILE__, __LINE__);
+    }
+    phl_destroy(lat);
+    return rc;
+}
+
+int phl_get_keys(phl_lattice *lat, int16_t *keys)
+{
+    if (!lat || !keys) { phl_set_error("phl_get_keys: bad arguments"); return PHL_ERR_INVALID; }
+    if (lat->M == 0) return PHL_OK;
+    device_guard g(lat->device);
+    PHL_HIP(hipDeviceSynchronize());
+    PHL_HIP(hipMemcpy(keys, lat->vkeys, sizeof(int16_t) * (size_t)lat->M * lat->d, hipMemcpyDeviceToHost));
+    return PHL_OK;
+}
+
+int phl_get_replay(phl_lattice *lat, int32_t *vid, float *w)
+{
+    if (!lat || !vid || !w) { phl_set_error("phl_get_replay: bad arguments"); return PHL_ERR_INVALID; }
+    if (lat->N == 0) return PHL_OK;
+    device_guard g(lat->device);
+    std::vector<phl_replay_t> h((size_t)lat->N);
+    PHL_HIP(hipDeviceSynchronize());
+    PHL_HIP(hipMemcpy(h.data(), lat->replay, sizeof(phl_replay_t) * h.size(), hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < h.size(); i++) { vid[i] = h[i].vid; w[i] = h[i].w; }
+    return PHL_OK;
+}
+
+int phl_get_neighbors(phl_lattice *lat, int32_t *nbr)
+{
+    if (!lat || !nbr) { phl_set_error("phl_get_neighbors: bad arguments"); return PHL_ERR_INVALID; }
+    if (lat->M == 0) return PHL_OK;
+    device_guard g(lat->device);
+    PHL_HIP(hipDeviceSynchronize());
+    PHL_HIP(hipMemcpy(nbr, lat->nbr, sizeof(int32_t) * (size_t)lat->M * (lat->d + 1) * 2, hipMemcpyDeviceToHost));
+    return PHL_OK;
+}
+
+int phl_get_splat_lists(phl_lattice *lat, int32_t *ptr, int32_t *pixel, float *w)
+{
+    if (!lat || !ptr || !pixel || !w) { phl_set_error("phl_get_splat_lists: bad arguments"); return PHL_ERR_INVALID; }
+    if (lat->N == 0) { ptr[0] = 0; return PHL_OK; }
+    device_guard g(lat->device);
+    std::vector<phl_contrib_t> h((size_t)lat->N);
+    PHL_HIP(hipDeviceSynchronize());
+    PHL_HIP(hipMemcpy(ptr, lat->csr_ptr, sizeof(int32_t) * ((size_t)lat->M + 1), hipMemcpyDeviceToHost));
+    PHL_HIP(hipMemcpy(h.data(), lat->csr, sizeof(phl_contrib_t) * h.size(), hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < h.size(); i++) { pixel[i] = h[i].pixel; w[i] = h[i].w; }
+    return PHL_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,496 @@
+// phl_build.hip -- lattice construction on gfx950 (runs once per `ref`, then cached).
+//
+// Replaces, for all n pixels at once, the geometry half of the reference's sequential
+// splat() loop (crf/lattice/lite/permutohedral.h:376-447,458-460), its insertion-ordered hash
+// table (:29-169) and the per-axis neighbour lookups of blur() (:504-522).
+//
+// Pipeline (one kernel each, all on the caller's stream):
+//   elevate    per pixel: elevate to H_d, nearest remainder-0 point, rank, barycentric
+//              weights -> d+1 candidate keys (int16[d]) + weights            (:380-447)
+//   insert     lock-free open addressing: slot <- atomicCAS(EMPTY, e), equal keys fold to the
+//              MINIMUM candidate index with atomicMin  => deterministic representative
+//   flag+scan  representative candidates, exclusive scan => vertex id = first-touch rank,
+//              i.e. exactly the reference's insertion order                   (:70-77)
+//   assign     vertex keys [M][d]; table now maps key -> vertex id
+//   count/scan/fill/sort   transpose of the replay matrix: per vertex the (pixel, weight)
+//              list in ascending pixel order, so that splat is a deterministic segmented
+//              sum with the reference's own accumulation order (no float atomics)
+//   neighbors  [d+1][M][2] blur neighbour ids, -1 where the vertex does not exist (:516-522)
+//
+// The whole translation unit is compiled with -ffp-contract=off: elevate must round exactly
+// like the reference's scalar C++ (mul and add separately) so that keys, ranks and weights
+// are bit-identical to the CPU path.
+#include <vector>
+
+#include "phl_internal.h"
+
+namespace {
+
+struct sf_t {
+    float v[PHL_MAX_D];
+};
+
+// ------------------------------------------------------------------------------------------
+// elevate: one thread per pixel, everything in registers (D is a template parameter so that
+// all loops unroll and no array is runtime-indexed).
+template <int D>
+__global__ __launch_bounds__(256) void k_elevate(const float *__restrict__ ref, int64_t rs, int64_t cs, int64_t n,
+                                                 sf_t sf, int16_t *__restrict__ ckeys,
+                                                 phl_replay_t *__restrict__ replay, int *__restrict__ err)
+{
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    float pos[D];
+#pragma unroll
+    for (int i = 0; i < D; i++) pos[i] = ref[p * rs + i * cs];
+
+    // permutohedral.h:380-384 (expression order kept)
+    float el[D + 1];
+    el[D] = (float)(-D) * pos[D - 1] * sf.v[D - 1];
+#pragma unroll
+    for (int i = D - 1; i > 0; i--)
+        el[i] = (el[i + 1] - (float)i * pos[i - 1] * sf.v[i - 1]) + (float)(i + 2) * pos[i] * sf.v[i];
+    el[0] = el[1] + 2.0f * pos[0] * sf.v[0];
+
+    // :387-403
+    const float scale = 1.0f / (float)(D + 1);
+    int greedy[D + 1];
+    int sum = 0;
+#pragma unroll
+    for (int i = 0; i <= D; i++) {
+        float v = el[i] * scale;
+        float up = ceilf(v) * (float)(D + 1);
+        float down = floorf(v) * (float)(D + 1);
+        greedy[i] = (up - el[i] < el[i] - down) ? (int)up : (int)down;
+        sum += greedy[i];
+    }
+    sum = (int)((float)sum * scale);
+
+    // :407-411  (ties go to the later index)
+    int rank[D + 1];
+#pragma unroll
+    for (int i = 0; i <= D; i++) rank[i] = 0;
+#pragma unroll
+    for (int i = 0; i < D; i++)
+#pragma unroll
+        for (int j = i + 1; j <= D; j++) {
+            bool lt = (el[i] - (float)greedy[i]) < (el[j] - (float)greedy[j]);
+            rank[i] += lt ? 1 : 0;
+            rank[j] += lt ? 0 : 1;
+        }
+
+    // :413-433
+    if (sum > 0) {
+#pragma unroll
+        for (int i = 0; i <= D; i++) {
+            if (rank[i] >= D + 1 - sum) { greedy[i] -= D + 1; rank[i] += sum - (D + 1); }
+            else rank[i] += sum;
+        }
+    } else if (sum < 0) {
+#pragma unroll
+        for (int i = 0; i <= D; i++) {
+            if (rank[i] < -sum) { greedy[i] += D + 1; rank[i] += (D + 1) + sum; }
+            else rank[i] += sum;
+        }
+    }
+
+    // :436-441  barycentric; selects instead of runtime-indexed stores keep it in registers
+    float bary[D + 2];
+#pragma unroll
+    for (int k = 0; k <= D + 1; k++) bary[k] = 0.0f;
+#pragma unroll
+    for (int i = 0; i <= D; i++) {
+        float t = (el[i] - (float)greedy[i]) * scale;
+#pragma unroll
+        for (int k = 0; k <= D + 1; k++) {
+            if (k == D - rank[i]) bary[k] = bary[k] + t;
+            if (k == D + 1 - rank[i]) bary[k] = bary[k] - t;
+        }
+    }
+    bary[0] = bary[0] + (1.0f + bary[D + 1]);
+
+    // :444-447, :458-460
+    bool bad = false;
+    int16_t *kout = ckeys + p * (int64_t)((D + 1) * D);
+    phl_replay_t *rout = replay + p * (D + 1);
+#pragma unroll
+    for (int r = 0; r <= D; r++) {
+#pragma unroll
+        for (int i = 0; i < D; i++) {
+            int c = greedy[i] + (rank[i] <= D - r ? r : r - (D + 1));  // canonical[r][rank], :346-351
+            bad |= (c < -32768) | (c > 32767);
+            kout[r * D + i] = (int16_t)c;
+        }
+        rout[r].w = bary[r];
+    }
+    if (bad) atomicOr(err, 1);
+}
+
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t mix_begin() { return 0x811C9DC5u; }
+__device__ __forceinline__ uint32_t mix_step(uint32_t h, int c) { return (h ^ (uint32_t)(uint16_t)c) * 0x01000193u; }
+__device__ __forceinline__ uint32_t mix_end(uint32_t h)
+{
+    h ^= h >> 15; h *= 0x2C1B3C6Du;
+    h ^= h >> 12; h *= 0x297A2D39u;
+    h ^= h >> 15;
+    return h;
+}
+
+// One thread per candidate (pixel, remainder).  table[slot] ends up holding the SMALLEST
+// candidate index among all candidates with that key.  ckeys was written by the previous
+// launch, and the index read back from the atomic is always a candidate with an equal-or-
+// different key that is fully written, so no in-kernel hand-off of plain data is needed.
+__global__ __launch_bounds__(256) void k_insert(const int16_t *__restrict__ ckeys, int d, int N, int *table,
+                                                uint32_t mask, int *__restrict__ slot_of)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= N) return;
+    const int16_t *key = ckeys + (int64_t)e * d;
+    uint32_t h = mix_begin();
+    for (int i = 0; i < d; i++) h = mix_step(h, key[i]);
+    h = mix_end(h) & mask;
+    for (;;) {
+        int prev = atomicCAS(&table[h], PHL_EMPTY, e);
+        if (prev == PHL_EMPTY) break;
+        const int16_t *other = ckeys + (int64_t)prev * d;
+        bool same = true;
+        for (int i = 0; i < d; i++) same &= (other[i] == key[i]);
+        if (same) {
+            if (e < prev) atomicMin(&table[h], e);
+            break;
+        }
+        h = (h + 1) & mask;
+    }
+    slot_of[e] = (int)h;
+}
+
+__global__ __launch_bounds__(256) void k_flag(const int *__restrict__ table, const int *__restrict__ slot_of, int N,
+                                              int *__restrict__ flag)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= N) return;
+    flag[e] = (table[slot_of[e]] == e) ? 1 : 0;
+}
+
+__global__ __launch_bounds__(256) void k_assign(const int *__restrict__ flag, const int *__restrict__ rankv,
+                                                const int *__restrict__ slot_of, const int16_t *__restrict__ ckeys,
+                                                int d, int N, int *table, int16_t *__restrict__ vkeys)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= N || !flag[e]) return;
+    const int vid = rankv[e];
+    for (int i = 0; i < d; i++) vkeys[(int64_t)vid * d + i] = ckeys[(int64_t)e * d + i];
+    table[slot_of[e]] = -(vid + 1);
+}
+
+__global__ __launch_bounds__(256) void k_count(const int *__restrict__ table, const int *__restrict__ slot_of, int N,
+                                               phl_replay_t *__restrict__ replay, int *cnt)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= N) return;
+    const int vid = -(table[slot_of[e]] + 1);
+    replay[e].vid = vid;
+    atomicAdd(&cnt[vid], 1);
+}
+
+__global__ __launch_bounds__(256) void k_fill(const phl_replay_t *__restrict__ replay, const int *__restrict__ ptr,
+                                              int *cursor, int N, int dp1, phl_contrib_t *__restrict__ tmp)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= N) return;
+    const phl_replay_t r = replay[e];
+    const int pos = ptr[r.vid] + atomicAdd(&cursor[r.vid], 1);
+    phl_contrib_t c;
+    c.pixel = e / dp1;
+    c.w = r.w;
+    tmp[pos] = c;
+}
+
+// One wave per vertex: rank-sort its contribution list by pixel index (pixels are distinct
+// inside a list because the d+1 vertices of one pixel's simplex are distinct).
+__global__ __launch_bounds__(256) void k_sort_lists(const phl_contrib_t *__restrict__ tmp, const int *__restrict__ ptr,
+                                                    int M, phl_contrib_t *__restrict__ out)
+{
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int nwaves = (gridDim.x * blockDim.x) >> 6;
+    for (int v = wave; v < M; v += nwaves) {
+        const int beg = ptr[v], k = ptr[v + 1] - beg;
+        for (int i0 = 0; i0 < k; i0 += 64) {
+            const bool valid = (i0 + lane) < k;
+            phl_contrib_t mine;
+            mine.pixel = 0x7FFFFFFF;
+            mine.w = 0.f;
+            if (valid) mine = tmp[beg + i0 + lane];
+            int rank = 0;
+            for (int j0 = 0; j0 < k; j0 += 64) {
+                const int other = (j0 + lane) < k ? tmp[beg + j0 + lane].pixel : 0x7FFFFFFF;
+                const int cnt = min(64, k - j0);
+                for (int t = 0; t < cnt; t++) rank += (__shfl(other, t) < mine.pixel) ? 1 : 0;
+            }
+            if (valid) out[beg + rank] = mine;
+        }
+    }
+}
+
+// Thread per (axis, vertex): neighbour keys are key +- 1 in every stored coordinate, with
+// coordinate `axis` set to key[axis] -+ d; for axis == d the touched coordinate is the implied
+// (d+1)-th one, i.e. all d stored coordinates move by +-1 (permutohedral.h:504-509).
+__global__ __launch_bounds__(256) void k_neighbors(const int16_t *__restrict__ vkeys, int d, int M,
+                                                   const int *__restrict__ table, uint32_t mask,
+                                                   int *__restrict__ nbr)
+{
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)M * (d + 1)) return;
+    const int axis = (int)(idx / M);
+    const int v = (int)(idx - (int64_t)axis * M);
+    const int16_t *key = vkeys + (int64_t)v * d;
+    int res[2];
+    for (int side = 0; side < 2; side++) {
+        const int step = side == 0 ? 1 : -1;  // side 0 = neighbor1 (vm1), side 1 = neighbor2 (vp1)
+        uint32_t h = mix_begin();
+        for (int i = 0; i < d; i++) {
+            int c = (i == axis) ? key[i] - step * d : key[i] + step;
+            h = mix_step(h, (int16_t)c);
+        }
+        h = mix_end(h) & mask;
+        int found = -1;
+        for (;;) {
+            const int t = table[h];
+            if (t == PHL_EMPTY) break;
+            const int vid = -(t + 1);
+            const int16_t *other = vkeys + (int64_t)vid * d;
+            bool same = true;
+            for (int i = 0; i < d; i++) {
+                int c = (i == axis) ? key[i] - step * d : key[i] + step;
+                same &= (other[i] == (int16_t)c);
+            }
+            if (same) { found = vid; break; }
+            h = (h + 1) & mask;
+        }
+        res[side] = found;
+    }
+    nbr[idx * 2 + 0] = res[0];
+    nbr[idx * 2 + 1] = res[1];
+}
+
+__global__ void k_fill_i32(int *p, int64_t n, int value)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) p[i] = value;
+}
+
+// ------------------------------------------------------------------------------------------
+// exclusive scan of int32 (three launches; out has n+1 entries, out[n] = total)
+constexpr int SCAN_T = 256, SCAN_I = 8, SCAN_TILE = SCAN_T * SCAN_I;
+
+__device__ __forceinline__ int block_exclusive_scan(int x, int *total)
+{
+    __shared__ int wsum[SCAN_T / 64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int incl = x;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        int y = __shfl_up(incl, o);
+        if (lane >= o) incl += y;
+    }
+    if (lane == 63) wsum[w] = incl;
+    __syncthreads();
+    int base = 0, tot = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_T / 64; i++) {
+        if (i < w) base += wsum[i];
+        tot += wsum[i];
+    }
+    __syncthreads();
+    *total = tot;
+    return base + incl - x;
+}
+
+__global__ __launch_bounds__(SCAN_T) void k_scan_tile(const int *__restrict__ in, int *__restrict__ out,
+                                                      int *__restrict__ tile_sums, int n)
+{
+    const int base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_I;
+    int v[SCAN_I], s = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_I; i++) {
+        v[i] = (base + i) < n ? in[base + i] : 0;
+        s += v[i];
+    }
+    int tot;
+    int ex = block_exclusive_scan(s, &tot);
+#pragma unroll
+    for (int i = 0; i < SCAN_I; i++) {
+        if ((base + i) < n) out[base + i] = ex;
+        ex += v[i];
+    }
+    if (threadIdx.x == 0) tile_sums[blockIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(SCAN_T) void k_scan_sums(int *tile_sums, int ntiles, int *total_out)
+{
+    __shared__ int carry_s;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (int base = 0; base < ntiles; base += SCAN_T) {
+        const int i = base + threadIdx.x;
+        const int x = i < ntiles ? tile_sums[i] : 0;
+        int tot;
+        const int ex = block_exclusive_scan(x, &tot);
+        const int carry = carry_s;
+        if (i < ntiles) tile_sums[i] = carry + ex;
+        __syncthreads();
+        if (threadIdx.x == 0) carry_s = carry + tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *total_out = carry_s;
+}
+
+__global__ __launch_bounds__(SCAN_T) void k_scan_add(int *__restrict__ out, const int *__restrict__ tile_sums, int n)
+{
+    const int base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_I;
+    const int add = tile_sums[blockIdx.x];
+#pragma unroll
+    for (int i = 0; i < SCAN_I; i++)
+        if ((base + i) < n) out[base + i] += add;
+}
+
+int exclusive_scan(const int *in, int *out /* n+1 */, int n, int *tile_sums, hipStream_t st)
+{
+    if (n <= 0) {
+        PHL_HIP(hipMemsetAsync(out, 0, sizeof(int), st));
+        return PHL_OK;
+    }
+    const int ntiles = (n + SCAN_TILE - 1) / SCAN_TILE;
+    hipLaunchKernelGGL(k_scan_tile, dim3(ntiles), dim3(SCAN_T), 0, st, in, out, tile_sums, n);
+    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(SCAN_T), 0, st, tile_sums, ntiles, out + n);
+    hipLaunchKernelGGL(k_scan_add, dim3(ntiles), dim3(SCAN_T), 0, st, out, tile_sums, n);
+    PHL_HIP(hipGetLastError());
+    return PHL_OK;
+}
+
+struct temp_pool {
+    std::vector<void *> ptrs;
+    ~temp_pool()
+    {
+        for (void *p : ptrs) (void)hipFree(p);
+    }
+    template <typename T>
+    hipError_t get(T **out, size_t count)
+    {
+        void *p = nullptr;
+        hipError_t e = hipMalloc(&p, (count ? count : 1) * sizeof(T));
+        if (e == hipSuccess) ptrs.push_back(p);
+        *out = (T *)p;
+        return e;
+    }
+};
+
+template <int D>
+void launch_elevate(const float *ref, int64_t rs, int64_t cs, int64_t n, const sf_t &sf, int16_t *ckeys,
+                    phl_replay_t *replay, int *err, hipStream_t st)
+{
+    const unsigned blocks = (unsigned)((n + 255) / 256);
+    hipLaunchKernelGGL(k_elevate<D>, dim3(blocks), dim3(256), 0, st, ref, rs, cs, n, sf, ckeys, replay, err);
+}
+
+}  // namespace
+
+int phl_build_device(phl_lattice *lat, const float *ref, int64_t rs, int64_t cs, hipStream_t st)
+{
+    const int d = lat->d;
+    const int64_t n = lat->n;
+    const int64_t N64 = n * (d + 1);
+    lat->N = N64;
+    lat->M = 0;
+    if (n == 0) return PHL_OK;
+    const int N = (int)N64;
+
+    // scaleFactor exactly as the reference computes it on the host (permutohedral.h:354-371)
+    sf_t sf;
+    for (int i = 0; i < PHL_MAX_D; i++) sf.v[i] = 0.f;
+    for (int i = 0; i < d; i++) {
+        sf.v[i] = 1.0f / (sqrtf((float)(i + 1) * (i + 2)));
+        sf.v[i] *= (d + 1) * sqrtf(2.0 / 3);
+    }
+
+    uint64_t cap = 1024;
+    while (cap < (uint64_t)N * 2) cap <<= 1;
+    const uint32_t mask = (uint32_t)(cap - 1);
+
+    temp_pool tmp;
+    int16_t *ckeys;
+    int *table, *slot_of, *flag, *rankv, *tile_sums, *err, *cursor;
+    phl_contrib_t *csr_tmp;
+    PHL_HIP(tmp.get(&ckeys, (size_t)N * d));
+    PHL_HIP(tmp.get(&table, cap));
+    PHL_HIP(tmp.get(&slot_of, (size_t)N));
+    PHL_HIP(tmp.get(&flag, (size_t)N));
+    PHL_HIP(tmp.get(&rankv, (size_t)N + 1));
+    PHL_HIP(tmp.get(&tile_sums, (size_t)N / SCAN_TILE + 2));
+    PHL_HIP(tmp.get(&err, 1));
+    PHL_HIP(hipMalloc((void **)&lat->replay, sizeof(phl_replay_t) * (size_t)N));
+    PHL_HIP(hipMemsetAsync(err, 0, sizeof(int), st));
+
+    switch (d) {
+#define PHL_CASE(D) case D: launch_elevate<D>(ref, rs, cs, n, sf, ckeys, lat->replay, err, st); break;
+        PHL_CASE(1) PHL_CASE(2) PHL_CASE(3) PHL_CASE(4) PHL_CASE(5) PHL_CASE(6) PHL_CASE(7) PHL_CASE(8)
+        PHL_CASE(9) PHL_CASE(10) PHL_CASE(11) PHL_CASE(12) PHL_CASE(13) PHL_CASE(14) PHL_CASE(15) PHL_CASE(16)
+#undef PHL_CASE
+        default: phl_set_error("d=%d unsupported (1..%d)", d, PHL_MAX_D); return PHL_ERR_UNSUPPORTED;
+    }
+    const unsigned gN = (unsigned)((N + 255) / 256);
+    hipLaunchKernelGGL(k_fill_i32, dim3(2048), dim3(256), 0, st, table, (int64_t)cap, PHL_EMPTY);
+    hipLaunchKernelGGL(k_insert, dim3(gN), dim3(256), 0, st, ckeys, d, N, table, mask, slot_of);
+    hipLaunchKernelGGL(k_flag, dim3(gN), dim3(256), 0, st, table, slot_of, N, flag);
+    PHL_HIP(hipGetLastError());
+    int rc = exclusive_scan(flag, rankv, N, tile_sums, st);
+    if (rc) return rc;
+
+    int host[2] = {0, 0};
+    PHL_HIP(hipMemcpyAsync(&host[0], rankv + N, sizeof(int), hipMemcpyDeviceToHost, st));
+    PHL_HIP(hipMemcpyAsync(&host[1], err, sizeof(int), hipMemcpyDeviceToHost, st));
+    PHL_HIP(hipStreamSynchronize(st));
+    if (host[1]) {
+        phl_set_error("lattice coordinate outside int16 (reference keys are `short`, permutohedral.h:39,398); "
+                      "rescale the features");
+        return PHL_ERR_KEY_RANGE;
+    }
+    const int M = host[0];
+    lat->M = M;
+
+    PHL_HIP(hipMalloc((void **)&lat->vkeys, sizeof(int16_t) * (size_t)M * d));
+    PHL_HIP(hipMalloc((void **)&lat->csr_ptr, sizeof(int32_t) * ((size_t)M + 1)));
+    PHL_HIP(hipMalloc((void **)&lat->csr, sizeof(phl_contrib_t) * (size_t)N));
+    PHL_HIP(hipMalloc((void **)&lat->nbr, sizeof(int32_t) * (size_t)M * (d + 1) * 2));
+    PHL_HIP(tmp.get(&cursor, (size_t)M * 2));  // cnt | cursor
+    PHL_HIP(tmp.get(&csr_tmp, (size_t)N));
+    int *cnt = cursor + M;
+    PHL_HIP(hipMemsetAsync(cursor, 0, sizeof(int) * (size_t)M * 2, st));
+
+    hipLaunchKernelGGL(k_assign, dim3(gN), dim3(256), 0, st, flag, rankv, slot_of, ckeys, d, N, table, lat->vkeys);
+    hipLaunchKernelGGL(k_count, dim3(gN), dim3(256), 0, st, table, slot_of, N, lat->replay, cnt);
+    PHL_HIP(hipGetLastError());
+    rc = exclusive_scan(cnt, lat->csr_ptr, M, tile_sums, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_fill, dim3(gN), dim3(256), 0, st, lat->replay, lat->csr_ptr, cursor, N, d + 1, csr_tmp);
+    {
+        const int waves_needed = M;
+        int blocks = (waves_needed + 3) / 4;
+        if (blocks > 256 * 16) blocks = 256 * 16;
+        hipLaunchKernelGGL(k_sort_lists, dim3(blocks), dim3(256), 0, st, csr_tmp, lat->csr_ptr, M, lat->csr);
+    }
+    {
+        const int64_t tot = (int64_t)M * (d + 1);
+        hipLaunchKernelGGL(k_neighbors, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, lat->vkeys, d, M, table,
+                           mask, lat->nbr);
+    }
+    PHL_HIP(hipGetLastError());
+    PHL_HIP(hipStreamSynchronize(st));  // temporaries are freed on return
+    lat->table_bytes = (int64_t)(sizeof(int16_t) * (size_t)M * d + sizeof(int32_t) * ((size_t)M + 1) +
+                                 sizeof(phl_contrib_t) * (size_t)N + sizeof(phl_replay_t) * (size_t)N +
+                                 sizeof(int32_t) * (size_t)M * (d + 1) * 2);
+    return PHL_OK;
+}

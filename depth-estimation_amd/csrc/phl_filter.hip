@@ -1,0 +1,354 @@
+// phl_filter.hip -- the hot path: splat -> blur (d+1 axes) -> slice on gfx950.
+//
+// All three stages are HBM/L2-bound row gathers over fp32 rows of `vd` channels (no MFMA:
+// arithmetic intensity < 1 flop/byte).  Common shape of every kernel:
+//
+//   * a row (one lattice vertex or one pixel, vd channels) is owned by a group of LPR lanes,
+//     each lane moving VEC=4 consecutive channels with one 16-byte global_load/store_dwordx4
+//     (VEC=1 fallback for vd % 4 != 0 or unaligned rows).  vd = 256 -> one 64-lane wavefront
+//     reads a whole 1 KiB row per instruction, the widest coalesced access gfx950 has;
+//   * a wavefront owns 64/LPR rows at a time and keeps several independent row loads in
+//     flight before the first use (the only latency hiding a gather has);
+//   * index data (contribution lists, neighbour ids, replay entries) is read once per row
+//     group, wave-uniform where LPR == 64 so it goes through the scalar cache.
+//
+// Numerics: compiled with -ffp-contract=off and written so that each stage rounds exactly
+// like the reference's scalar loops (crf/lattice/lite/permutohedral.h):
+//   splat  vert[v] += w * src[p]   in ascending pixel order           (:236-238, :454-455)
+//   blur   2*(0.25*a + 0.5*s + 0.25*b), Jacobi per axis               (:526, :530-532)
+//   slice  col += w * vert / (1 + 2^-d) per term                      (:480)
+// so the device results are bit-identical to the CPU path wherever the summation order is
+// defined by the algorithm (which is everywhere: the splat lists are pixel-sorted).
+#include <type_traits>
+
+#include "phl_internal.h"
+
+namespace {
+
+template <int VEC> struct vec_of;
+template <> struct vec_of<1> { using type = float; };
+template <> struct vec_of<4> { using type = float4; };
+
+template <int VEC> __device__ __forceinline__ typename vec_of<VEC>::type vzero();
+template <> __device__ __forceinline__ float vzero<1>() { return 0.f; }
+template <> __device__ __forceinline__ float4 vzero<4>() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+
+__device__ __forceinline__ float vload(const float *p, float) { return *p; }
+__device__ __forceinline__ float4 vload(const float *p, float4) { return *reinterpret_cast<const float4 *>(p); }
+__device__ __forceinline__ void vstore(float *p, float v) { *p = v; }
+__device__ __forceinline__ void vstore(float *p, float4 v) { *reinterpret_cast<float4 *>(p) = v; }
+
+// acc + w*q, mul and add rounded separately (reference: val[i] += (barycentric*value[i]))
+__device__ __forceinline__ float mac(float acc, float w, float q) { return acc + w * q; }
+__device__ __forceinline__ float4 mac(float4 acc, float w, float4 q)
+{
+    return make_float4(acc.x + w * q.x, acc.y + w * q.y, acc.z + w * q.z, acc.w + w * q.w);
+}
+__device__ __forceinline__ float fmac(float acc, float w, float q) { return __builtin_fmaf(w, q, acc); }
+__device__ __forceinline__ float4 fmac(float4 acc, float w, float4 q)
+{
+    return make_float4(__builtin_fmaf(w, q.x, acc.x), __builtin_fmaf(w, q.y, acc.y), __builtin_fmaf(w, q.z, acc.z),
+                       __builtin_fmaf(w, q.w, acc.w));
+}
+
+// reference blur arithmetic, literally (:526)
+__device__ __forceinline__ float blur3(float a, float s, float b) { return 2 * (0.25f * a + 0.5f * s + 0.25f * b); }
+__device__ __forceinline__ float4 blur3(float4 a, float4 s, float4 b)
+{
+    return make_float4(blur3(a.x, s.x, b.x), blur3(a.y, s.y, b.y), blur3(a.z, s.z, b.z), blur3(a.w, s.w, b.w));
+}
+
+// correctly rounded t / c for c = 1 + 2^-d with rc = RN(1/c): multiply, exact residual, one
+// correction (Markstein).  Equals the IEEE quotient the reference computes in every normal-
+// range case (checked exhaustively-by-sampling in tests/test_exact_divide.py).
+__device__ __forceinline__ float div_c(float t, float c, float rc)
+{
+    float q = t * rc;
+    float rem = __builtin_fmaf(-q, c, t);
+    return __builtin_fmaf(rem, rc, q);
+}
+// acc + (w*v)/c
+__device__ __forceinline__ float slice_term(float acc, float w, float v, float c, float rc)
+{
+    return acc + div_c(w * v, c, rc);
+}
+__device__ __forceinline__ float4 slice_term(float4 acc, float w, float4 v, float c, float rc)
+{
+    return make_float4(slice_term(acc.x, w, v.x, c, rc), slice_term(acc.y, w, v.y, c, rc),
+                       slice_term(acc.z, w, v.z, c, rc), slice_term(acc.w, w, v.w, c, rc));
+}
+__device__ __forceinline__ float vscale(float a, float s) { return a * s; }
+__device__ __forceinline__ float4 vscale(float4 a, float s) { return make_float4(a.x * s, a.y * s, a.z * s, a.w * s); }
+__device__ __forceinline__ float vsub(float a, float b) { return a - b; }
+__device__ __forceinline__ float4 vsub(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
+
+// wave id inside the grid, as a scalar
+__device__ __forceinline__ int wave_in_grid()
+{
+    return (int)blockIdx.x * (int)(blockDim.x >> 6) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+}
+__device__ __forceinline__ int waves_in_grid() { return (int)gridDim.x * (int)(blockDim.x >> 6); }
+
+// ------------------------------------------------------------------------------------------
+// splat: vert[v][:] = sum_{(p,w) in list(v), ascending p}  w * src[p][:]
+// Gather form of the reference's scatter: every vertex sums its own contribution list, so no
+// float atomics, and the accumulation order is the reference's pixel order.
+template <int VEC, int LPR>
+__global__ __launch_bounds__(256) void k_splat(const float *__restrict__ src, int64_t src_rs, int vd,
+                                               const int *__restrict__ ptr, const phl_contrib_t *__restrict__ csr,
+                                               int M, float *__restrict__ vert)
+{
+    using V = typename vec_of<VEC>::type;
+    constexpr int G = 64 / LPR;
+    const int lane = threadIdx.x & 63;
+    const int sub = lane / LPR;
+    const int l = lane % LPR;
+    const int64_t stride = (int64_t)waves_in_grid() * G;
+    for (int64_t v0 = (int64_t)wave_in_grid() * G; v0 < M; v0 += stride) {
+        const int64_t v = v0 + sub;
+        const bool act = v < M;
+        int beg = 0, end = 0;
+        if (act) { beg = ptr[v]; end = ptr[v + 1]; }
+        for (int c = l * VEC; c < vd; c += LPR * VEC) {
+            V acc = vzero<VEC>();
+            int e = beg;
+            for (; e + 4 <= end; e += 4) {
+                const phl_contrib_t c0 = csr[e], c1 = csr[e + 1], c2 = csr[e + 2], c3 = csr[e + 3];
+                const V q0 = vload(src + (int64_t)c0.pixel * src_rs + c, V());
+                const V q1 = vload(src + (int64_t)c1.pixel * src_rs + c, V());
+                const V q2 = vload(src + (int64_t)c2.pixel * src_rs + c, V());
+                const V q3 = vload(src + (int64_t)c3.pixel * src_rs + c, V());
+                acc = mac(acc, c0.w, q0);
+                acc = mac(acc, c1.w, q1);
+                acc = mac(acc, c2.w, q2);
+                acc = mac(acc, c3.w, q3);
+            }
+            for (; e < end; e++) {
+                const phl_contrib_t c0 = csr[e];
+                acc = mac(acc, c0.w, vload(src + (int64_t)c0.pixel * src_rs + c, V()));
+            }
+            if (act) vstore(vert + v * vd + c, acc);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// blur along one lattice axis (Jacobi): out[v] = 2*(1/4 in[n1(v)] + 1/2 in[v] + 1/4 in[n2(v)]),
+// absent neighbour = 0 (the reference never creates vertices in blur, :516-522).
+template <int VEC, int LPR>
+__global__ __launch_bounds__(256) void k_blur(const float *__restrict__ vin, float *__restrict__ vout,
+                                              const int2 *__restrict__ nbr, int M, int vd)
+{
+    using V = typename vec_of<VEC>::type;
+    constexpr int G = 64 / LPR;
+    constexpr int U = 4;  // row groups in flight per wave
+    const int lane = threadIdx.x & 63;
+    const int sub = lane / LPR;
+    const int l = lane % LPR;
+    const int64_t stride = (int64_t)waves_in_grid() * G * U;
+    for (int64_t v0 = (int64_t)wave_in_grid() * G * U; v0 < M; v0 += stride) {
+        int64_t v[U];
+        int2 nb[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            v[u] = v0 + u * G + sub;
+            nb[u] = v[u] < M ? nbr[v[u]] : make_int2(-1, -1);
+        }
+        for (int c = l * VEC; c < vd; c += LPR * VEC) {
+            V a[U], s[U], b[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                a[u] = s[u] = b[u] = vzero<VEC>();
+                if (v[u] < M) {
+                    s[u] = vload(vin + v[u] * vd + c, V());
+                    if (nb[u].x >= 0) a[u] = vload(vin + (int64_t)nb[u].x * vd + c, V());
+                    if (nb[u].y >= 0) b[u] = vload(vin + (int64_t)nb[u].y * vd + c, V());
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++)
+                if (v[u] < M) vstore(vout + v[u] * vd + c, blur3(a[u], s[u], b[u]));
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// slice: out[p][:] = sum_{r<=d} w_r * vert[v_r][:] / (1 + 2^-d)   [ - sub[p][:] ]
+template <int VEC, int LPR, bool EXACT>
+__global__ __launch_bounds__(256) void k_slice(const float *__restrict__ vert, int vd,
+                                               const phl_replay_t *__restrict__ replay, int dp1, int64_t n,
+                                               float *__restrict__ out, int64_t out_rs,
+                                               const float *__restrict__ sub_src, int64_t sub_rs, float cdiv,
+                                               float rcdiv)
+{
+    using V = typename vec_of<VEC>::type;
+    constexpr int G = 64 / LPR;
+    const int lane = threadIdx.x & 63;
+    const int sub = lane / LPR;
+    const int l = lane % LPR;
+    const int64_t stride = (int64_t)waves_in_grid() * G;
+    for (int64_t p0 = (int64_t)wave_in_grid() * G; p0 < n; p0 += stride) {
+        const int64_t p = p0 + sub;
+        if (p >= n) continue;
+        const phl_replay_t *rp = replay + p * dp1;
+        for (int c = l * VEC; c < vd; c += LPR * VEC) {
+            V acc = vzero<VEC>();
+            int r = 0;
+            for (; r + 3 <= dp1; r += 3) {
+                const phl_replay_t r0 = rp[r], r1 = rp[r + 1], r2 = rp[r + 2];
+                const V q0 = vload(vert + (int64_t)r0.vid * vd + c, V());
+                const V q1 = vload(vert + (int64_t)r1.vid * vd + c, V());
+                const V q2 = vload(vert + (int64_t)r2.vid * vd + c, V());
+                if (EXACT) {
+                    acc = slice_term(acc, r0.w, q0, cdiv, rcdiv);
+                    acc = slice_term(acc, r1.w, q1, cdiv, rcdiv);
+                    acc = slice_term(acc, r2.w, q2, cdiv, rcdiv);
+                } else {
+                    acc = fmac(acc, r0.w, q0);
+                    acc = fmac(acc, r1.w, q1);
+                    acc = fmac(acc, r2.w, q2);
+                }
+            }
+            for (; r < dp1; r++) {
+                const phl_replay_t r0 = rp[r];
+                const V q0 = vload(vert + (int64_t)r0.vid * vd + c, V());
+                if (EXACT) acc = slice_term(acc, r0.w, q0, cdiv, rcdiv);
+                else acc = fmac(acc, r0.w, q0);
+            }
+            if (!EXACT) acc = vscale(acc, rcdiv);
+            if (sub_src) acc = vsub(acc, vload(sub_src + p * sub_rs + c, V()));
+            vstore(out + p * out_rs + c, acc);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// strided 2-D copy through a padded 64x64 LDS tile: both sides coalesced when either stride
+// of each side is 1 (NCHW <-> pixel-major staging for BatchedAdjacency-style views,
+// gaussian_matrix.py:348-349).
+__global__ __launch_bounds__(256) void k_copy2d(const float *__restrict__ src, int64_t srs, int64_t scs,
+                                                float *__restrict__ dst, int64_t drs, int64_t dcs, int64_t rows,
+                                                int cols)
+{
+    __shared__ float tile[64][65];
+    const int64_t r0 = (int64_t)blockIdx.x * 64;
+    const int c0 = blockIdx.y * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // 64 x 4
+    // read: make the unit-stride source dimension the fast one
+    const bool src_col_fast = (scs == 1) || (srs != 1);
+    for (int k = ty; k < 64; k += 4) {
+        int rr = src_col_fast ? k : tx, cc = src_col_fast ? tx : k;
+        if (r0 + rr < rows && c0 + cc < cols) tile[rr][cc] = src[(r0 + rr) * srs + (int64_t)(c0 + cc) * scs];
+    }
+    __syncthreads();
+    const bool dst_col_fast = (dcs == 1) || (drs != 1);
+    for (int k = ty; k < 64; k += 4) {
+        int rr = dst_col_fast ? k : tx, cc = dst_col_fast ? tx : k;
+        if (r0 + rr < rows && c0 + cc < cols) dst[(r0 + rr) * drs + (int64_t)(c0 + cc) * dcs] = tile[rr][cc];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+inline int pick_lpr(int vd, int vec)
+{
+    const int need = (vd + vec - 1) / vec;
+    if (need >= 64) return 64;
+    if (need >= 16) return 16;
+    if (need >= 4) return 4;
+    return 1;
+}
+
+inline unsigned grid_for(int64_t rows, int rows_per_wave)
+{
+    int64_t waves = (rows + rows_per_wave - 1) / rows_per_wave;
+    int64_t blocks = (waves + 3) / 4;
+    const int64_t cap = 256 * 8;  // 8 blocks of 4 waves per CU: full occupancy, grid-stride the rest
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    return (unsigned)blocks;
+}
+
+template <typename F>
+inline void dispatch_lpr(int lpr, F &&f)
+{
+    switch (lpr) {
+        case 64: f(std::integral_constant<int, 64>{}); break;
+        case 16: f(std::integral_constant<int, 16>{}); break;
+        case 4: f(std::integral_constant<int, 4>{}); break;
+        default: f(std::integral_constant<int, 1>{}); break;
+    }
+}
+
+}  // namespace
+
+int phl_launch_splat(const phl_lattice *lat, const float *src, int64_t src_rs, int vd, float *vert, hipStream_t st)
+{
+    const int M = (int)lat->M;
+    if (M == 0 || vd == 0) return PHL_OK;
+    const bool v4 = (vd % 4 == 0) && (src_rs % 4 == 0) && aligned16(src) && aligned16(vert);
+    const int lpr = pick_lpr(vd, v4 ? 4 : 1);
+    const unsigned grid = grid_for(M, 64 / lpr);
+    dispatch_lpr(lpr, [&](auto L) {
+        constexpr int LPR = decltype(L)::value;
+        if (v4) k_splat<4, LPR><<<dim3(grid), dim3(256), 0, st>>>(src, src_rs, vd, lat->csr_ptr, lat->csr, M, vert);
+        else k_splat<1, LPR><<<dim3(grid), dim3(256), 0, st>>>(src, src_rs, vd, lat->csr_ptr, lat->csr, M, vert);
+    });
+    PHL_HIP(hipGetLastError());
+    return PHL_OK;
+}
+
+int phl_launch_blur(const phl_lattice *lat, int axis, const float *vin, float *vout, int vd, hipStream_t st)
+{
+    const int M = (int)lat->M;
+    if (M == 0 || vd == 0) return PHL_OK;
+    const int2 *nbr = reinterpret_cast<const int2 *>(lat->nbr) + (int64_t)axis * M;
+    const bool v4 = (vd % 4 == 0) && aligned16(vin) && aligned16(vout);
+    const int lpr = pick_lpr(vd, v4 ? 4 : 1);
+    const unsigned grid = grid_for(M, (64 / lpr) * 4);
+    dispatch_lpr(lpr, [&](auto L) {
+        constexpr int LPR = decltype(L)::value;
+        if (v4) k_blur<4, LPR><<<dim3(grid), dim3(256), 0, st>>>(vin, vout, nbr, M, vd);
+        else k_blur<1, LPR><<<dim3(grid), dim3(256), 0, st>>>(vin, vout, nbr, M, vd);
+    });
+    PHL_HIP(hipGetLastError());
+    return PHL_OK;
+}
+
+int phl_launch_slice(const phl_lattice *lat, const float *vert, int vd, float *out, int64_t out_rs, const float *sub,
+                     int64_t sub_rs, unsigned flags, hipStream_t st)
+{
+    const int64_t n = lat->n;
+    if (n == 0 || vd == 0) return PHL_OK;
+    const int dp1 = lat->d + 1;
+    // the reference's constant, computed as it computes it: 1 + powf(2, -d)   (:480)
+    const float cdiv = 1 + powf(2, -lat->d);
+    const float rcdiv = 1.0f / cdiv;
+    const bool v4 = (vd % 4 == 0) && (out_rs % 4 == 0) && aligned16(vert) && aligned16(out) &&
+                    (!sub || ((sub_rs % 4 == 0) && aligned16(sub)));
+    const int lpr = pick_lpr(vd, v4 ? 4 : 1);
+    const unsigned grid = grid_for(n, 64 / lpr);
+    const bool exact = !(flags & PHL_FILTER_FAST_SLICE);
+    dispatch_lpr(lpr, [&](auto L) {
+        constexpr int LPR = decltype(L)::value;
+#define PHL_SLICE_ARGS vert, vd, lat->replay, dp1, n, out, out_rs, sub, sub_rs, cdiv, rcdiv
+        if (v4 && exact) k_slice<4, LPR, true><<<dim3(grid), dim3(256), 0, st>>>(PHL_SLICE_ARGS);
+        else if (v4) k_slice<4, LPR, false><<<dim3(grid), dim3(256), 0, st>>>(PHL_SLICE_ARGS);
+        else if (exact) k_slice<1, LPR, true><<<dim3(grid), dim3(256), 0, st>>>(PHL_SLICE_ARGS);
+        else k_slice<1, LPR, false><<<dim3(grid), dim3(256), 0, st>>>(PHL_SLICE_ARGS);
+#undef PHL_SLICE_ARGS
+    });
+    PHL_HIP(hipGetLastError());
+    return PHL_OK;
+}
+
+int phl_launch_copy2d(const float *src, int64_t srs, int64_t scs, float *dst, int64_t drs, int64_t dcs, int64_t rows,
+                      int cols, hipStream_t st)
+{
+    if (rows == 0 || cols == 0) return PHL_OK;
+    dim3 grid((unsigned)((rows + 63) / 64), (unsigned)((cols + 63) / 64));
+    hipLaunchKernelGGL(k_copy2d, grid, dim3(256), 0, st, src, srs, scs, dst, drs, dcs, rows, cols);
+    PHL_HIP(hipGetLastError());
+    return PHL_OK;
+}

@@ -1,0 +1,66 @@
+// Internal declarations shared by the phl translation units (not part of the C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "phl.h"
+
+#define PHL_WAVE 64
+#define PHL_EMPTY 0x7FFFFFFF  // empty hash slot (larger than any candidate index)
+
+// (vertex, weight) per (pixel, remainder): the sparse n x M splat matrix, d+1 entries per
+// row.  Same content as the reference's ReplayEntry (permutohedral.h:558-561) with a vertex
+// id instead of a value offset.
+struct phl_replay_t {
+    int32_t vid;
+    float w;
+};
+// (pixel, weight): the transpose of the above, grouped by vertex and sorted by pixel.
+struct phl_contrib_t {
+    int32_t pixel;
+    float w;
+};
+
+struct phl_lattice {
+    int device;
+    int d;
+    int64_t n;
+    int64_t M;
+    int64_t N;  // n*(d+1) (pixel, remainder) pairs
+
+    int16_t *vkeys;         // [M][d]
+    phl_replay_t *replay;   // [n][d+1]
+    int32_t *csr_ptr;       // [M+1]
+    phl_contrib_t *csr;     // [N] grouped by vertex, pixel-ascending inside a group
+    int32_t *nbr;           // [d+1][M][2]
+
+    // value workspace, grown on demand
+    float *buf[2];
+    int64_t buf_elems;      // capacity of each buffer in floats
+    float *stage_in;        // [n][vd] staging for non pixel-major inputs
+    float *stage_out;
+    int64_t stage_elems;
+
+    int64_t table_bytes;    // device bytes of the persistent tables
+};
+
+// thread-local error message
+void phl_set_error(const char *fmt, ...);
+int phl_hip_fail(hipError_t e, const char *what, const char *file, int line);
+#define PHL_HIP(call)                                                              \
+    do {                                                                           \
+        hipError_t e__ = (call);                                                   \
+        if (e__ != hipSuccess) return phl_hip_fail(e__, #call, __FILE__, __LINE__); \
+    } while (0)
+
+// ---- launchers implemented in phl_build.hip ----
+int phl_build_device(phl_lattice *lat, const float *ref, int64_t rs, int64_t cs, hipStream_t st);
+
+// ---- launchers implemented in phl_filter.hip ----
+int phl_launch_splat(const phl_lattice *lat, const float *src, int64_t src_rs, int vd, float *vert, hipStream_t st);
+int phl_launch_blur(const phl_lattice *lat, int axis, const float *vin, float *vout, int vd, hipStream_t st);
+int phl_launch_slice(const phl_lattice *lat, const float *vert, int vd, float *out, int64_t out_rs,
+                     const float *sub, int64_t sub_rs, unsigned flags, hipStream_t st);
+// generic strided 2-D copy dst[r*drs + c*dcs] = src[r*srs + c*scs], rows x cols
+int phl_launch_copy2d(const float *src, int64_t srs, int64_t scs, float *dst, int64_t drs, int64_t dcs,
+                      int64_t rows, int cols, hipStream_t st);

@@ -1,0 +1,261 @@
+"""phl -- Python binding of the MI355X permutohedral-lattice filter (C ABI in include/phl.h).
+
+Thin plumbing only: torch supplies device memory and the current HIP stream, ctypes calls
+``lib/libphl.so``.  There is NO CPU implementation behind this module: if the shared library or
+a HIP device is missing, calls raise ``RuntimeError``.  CPU tensors are accepted the way the
+reference accepts them (its extension is CPU-only, crf/lattice/lite/permutohedral.h:214) but
+are computed on the GPU and copied back.
+
+Public surface
+    Lattice(ref)                 build once per feature tensor  (init-once / filter-many)
+    Lattice.filter(src, ...)     == reference ``lattice.filter(src, ref)`` for that ref
+    filter(src, ref)             drop-in for ``latticefilter`` (crf/gaussian_matrix.py:15-16);
+                                 lattices are cached per ``ref`` tensor, invisibly
+"""
+import ctypes as C
+import os
+import threading
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libphl.so")
+
+SUBTRACT_INPUT = 1
+FAST_SLICE = 2
+
+_f32p = C.c_void_p
+_lib = None
+_lib_lock = threading.Lock()
+
+
+class PhlError(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__(f"phl error {status}: {message}")
+        self.status = status
+
+
+def load_library():
+    """Load lib/libphl.so (built by ``python __graft_entry__.py`` / ``make -C csrc``)."""
+    global _lib
+    with _lib_lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} not found: the HIP extension is not built (run `python __graft_entry__.py`). "
+                "There is no CPU fallback for the lattice filter.")
+        lib = C.CDLL(LIB_PATH)
+        i64, i32, vp, u32 = C.c_int64, C.c_int, C.c_void_p, C.c_uint
+        lib.phl_version.restype = i32
+        lib.phl_last_error.restype = C.c_char_p
+        lib.phl_status_string.restype = C.c_char_p
+        lib.phl_status_string.argtypes = [i32]
+        lib.phl_device_count.restype = i32
+        lib.phl_build.argtypes = [C.POINTER(vp), vp, i64, i32, i64, i64, i32, vp]
+        lib.phl_destroy.argtypes = [vp]
+        for name in ("phl_num_pixels", "phl_num_vertices", "phl_device_bytes"):
+            getattr(lib, name).restype = i64
+            getattr(lib, name).argtypes = [vp]
+        lib.phl_num_dims.argtypes = [vp]
+        lib.phl_device.argtypes = [vp]
+        lib.phl_reserve.argtypes = [vp, i32]
+        lib.phl_filter.argtypes = [vp, vp, i32, i64, i64, vp, i64, i64, u32, vp]
+        lib.phl_filter_once.argtypes = [vp, i32, i64, i64, vp, i32, i64, i64, i64, vp, i64, i64, u32, i32, vp]
+        lib.phl_splat.argtypes = [vp, vp, i32, i64, vp, vp]
+        lib.phl_blur_axis.argtypes = [vp, i32, vp, vp, i32, vp]
+        lib.phl_slice.argtypes = [vp, vp, i32, vp, i64, vp, i64, u32, vp]
+        lib.phl_get_keys.argtypes = [vp, vp]
+        lib.phl_get_replay.argtypes = [vp, vp, vp]
+        lib.phl_get_neighbors.argtypes = [vp, vp]
+        lib.phl_get_splat_lists.argtypes = [vp, vp, vp, vp]
+        _lib = lib
+        return lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise PhlError(rc, load_library().phl_last_error().decode("utf-8", "replace"))
+
+
+def _require_gpu():
+    if not torch.cuda.is_available():
+        raise RuntimeError("phl: no HIP device visible to torch; the lattice filter has no CPU fallback")
+
+
+def _stream(device):
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _as_device(t, device):
+    if t.dtype != torch.float32:
+        # the reference extension is float-only (accessor<float,2>, permutohedral.h:214-215)
+        raise TypeError(f"phl: expected float32 tensor, got {t.dtype}")
+    return t if t.device == device else t.to(device)
+
+
+class Lattice:
+    """Permutohedral lattice of a feature tensor ``ref`` [n, d] (fp32, any strides).
+
+    Build cost is paid once; ``filter`` then runs splat -> blur -> slice for any [n, vd] values.
+    Not re-entrant: use one Lattice per concurrent stream.
+    """
+
+    def __init__(self, ref, device=None):
+        _require_gpu()
+        lib = load_library()
+        if ref.dim() != 2:
+            raise ValueError(f"ref must be [n, d], got {tuple(ref.shape)}")
+        if device is None:
+            device = ref.device if ref.is_cuda else torch.device("cuda", torch.cuda.current_device())
+        self.device = torch.device(device)
+        ref_d = _as_device(ref.detach(), self.device)
+        self.n, self.d = int(ref_d.shape[0]), int(ref_d.shape[1])
+        handle = C.c_void_p()
+        with torch.cuda.device(self.device):
+            _check(lib.phl_build(C.byref(handle), C.c_void_p(ref_d.data_ptr()), self.n, self.d, ref_d.stride(0),
+                                 ref_d.stride(1), self.device.index or 0, _stream(self.device)))
+        self._h = handle
+        self.M = int(lib.phl_num_vertices(handle))
+
+    def close(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            load_library().phl_destroy(h)
+
+    __del__ = close
+
+    @property
+    def device_bytes(self):
+        return int(load_library().phl_device_bytes(self._h))
+
+    def reserve(self, vd):
+        _check(load_library().phl_reserve(self._h, int(vd)))
+
+    # ---- hot path ---------------------------------------------------------------------------
+    def filter(self, src, subtract_input=False, fast_slice=False, out=None):
+        """``lattice.filter(src, ref)`` of the reference; result lives on ``src``'s device."""
+        if src.dim() != 2 or src.shape[0] != self.n:
+            # same text as the reference's assert (gaussian_matrix.py:429-430)
+            raise AssertionError("Incompatible shapes {}, and {}".format(tuple(src.shape), (self.n, self.d)))
+        src_d = _as_device(src.detach(), self.device)
+        vd = int(src_d.shape[1])
+        res = out if (out is not None and out.device == self.device) else torch.empty(
+            (self.n, vd), dtype=torch.float32, device=self.device)
+        flags = (SUBTRACT_INPUT if subtract_input else 0) | (FAST_SLICE if fast_slice else 0)
+        with torch.cuda.device(self.device):
+            _check(load_library().phl_filter(self._h, C.c_void_p(src_d.data_ptr()), vd, src_d.stride(0),
+                                             src_d.stride(1), C.c_void_p(res.data_ptr()), res.stride(0),
+                                             res.stride(1), flags, _stream(self.device)))
+        if out is not None and out is not res:
+            out.copy_(res)
+            return out
+        return res if src.device == self.device else res.to(src.device)
+
+    # ---- stages (profiling / parity of intermediates) ---------------------------------------
+    def splat(self, src):
+        src_d = _as_device(src.detach(), self.device)
+        assert src_d.stride(1) == 1, "stage API takes pixel-major rows"
+        vd = int(src_d.shape[1])
+        vert = torch.empty((self.M, vd), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _check(load_library().phl_splat(self._h, C.c_void_p(src_d.data_ptr()), vd, src_d.stride(0),
+                                            C.c_void_p(vert.data_ptr()), _stream(self.device)))
+        return vert
+
+    def blur_axis(self, axis, vin, vout=None):
+        vd = int(vin.shape[1])
+        vout = torch.empty_like(vin) if vout is None else vout
+        assert vin.is_contiguous() and vout.is_contiguous()
+        with torch.cuda.device(self.device):
+            _check(load_library().phl_blur_axis(self._h, int(axis), C.c_void_p(vin.data_ptr()),
+                                                C.c_void_p(vout.data_ptr()), vd, _stream(self.device)))
+        return vout
+
+    def blur(self, vert):
+        a, b = vert, torch.empty_like(vert)
+        for axis in range(self.d + 1):
+            self.blur_axis(axis, a, b)
+            a, b = b, a
+        return a
+
+    def slice(self, vert, sub=None, fast_slice=False, out=None):
+        vd = int(vert.shape[1])
+        out = torch.empty((self.n, vd), dtype=torch.float32, device=self.device) if out is None else out
+        with torch.cuda.device(self.device):
+            _check(load_library().phl_slice(self._h, C.c_void_p(vert.data_ptr()), vd, C.c_void_p(out.data_ptr()),
+                                            out.stride(0), C.c_void_p(sub.data_ptr()) if sub is not None else None,
+                                            sub.stride(0) if sub is not None else 0,
+                                            FAST_SLICE if fast_slice else 0, _stream(self.device)))
+        return out
+
+    # ---- introspection (host copies) --------------------------------------------------------
+    def keys(self):
+        out = np.empty((self.M, self.d), np.int16)
+        _check(load_library().phl_get_keys(self._h, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def replay(self):
+        vid = np.empty((self.n, self.d + 1), np.int32)
+        w = np.empty((self.n, self.d + 1), np.float32)
+        _check(load_library().phl_get_replay(self._h, vid.ctypes.data_as(C.c_void_p), w.ctypes.data_as(C.c_void_p)))
+        return vid, w
+
+    def neighbors(self):
+        out = np.empty((self.d + 1, self.M, 2), np.int32)
+        _check(load_library().phl_get_neighbors(self._h, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def splat_lists(self):
+        ptr = np.empty(self.M + 1, np.int32)
+        pix = np.empty(self.n * (self.d + 1), np.int32)
+        w = np.empty(self.n * (self.d + 1), np.float32)
+        _check(load_library().phl_get_splat_lists(self._h, ptr.ctypes.data_as(C.c_void_p),
+                                                  pix.ctypes.data_as(C.c_void_p), w.ctypes.data_as(C.c_void_p)))
+        return ptr, pix, w
+
+
+# ---------------------------------------------------------------------------------------------
+# invisible lattice cache for the reference's stateless call shape
+_CACHE_SIZE = int(os.environ.get("PHL_LATTICE_CACHE", "4"))
+_cache = OrderedDict()
+_cache_lock = threading.Lock()
+
+
+def _cache_key(ref):
+    return (ref.device.type, ref.device.index, ref.data_ptr(), tuple(ref.shape), tuple(ref.stride()), ref._version)
+
+
+def lattice_for(ref):
+    """Cached Lattice for ``ref``.  The entry keeps ``ref`` alive, so its storage address cannot be
+    recycled while cached; an in-place update bumps ``ref._version`` and misses."""
+    if _CACHE_SIZE <= 0:
+        return Lattice(ref)
+    key = _cache_key(ref)
+    with _cache_lock:
+        hit = _cache.get(key)
+        if hit is not None:
+            _cache.move_to_end(key)
+            return hit[0]
+    lat = Lattice(ref)
+    with _cache_lock:
+        _cache[key] = (lat, ref)
+        while len(_cache) > _CACHE_SIZE:
+            _cache.popitem(last=False)
+    return lat
+
+
+def clear_cache():
+    with _cache_lock:
+        _cache.clear()
+
+
+def filter(src, ref):
+    """Drop-in for the reference's ``lattice.filter(src, ref)``: src [n, vd], ref [n, d], fp32.
+
+    Argument order is the reference's (src first, ref second; lattice.cpp:6)."""
+    if src.shape[0] != ref.shape[0]:
+        raise AssertionError("Incompatible shapes {}, and {}".format(tuple(src.shape), tuple(ref.shape)))
+    return lattice_for(ref.detach()).filter(src)

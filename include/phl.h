@@ -1,0 +1,133 @@
+/*
+ * phl.h -- C ABI of the MI355X-native permutohedral-lattice filter ("phl").
+ *
+ * This is the drop-in boundary for the dense-CRF mean-field message-passing step of
+ * mfinzi/depth-estimation.  Every entry point names the reference interface it replaces
+ * (paths relative to the reference repo).  Plain pointers and sizes only: no torch types.
+ *
+ * Reference boundary being replaced
+ *   python : latticefilter = lattice.filter            crf/gaussian_matrix.py:15-16
+ *   C++    : at::Tensor filter(at::Tensor src, at::Tensor ref)
+ *                                                      crf/lattice/lite/lattice.cpp:6-15
+ *   engine : PermutohedralLattice::filter / splat / blur / slice
+ *                                                      crf/lattice/lite/permutohedral.h:199-548
+ *
+ * Design difference (MI355X-first): the reference rebuilds the lattice inside every filter()
+ * call although `ref` never changes during mean-field inference.  Here the
+ * lattice is an object: build once per `ref` (phl_build), filter many value sets
+ * (phl_filter).  phl_filter_once() keeps the reference's one-shot call shape.
+ *
+ * All pointers named *_dev are DEVICE pointers to fp32 (the reference is fp32 only,
+ * permutohedral.h:16-19).  Strides are in ELEMENTS, so permuted NCHW views
+ * (gaussian_matrix.py:348-349) are accepted without a host copy.  All work is enqueued on
+ * the caller's HIP stream (NULL = default stream); functions that return host data
+ * synchronise that stream.  Functions return PHL_OK or an error code and never abort;
+ * phl_last_error() gives the message for the calling thread.
+ */
+#ifndef PHL_H
+#define PHL_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PHL_VERSION 100 /* major*10000 + minor*100 + patch */
+
+typedef struct phl_lattice phl_lattice; /* opaque, owns device memory */
+typedef void *phl_stream;               /* hipStream_t */
+
+enum phl_status {
+    PHL_OK = 0,
+    PHL_ERR_INVALID = 1,     /* bad argument (NULL, negative size, d out of range, ...) */
+    PHL_ERR_SHAPE = 2,       /* rows of src and ref differ: reference asserts
+                                "Incompatible shapes {}, and {}" (gaussian_matrix.py:429-430,
+                                permutohedral.h:204) */
+    PHL_ERR_HIP = 3,         /* a HIP runtime call failed (message has hipGetErrorString) */
+    PHL_ERR_NO_DEVICE = 4,   /* no gfx950 device: the product path has NO CPU fallback */
+    PHL_ERR_KEY_RANGE = 5,   /* a lattice coordinate left int16: the reference stores keys as
+                                `short` (permutohedral.h:39,398) and silently wraps */
+    PHL_ERR_TOO_LARGE = 6,   /* n*(d+1) does not fit int32 indexing */
+    PHL_ERR_UNSUPPORTED = 7
+};
+
+enum phl_filter_flags {
+    PHL_FILTER_DEFAULT = 0,
+    /* out = filter(src) - src : LatticeGaussian.forward, gaussian_matrix.py:302-303, and
+       BatchedAdjacency.forward :352, fused into the slice epilogue */
+    PHL_FILTER_SUBTRACT_INPUT = 1,
+    /* sum_i w_i*v_i * 1/(1+2^-d) with one final multiply instead of the reference's
+       per-term divide (permutohedral.h:480); differs in the last bit only */
+    PHL_FILTER_FAST_SLICE = 2
+};
+
+/* Limits. */
+#define PHL_MAX_D 16 /* feature dimensions supported by the device build */
+
+int phl_version(void);
+const char *phl_last_error(void);
+const char *phl_status_string(int status);
+/* Number of visible HIP devices (0 if none); never initialises a device context. */
+int phl_device_count(void);
+
+/* ---- lattice construction ---------------------------------------------------------------
+ * Replaces PermutohedralLattice(d, vd, n) + the geometry half of splat() for all n pixels
+ * (permutohedral.h:328-372, :376-447, :458-460) + the neighbour lookups of blur() (:504-522).
+ * ref_dev: [n][d] fp32 with element strides (row_stride, col_stride).
+ * Vertices are numbered in first-touch order of the (pixel, remainder) sequence -- the same
+ * numbering the reference's insertion-ordered hash table produces (permutohedral.h:70-77). */
+int phl_build(phl_lattice **out, const float *ref_dev, int64_t n, int d, int64_t ref_row_stride,
+              int64_t ref_col_stride, int device, phl_stream stream);
+int phl_destroy(phl_lattice *lat);
+
+int64_t phl_num_pixels(const phl_lattice *lat);
+int64_t phl_num_vertices(const phl_lattice *lat); /* == hashTable.size() after splat */
+int phl_num_dims(const phl_lattice *lat);
+int phl_device(const phl_lattice *lat);
+/* Device bytes held by the lattice (tables + value workspace). */
+int64_t phl_device_bytes(const phl_lattice *lat);
+
+/* Pre-size the [M][vd] ping-pong value buffers so that phl_filter allocates nothing
+ * (needed before hipGraph capture). */
+int phl_reserve(phl_lattice *lat, int vd);
+
+/* ---- the hot path -----------------------------------------------------------------------
+ * out = slice(blur(splat(src)))  == lattice.filter(src, ref) of the reference
+ * (lattice.cpp:6-10 -> permutohedral.h:236-238, :260, :264-276).
+ * src_dev/out_dev: [n][vd] fp32, element strides; out may not alias src. */
+int phl_filter(phl_lattice *lat, const float *src_dev, int vd, int64_t src_row_stride,
+               int64_t src_col_stride, float *out_dev, int64_t out_row_stride,
+               int64_t out_col_stride, unsigned flags, phl_stream stream);
+
+/* One-shot call with the reference's argument order (src first, ref second):
+ * builds, filters, destroys -- what lattice.filter(src, ref) does on every call. */
+int phl_filter_once(const float *src_dev, int vd, int64_t src_row_stride, int64_t src_col_stride,
+                    const float *ref_dev, int d, int64_t ref_row_stride, int64_t ref_col_stride,
+                    int64_t n, float *out_dev, int64_t out_row_stride, int64_t out_col_stride,
+                    unsigned flags, int device, phl_stream stream);
+
+/* ---- stage-level entry points (profiling, roofline measurement, parity of intermediates) --
+ * vert buffers are dense [M][vd] fp32 device arrays owned by the caller. */
+/* value half of splat(): vert[v] = sum over (pixel,weight) of w*src[pixel]   (:454-455) */
+int phl_splat(phl_lattice *lat, const float *src_dev, int vd, int64_t src_row_stride,
+              float *vert_dev, phl_stream stream);
+/* one blur axis, Jacobi: dst[v] = 2*(1/4 src[n1] + 1/2 src[v] + 1/4 src[n2])   (:498-533) */
+int phl_blur_axis(phl_lattice *lat, int axis, const float *vert_src_dev, float *vert_dst_dev, int vd,
+                  phl_stream stream);
+/* slice(): out[p] = sum_i w_i * vert[v_i] / (1 + 2^-d)                        (:473-483) */
+int phl_slice(phl_lattice *lat, const float *vert_dev, int vd, float *out_dev, int64_t out_row_stride,
+              const float *sub_dev /* NULL or src to subtract */, int64_t sub_row_stride, unsigned flags,
+              phl_stream stream);
+
+/* ---- introspection for parity tests (synchronous device->host copies) --------------------- */
+int phl_get_keys(phl_lattice *lat, int16_t *keys_host /* [M][d] */);
+int phl_get_replay(phl_lattice *lat, int32_t *vid_host /* [n][d+1] */, float *w_host /* [n][d+1] */);
+int phl_get_neighbors(phl_lattice *lat, int32_t *nbr_host /* [d+1][M][2], -1 = absent */);
+int phl_get_splat_lists(phl_lattice *lat, int32_t *ptr_host /* [M+1] */, int32_t *pixel_host /* [n(d+1)] */,
+                        float *w_host /* [n(d+1)] */);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PHL_H */
