@@ -1,0 +1,138 @@
+"""Dense-CRF mean-field inference, mirroring the reference's crf/crf_module.py.
+
+    Q <- softmax(-E0);  repeat niters:  E <- E0 + (W @ Q) @ Mu;  Q <- softmax(-E)
+
+``W`` is any object with ``@`` -- for the lattice path a crf.gaussian_matrix.LatticeGaussian,
+whose product is one splat -> blur -> slice on the MI355X lattice built ONCE for the fixed
+reference features (the reference rebuilds it on every iteration).
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from crf.gaussian_matrix import BatchedAdjacency, BatchedGuidedAdjacency  # noqa: F401  (crf_module.py:5)
+
+
+def gaussian_weights_u(f):
+    """Dense brute-force W = exp(-|fi-fj|^2) - I for tiny n (crf_module.py:17-20)."""
+    sq = torch.cdist(f, f).pow(2)
+    return torch.exp(-sq) - torch.eye(f.shape[0], device=f.device, dtype=f.dtype)
+
+
+def gaussian_weights(f):
+    """Symmetrically normalised version of gaussian_weights_u, minus I (crf_module.py:8-15)."""
+    W = gaussian_weights_u(f)
+    s = W.sum(1).rsqrt()
+    return s[:, None] * W * s[None, :] - torch.eye(f.shape[0], device=f.device, dtype=f.dtype)
+
+
+def lazy_W(f):
+    """Row generator of the normalised dense affinity for an [h, w, c] numpy image (crf_module.py:22-30)."""
+    def W(i, j):
+        a = np.exp(-((f - f[i, j]) ** 2).sum(-1).reshape(-1))
+        a = a / np.sqrt(a.sum() - 1)
+        return a.reshape(f.shape[:2])
+    return W
+
+
+def charbonneir(a, b, gamma=.1):
+    """Charbonnier label compatibility sqrt(gamma^2 + (a-b)^2) - gamma (crf_module.py:32-33)."""
+    return torch.sqrt(gamma ** 2 + (a - b) ** 2) - gamma
+
+
+def charbonneir2(a, b, gamma=3):
+    return torch.sqrt(1 + ((a - b) / gamma) ** 2) - 1
+
+
+def compatibility_matrix(compat, labels):
+    """Mu[a, b] = compat(labels[a], labels[b]) (crf_module.py:38-39)."""
+    return compat(labels[:, None], labels[None, :])
+
+
+def mean_field_infer(E_0, W, Mu, niters=10):
+    """[E_0] n x L unaries, [W] n x n operator, [Mu] L x L compatibility -> Q n x L (crf_module.py:41-53)."""
+    Q = F.softmax(-E_0, dim=1)
+    for _ in range(niters):
+        Q = F.softmax(-(E_0 + (W @ Q) @ Mu), dim=1)
+    return Q
+
+
+def potts(num_classes):
+    """1x1 conv holding the Potts compatibility 1 - I (crf_module.py:55-64)."""
+    layer = nn.Conv2d(num_classes, num_classes, kernel_size=1, bias=False)
+    with torch.no_grad():
+        layer.weight.copy_((1 - torch.eye(num_classes))[..., None, None])
+    return layer
+
+
+class charb(nn.Module):
+    """Learnable Charbonnier compatibility applied as a 1x1 conv over label channels
+    (crf_module.py:66-79): Mu(Q) = conv(Q, charbonneir(l_a, l_b, gamma)) * exp(s)."""
+
+    def __init__(self, gamma):
+        super().__init__()
+        self.gamma = nn.Parameter(torch.tensor(gamma))
+        self.s = nn.Parameter(torch.tensor(0.))
+
+    def forward(self, x, labels=None):
+        if labels is None:
+            labels = torch.arange(x.shape[1], dtype=torch.float32, device=x.device)
+        Mu = charbonneir(labels[None, :], labels[:, None], self.gamma)
+        return F.conv2d(x, Mu[..., None, None]) * torch.exp(self.s)
+
+    def get_energies_from_scalar(self, x, labels):
+        return charbonneir(labels, x, self.gamma * labels.max()) * torch.exp(self.s)
+
+
+class CRFasRNN(nn.Module):
+    """Batched NCHW mean field (crf_module.py:81-104); returns logits -E of the LAST iteration.
+
+    ``lattice=True`` selects the permutohedral W (BatchedAdjacency, the MI355X path); the default
+    stays the reference's guided-filter W."""
+
+    def __init__(self, mu_init, niters=5, r=20, eps=1e-5, notrain_mu=False, gaussian=False, gchannels=1, lattice=False):
+        super().__init__()
+        self.Mu = mu_init
+        if notrain_mu:
+            for p in self.Mu.parameters():
+                p.requires_grad = False
+        self.niters = niters
+        self.W = BatchedAdjacency() if lattice else BatchedGuidedAdjacency(gchannels, r, eps, gaussian=gaussian)
+
+    def forward(self, refs, logits, confidence=None, labels=None):
+        E0 = -logits * (1 if confidence is None else confidence)
+        compat = (lambda q: self.Mu(q)) if labels is None else (lambda q: self.Mu(q, labels))
+        Q = F.softmax(-E0, dim=1)
+        E = E0
+        for _ in range(self.niters):
+            E = E0 + self.W(compat(Q), refs)
+            Q = F.softmax(-E, dim=1)
+        return -E
+
+
+def _ij_grid(x):
+    bs, _, h, w = x.shape
+    ij = torch.from_numpy(np.mgrid[:h, :w] / np.sqrt(h ** 2 + w ** 2)).float().to(x.device)
+    return ij[None].expand(bs, -1, -1, -1)
+
+
+class ijrgbGuide(nn.Module):
+    """Guide features (i, j)/s_ij ++ rgb/s_rgb (crf_module.py:106-114)."""
+
+    def __init__(self, s_ij=.1, s_rgb=.1, trainable=True):
+        super().__init__()
+        self.s_ij = nn.Parameter(torch.tensor(s_ij)) if trainable else s_ij
+        self.s_rgb = nn.Parameter(torch.tensor(s_rgb)) if trainable else s_rgb
+
+    def forward(self, x):
+        return torch.cat([_ij_grid(x) / self.s_ij, x / self.s_rgb], dim=1)
+
+
+class ijGuide(nn.Module):
+    def __init__(self, s_ij=.1, trainable=True):
+        super().__init__()
+        self.s_ij = nn.Parameter(torch.tensor(s_ij)) if trainable else s_ij
+
+    def forward(self, x):
+        return _ij_grid(x) / self.s_ij

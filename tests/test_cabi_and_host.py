@@ -1,0 +1,96 @@
+"""CPU: the C-ABI library loads and exports every symbol include/phl.h declares; host-side
+logic that needs no GPU; and the loud-failure contract (no CPU fallback in the product)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "phl.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(phl_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    import phl
+
+    lib = phl.load_library()
+    names = _declared_symbols()
+    assert len(names) >= 20
+    for name in names:
+        assert hasattr(lib, name), f"{name} declared in include/phl.h but not exported by libphl.so"
+    assert lib.phl_version() == 100
+    assert lib.phl_status_string(5).decode() == "lattice key outside int16"
+
+
+def test_library_has_gfx950_code_object_and_no_oracle_symbols():
+    import phl
+
+    blob = open(phl.LIB_PATH, "rb").read()
+    assert b"gfx950" in blob
+    assert b"phlo_" not in blob, "the product library must not contain the test oracle"
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "depth-estimation_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "phl_oracle" not in txt and "from oracle" not in txt and "import oracle" not in txt, f
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode")
+def test_fails_loudly_without_gpu():
+    import phl
+
+    assert phl.load_library().phl_device_count() == 0
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        phl.filter(torch.rand(10, 2), torch.rand(10, 3))
+    # C ABI level: build refuses with PHL_ERR_NO_DEVICE and a message, it does not abort
+    lib = phl.load_library()
+    h = ctypes.c_void_p()
+    dummy = (ctypes.c_float * 30)()
+    rc = lib.phl_build(ctypes.byref(h), ctypes.cast(dummy, ctypes.c_void_p), 10, 3, 3, 1, 0, None)
+    assert rc == 4 and b"no CPU fallback" in lib.phl_last_error()
+    rc = lib.phl_build(ctypes.byref(h), ctypes.cast(dummy, ctypes.c_void_p), 10, 0, 3, 1, 0, None)
+    assert rc == 1
+
+
+def test_compatibility_and_dense_weights_host_logic(golden_dir):
+    from crf.crf_module import charbonneir, compatibility_matrix, gaussian_weights_u, mean_field_infer
+
+    g = np.load(os.path.join(golden_dir, "meanfield_tsukuba_crop.npz"))
+    labels = torch.from_numpy(g["labels"])
+    Mu = compatibility_matrix(lambda a, b: charbonneir(a, b, float(g["gamma"])), labels)
+    assert torch.equal(Mu, torch.from_numpy(g["Mu"]))          # reference's Mu, bit for bit
+    # mean-field driver with a dense brute-force W (no lattice, no GPU)
+    f = torch.rand(40, 3)
+    W = gaussian_weights_u(f)
+    E0 = torch.rand(40, 5) * 3
+    Mu5 = compatibility_matrix(lambda a, b: charbonneir(a, b, 3), torch.arange(5.))
+    Q = mean_field_infer(E0, W, Mu5, 3)
+    Qm = torch.softmax(-E0, 1)
+    for _ in range(3):
+        Qm = torch.softmax(-(E0 + W @ Qm @ Mu5), 1)
+    assert torch.allclose(Q, Qm, atol=1e-6) and torch.allclose(Q.sum(1), torch.ones(40), atol=1e-5)
+
+
+def test_exact_divide_recipe_matches_ieee_division():
+    """csrc/phl_filter.hip div_c(): q = t*rc; q += fma(-q, c, t)*rc must equal IEEE t/c for
+    c = 1 + 2^-d (reference slice constant, permutohedral.h:480).  float64 emulates the fmas."""
+    rng = np.random.default_rng(0)
+    for d in range(1, 17):
+        c = np.float32(1) + np.float32(2.0 ** -d)
+        rc = np.float32(1) / c
+        t = (rng.standard_normal(400_000) * np.exp(rng.uniform(-20, 20, 400_000))).astype(np.float32)
+        q = (t * rc).astype(np.float32)
+        rem = (t.astype(np.float64) - q.astype(np.float64) * np.float64(c)).astype(np.float32)
+        q2 = (q.astype(np.float64) + rem.astype(np.float64) * np.float64(rc)).astype(np.float32)
+        assert np.array_equal(q2, t / c), d

@@ -1,0 +1,99 @@
+"""GPU: the mirrored crf.* Python surface (rows a1-a6 of SURVEY.md 8a) against vectors produced
+by the reference's own Python + C++ in the build container (tests/golden/generate.py)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-4  # north_star: disparity maps within 1e-4 relative per pixel
+
+
+def rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float((np.abs(a - b) / np.maximum(np.abs(b), 1e-3 * np.abs(b).max())).max())
+
+
+def test_mean_field_tsukuba_crop(golden_dir):
+    from crf.crf_module import charbonneir, compatibility_matrix, mean_field_infer
+    from crf.gaussian_matrix import LatticeGaussian
+
+    g = np.load(os.path.join(golden_dir, "meanfield_tsukuba_crop.npz"))
+    dev = torch.device("cuda")
+    E0 = torch.from_numpy(g["E0"]).to(dev)
+    ref = torch.from_numpy(g["ref"]).to(dev)
+    labels = torch.from_numpy(g["labels"]).to(dev)
+    Mu = compatibility_matrix(lambda a, b: charbonneir(a, b, float(g["gamma"])), labels)
+    assert rel(Mu.cpu().numpy(), g["Mu"]) <= 1e-6
+    W = LatticeGaussian(ref)
+    WQ0 = W @ torch.softmax(-E0, dim=1)
+    assert rel(WQ0.cpu().numpy(), g["WQ0"]) <= RTOL
+    for it, key in ((1, "1"), (5, "5")):
+        Q = mean_field_infer(E0, W, Mu, it)
+        assert rel(Q.cpu().numpy(), g["Q" + key]) <= RTOL * 10      # probabilities span many decades
+        disp = (Q @ labels).cpu().numpy()
+        assert np.abs(disp - g["disp" + key]).max() <= RTOL * np.abs(g["disp" + key]).max()
+        assert (np.abs(disp - g["disp" + key]) / np.maximum(g["disp" + key], 1e-2)).max() <= RTOL * 5
+    # CPU tensors in, CPU tensors out (the notebook runs on device('cpu'))
+    Qc = mean_field_infer(E0.cpu(), LatticeGaussian(ref.cpu()), Mu.cpu(), 1)
+    assert not Qc.is_cuda and rel(Qc.numpy(), g["Q1"]) <= RTOL * 10
+
+
+@pytest.mark.parametrize("name", ["grad_n80_d3_L2", "grad_n2000_d5_L4"])
+def test_lattice_filter_backward(golden_dir, name):
+    from crf.gaussian_matrix import LatticeFilter
+
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    dev = torch.device("cuda")
+    ref = torch.from_numpy(g["ref"]).to(dev).requires_grad_(True)
+    src = torch.from_numpy(g["src"]).to(dev).requires_grad_(True)
+    gout = torch.from_numpy(g["gout"]).to(dev)
+    out = LatticeFilter.apply(src, ref)
+    assert np.array_equal(out.detach().cpu().numpy().view(np.uint32), g["out"].view(np.uint32))
+    out.backward(gout)
+    assert rel(src.grad.cpu().numpy(), g["grad_src"]) <= RTOL
+    assert rel(ref.grad.cpu().numpy(), g["grad_ref"]) <= 5e-4      # reference's own gradcheck rtol (gaussian_matrix.py:516)
+    src2 = src.detach().clone().requires_grad_(True)
+    LatticeFilter.apply(src2, ref.detach()).backward(gout)
+    assert rel(src2.grad.cpu().numpy(), g["grad_src_only"]) <= RTOL
+
+
+def test_batched_adjacency_nchw(golden_dir):
+    from crf.gaussian_matrix import BatchedAdjacency
+
+    g = np.load(os.path.join(golden_dir, "batched_adjacency.npz"))
+    src = torch.from_numpy(g["src"]).cuda()
+    guide = torch.from_numpy(g["guide"]).cuda()
+    out = BatchedAdjacency(num_threads=2)(src, guide)
+    assert out.shape == src.shape and rel(out.cpu().numpy(), g["out"]) <= RTOL
+
+
+def test_laplacians(golden_dir):
+    from crf.gaussian_matrix import RbfLaplacian, RbfLaplacianC
+
+    g = np.load(os.path.join(golden_dir, "laplacians.npz"))
+    ref = torch.from_numpy(g["ref"]).cuda()
+    U = torch.from_numpy(g["U"]).cuda()
+    op = RbfLaplacian(ref, normalize=True)
+    assert rel(op.D.cpu().numpy(), g["rbf_D"]) <= RTOL
+    assert rel((op @ U).cpu().numpy(), g["rbf_norm"]) <= RTOL
+    assert rel((RbfLaplacian(ref, normalize=False) @ U).cpu().numpy(), g["rbf_unnorm"]) <= RTOL
+    for mode in ("sym", "right", "none"):
+        opc = RbfLaplacianC(ref, normalize=mode)
+        assert rel(opc.D.cpu().numpy(), g["rbfc_D"]) <= RTOL
+        assert rel((opc @ U).cpu().numpy(), g["rbfc_" + mode]) <= RTOL * 3   # "- U" cancellation
+
+
+def test_crf_as_rnn_lattice_runs():
+    from crf.crf_module import CRFasRNN, charb, ijrgbGuide
+
+    torch.manual_seed(0)
+    net = CRFasRNN(charb(3.0), niters=2, lattice=True).cuda()
+    img = torch.rand(2, 3, 24, 32, device="cuda")
+    logits = torch.randn(2, 8, 24, 32, device="cuda", requires_grad=True)
+    refs = ijrgbGuide(trainable=False)(img)
+    out = net(refs, logits)
+    assert out.shape == logits.shape and torch.isfinite(out).all()
+    out.sum().backward()
+    assert torch.isfinite(logits.grad).all()
