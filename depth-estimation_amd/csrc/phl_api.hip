@@ -117,7 +117,7 @@ int phl_destroy(phl_lattice *lat)
 {
     if (!lat) return PHL_OK;
     device_guard g(lat->device);
-    void *ptrs[] = {lat->vkeys, lat->replay, lat->csr_ptr, lat->csr, lat->nbr, lat->buf[0], lat->buf[1], lat->stage_in, lat->stage_out};
+    void *ptrs[] = {lat->vkeys, lat->replay, lat->csr_ptr, lat->csr, lat->nbr, lat->table, lat->buf[0], lat->buf[1], lat->stage_in, lat->stage_out};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     delete lat;
@@ -132,6 +132,16 @@ int64_t phl_device_bytes(const phl_lattice *lat)
 {
     if (!lat) return -1;
     return lat->table_bytes + 2 * lat->buf_elems * (int64_t)sizeof(float) + 2 * lat->stage_elems * (int64_t)sizeof(float);
+}
+
+int64_t phl_num_local_vertices(const phl_lattice *lat) { return lat ? lat->M_local : -1; }
+
+int phl_add_vertices(phl_lattice *lat, const int16_t *keys_host, int64_t count, int32_t *vid_host, phl_stream stream)
+{
+    if (!lat || count < 0 || (count > 0 && (!keys_host || !vid_host))) { phl_set_error("phl_add_vertices: bad arguments"); return PHL_ERR_INVALID; }
+    if (lat->M + count > ((int64_t)1 << 30)) { phl_set_error("phl_add_vertices: too many vertices"); return PHL_ERR_TOO_LARGE; }
+    device_guard g(lat->device);
+    return phl_add_vertices_device(lat, keys_host, count, vid_host, (hipStream_t)stream);
 }
 
 int phl_reserve(phl_lattice *lat, int vd)

@@ -275,6 +275,55 @@ __global__ __launch_bounds__(256) void k_neighbors(const int16_t *__restrict__ v
     nbr[idx * 2 + 1] = res[1];
 }
 
+// (re)build the persistent key -> vertex table from the distinct vertex keys
+__global__ __launch_bounds__(256) void k_table_insert(const int16_t *__restrict__ vkeys, int d, int M, int *table,
+                                                      uint32_t mask)
+{
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= M) return;
+    const int16_t *key = vkeys + (int64_t)v * d;
+    uint32_t h = mix_begin();
+    for (int i = 0; i < d; i++) h = mix_step(h, key[i]);
+    h = mix_end(h) & mask;
+    while (atomicCAS(&table[h], PHL_EMPTY, -(v + 1)) != PHL_EMPTY) h = (h + 1) & mask;
+}
+
+// vid of each query key, or -1
+__global__ __launch_bounds__(256) void k_table_lookup(const int16_t *__restrict__ qkeys, int d, int K,
+                                                      const int16_t *__restrict__ vkeys, const int *__restrict__ table,
+                                                      uint32_t mask, int *__restrict__ vid_out, int *__restrict__ missing)
+{
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= K) return;
+    const int16_t *key = qkeys + (int64_t)q * d;
+    uint32_t h = mix_begin();
+    for (int i = 0; i < d; i++) h = mix_step(h, key[i]);
+    h = mix_end(h) & mask;
+    int found = -1;
+    for (;;) {
+        const int t = table[h];
+        if (t == PHL_EMPTY) break;
+        const int16_t *other = vkeys + (int64_t)(-(t + 1)) * d;
+        bool same = true;
+        for (int i = 0; i < d; i++) same &= (other[i] == key[i]);
+        if (same) { found = -(t + 1); break; }
+        h = (h + 1) & mask;
+    }
+    vid_out[q] = found;
+    missing[q] = found < 0 ? 1 : 0;
+}
+
+__global__ __launch_bounds__(256) void k_append_missing(const int16_t *__restrict__ qkeys, int d, int K,
+                                                        const int *__restrict__ missing_rank, int M_old,
+                                                        int16_t *__restrict__ vkeys, int *__restrict__ vid_io)
+{
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= K || vid_io[q] >= 0) return;
+    const int v = M_old + missing_rank[q];
+    for (int i = 0; i < d; i++) vkeys[(int64_t)v * d + i] = qkeys[(int64_t)q * d + i];
+    vid_io[q] = v;
+}
+
 __global__ void k_fill_i32(int *p, int64_t n, int value)
 {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -398,6 +447,32 @@ void launch_elevate(const float *ref, int64_t rs, int64_t cs, int64_t n, const s
 
 }  // namespace
 
+// Persistent compact table (capacity >= 2M) + blur neighbour ids for ALL current vertices.
+static int phl_rebuild_table_and_neighbors(phl_lattice *lat, hipStream_t st)
+{
+    const int d = lat->d;
+    const int M = (int)lat->M;
+    if (lat->table) PHL_HIP(hipFree(lat->table));
+    if (lat->nbr) PHL_HIP(hipFree(lat->nbr));
+    lat->table = nullptr;
+    lat->nbr = nullptr;
+    uint64_t cap = 1024;
+    while (cap < (uint64_t)M * 2) cap <<= 1;
+    lat->table_mask = (uint32_t)(cap - 1);
+    PHL_HIP(hipMalloc((void **)&lat->table, sizeof(int) * cap));
+    PHL_HIP(hipMalloc((void **)&lat->nbr, sizeof(int32_t) * (size_t)(M ? M : 1) * (d + 1) * 2));
+    hipLaunchKernelGGL(k_fill_i32, dim3(1024), dim3(256), 0, st, lat->table, (int64_t)cap, PHL_EMPTY);
+    if (M > 0) {
+        hipLaunchKernelGGL(k_table_insert, dim3((M + 255) / 256), dim3(256), 0, st, lat->vkeys, d, M, lat->table,
+                           lat->table_mask);
+        const int64_t tot = (int64_t)M * (d + 1);
+        hipLaunchKernelGGL(k_neighbors, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, lat->vkeys, d, M,
+                           lat->table, lat->table_mask, lat->nbr);
+    }
+    PHL_HIP(hipGetLastError());
+    return PHL_OK;
+}
+
 int phl_build_device(phl_lattice *lat, const float *ref, int64_t rs, int64_t cs, hipStream_t st)
 {
     const int d = lat->d;
@@ -405,7 +480,8 @@ int phl_build_device(phl_lattice *lat, const float *ref, int64_t rs, int64_t cs,
     const int64_t N64 = n * (d + 1);
     lat->N = N64;
     lat->M = 0;
-    if (n == 0) return PHL_OK;
+    lat->M_local = 0;
+    if (n == 0) return phl_rebuild_table_and_neighbors(lat, st);
     const int N = (int)N64;
 
     // scaleFactor exactly as the reference computes it on the host (permutohedral.h:354-371)
@@ -464,7 +540,6 @@ int phl_build_device(phl_lattice *lat, const float *ref, int64_t rs, int64_t cs,
     PHL_HIP(hipMalloc((void **)&lat->vkeys, sizeof(int16_t) * (size_t)M * d));
     PHL_HIP(hipMalloc((void **)&lat->csr_ptr, sizeof(int32_t) * ((size_t)M + 1)));
     PHL_HIP(hipMalloc((void **)&lat->csr, sizeof(phl_contrib_t) * (size_t)N));
-    PHL_HIP(hipMalloc((void **)&lat->nbr, sizeof(int32_t) * (size_t)M * (d + 1) * 2));
     PHL_HIP(tmp.get(&cursor, (size_t)M * 2));  // cnt | cursor
     PHL_HIP(tmp.get(&csr_tmp, (size_t)N));
     int *cnt = cursor + M;
@@ -482,15 +557,73 @@ int phl_build_device(phl_lattice *lat, const float *ref, int64_t rs, int64_t cs,
         if (blocks > 256 * 16) blocks = 256 * 16;
         hipLaunchKernelGGL(k_sort_lists, dim3(blocks), dim3(256), 0, st, csr_tmp, lat->csr_ptr, M, lat->csr);
     }
-    {
-        const int64_t tot = (int64_t)M * (d + 1);
-        hipLaunchKernelGGL(k_neighbors, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, lat->vkeys, d, M, table,
-                           mask, lat->nbr);
-    }
+    lat->M_local = M;
+    rc = phl_rebuild_table_and_neighbors(lat, st);
+    if (rc) return rc;
     PHL_HIP(hipGetLastError());
     PHL_HIP(hipStreamSynchronize(st));  // temporaries are freed on return
     lat->table_bytes = (int64_t)(sizeof(int16_t) * (size_t)M * d + sizeof(int32_t) * ((size_t)M + 1) +
                                  sizeof(phl_contrib_t) * (size_t)N + sizeof(phl_replay_t) * (size_t)N +
-                                 sizeof(int32_t) * (size_t)M * (d + 1) * 2);
+                                 sizeof(int32_t) * (size_t)M * (d + 1) * 2 + sizeof(int) * ((size_t)lat->table_mask + 1));
+    return PHL_OK;
+}
+
+// Append vertices that exist in a neighbouring row band ("ghosts": no local contributions, so
+// their splat lists are empty) and return the local id of every queried key.  Keys must be
+// distinct.  Used by the row-band multi-GPU path; rebuilds the table and the neighbour ids.
+int phl_add_vertices_device(phl_lattice *lat, const int16_t *keys_host, int64_t count, int32_t *vid_host, hipStream_t st)
+{
+    if (count == 0) return PHL_OK;
+    const int d = lat->d;
+    const int K = (int)count;
+    const int M_old = (int)lat->M;
+    temp_pool tmp;
+    int16_t *qkeys;
+    int *vid, *missing, *mrank, *tile_sums;
+    PHL_HIP(tmp.get(&qkeys, (size_t)K * d));
+    PHL_HIP(tmp.get(&vid, (size_t)K));
+    PHL_HIP(tmp.get(&missing, (size_t)K));
+    PHL_HIP(tmp.get(&mrank, (size_t)K + 1));
+    PHL_HIP(tmp.get(&tile_sums, (size_t)K / SCAN_TILE + 2));
+    PHL_HIP(hipMemcpyAsync(qkeys, keys_host, sizeof(int16_t) * (size_t)K * d, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_table_lookup, dim3((K + 255) / 256), dim3(256), 0, st, qkeys, d, K, lat->vkeys, lat->table,
+                       lat->table_mask, vid, missing);
+    PHL_HIP(hipGetLastError());
+    int rc = exclusive_scan(missing, mrank, K, tile_sums, st);
+    if (rc) return rc;
+    int n_new = 0;
+    PHL_HIP(hipMemcpyAsync(&n_new, mrank + K, sizeof(int), hipMemcpyDeviceToHost, st));
+    PHL_HIP(hipStreamSynchronize(st));
+    if (n_new > 0) {
+        const int M_new = M_old + n_new;
+        int16_t *vkeys_new;
+        int32_t *ptr_new;
+        PHL_HIP(hipMalloc((void **)&vkeys_new, sizeof(int16_t) * (size_t)M_new * d));
+        PHL_HIP(hipMalloc((void **)&ptr_new, sizeof(int32_t) * ((size_t)M_new + 1)));
+        if (M_old > 0)
+            PHL_HIP(hipMemcpyAsync(vkeys_new, lat->vkeys, sizeof(int16_t) * (size_t)M_old * d, hipMemcpyDeviceToDevice, st));
+        if (lat->csr_ptr)
+            PHL_HIP(hipMemcpyAsync(ptr_new, lat->csr_ptr, sizeof(int32_t) * ((size_t)M_old + 1), hipMemcpyDeviceToDevice, st));
+        // ghosts have empty contribution lists: ptr[v] = N for all new v
+        hipLaunchKernelGGL(k_fill_i32, dim3(64), dim3(256), 0, st, ptr_new + M_old, (int64_t)n_new + 1, (int)lat->N);
+        hipLaunchKernelGGL(k_append_missing, dim3((K + 255) / 256), dim3(256), 0, st, qkeys, d, K, mrank, M_old, vkeys_new,
+                           vid);
+        PHL_HIP(hipGetLastError());
+        PHL_HIP(hipStreamSynchronize(st));
+        if (lat->vkeys) PHL_HIP(hipFree(lat->vkeys));
+        if (lat->csr_ptr) PHL_HIP(hipFree(lat->csr_ptr));
+        lat->vkeys = vkeys_new;
+        lat->csr_ptr = ptr_new;
+        lat->M = M_new;
+        rc = phl_rebuild_table_and_neighbors(lat, st);
+        if (rc) return rc;
+        // value workspace is sized by M: force re-reservation
+        if (lat->buf[0]) PHL_HIP(hipFree(lat->buf[0]));
+        if (lat->buf[1]) PHL_HIP(hipFree(lat->buf[1]));
+        lat->buf[0] = lat->buf[1] = nullptr;
+        lat->buf_elems = 0;
+    }
+    PHL_HIP(hipMemcpyAsync(vid_host, vid, sizeof(int32_t) * (size_t)K, hipMemcpyDeviceToHost, st));
+    PHL_HIP(hipStreamSynchronize(st));
     return PHL_OK;
 }

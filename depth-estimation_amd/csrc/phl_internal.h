@@ -33,6 +33,9 @@ struct phl_lattice {
     int32_t *csr_ptr;       // [M+1]
     phl_contrib_t *csr;     // [N] grouped by vertex, pixel-ascending inside a group
     int32_t *nbr;           // [d+1][M][2]
+    int *table;             // open-addressing key -> -(vid+1), PHL_EMPTY = free; kept for phl_add_vertices
+    uint32_t table_mask;
+    int64_t M_local;        // vertices created by this lattice's own pixels (ghosts come after)
 
     // value workspace, grown on demand
     float *buf[2];
@@ -55,6 +58,7 @@ int phl_hip_fail(hipError_t e, const char *what, const char *file, int line);
 
 // ---- launchers implemented in phl_build.hip ----
 int phl_build_device(phl_lattice *lat, const float *ref, int64_t rs, int64_t cs, hipStream_t st);
+int phl_add_vertices_device(phl_lattice *lat, const int16_t *keys_host, int64_t count, int32_t *vid_host, hipStream_t st);
 
 // ---- launchers implemented in phl_filter.hip ----
 int phl_launch_splat(const phl_lattice *lat, const float *src, int64_t src_rs, int vd, float *vert, hipStream_t st);

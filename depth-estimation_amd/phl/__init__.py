@@ -62,6 +62,9 @@ def load_library():
         lib.phl_num_dims.argtypes = [vp]
         lib.phl_device.argtypes = [vp]
         lib.phl_reserve.argtypes = [vp, i32]
+        lib.phl_add_vertices.argtypes = [vp, vp, i64, vp, vp]
+        lib.phl_num_local_vertices.restype = i64
+        lib.phl_num_local_vertices.argtypes = [vp]
         lib.phl_filter.argtypes = [vp, vp, i32, i64, i64, vp, i64, i64, u32, vp]
         lib.phl_filter_once.argtypes = [vp, i32, i64, i64, vp, i32, i64, i64, i64, vp, i64, i64, u32, i32, vp]
         lib.phl_splat.argtypes = [vp, vp, i32, i64, vp, vp]
@@ -190,6 +193,21 @@ class Lattice:
                                             sub.stride(0) if sub is not None else 0,
                                             FAST_SLICE if fast_slice else 0, _stream(self.device)))
         return out
+
+    def add_vertices(self, keys):
+        """Row-band support: append neighbouring-band vertices (distinct int16 keys [K, d]) as
+        ghosts; returns the local vertex id of every key (int32 [K]).  Updates ``M``."""
+        keys = np.ascontiguousarray(keys, np.int16).reshape(-1, self.d)
+        vid = np.empty(len(keys), np.int32)
+        with torch.cuda.device(self.device):
+            _check(load_library().phl_add_vertices(self._h, keys.ctypes.data_as(C.c_void_p), len(keys),
+                                                   vid.ctypes.data_as(C.c_void_p), _stream(self.device)))
+        self.M = int(load_library().phl_num_vertices(self._h))
+        return vid
+
+    @property
+    def M_local(self):
+        return int(load_library().phl_num_local_vertices(self._h))
 
     # ---- introspection (host copies) --------------------------------------------------------
     def keys(self):

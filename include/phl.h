@@ -88,6 +88,16 @@ int phl_device(const phl_lattice *lat);
 /* Device bytes held by the lattice (tables + value workspace). */
 int64_t phl_device_bytes(const phl_lattice *lat);
 
+/* ---- row-band multi-GPU support -------------------------------------------------------------
+ * Append vertices that exist in a NEIGHBOURING row band of the same image ("ghost" vertices:
+ * no local pixel splats into them) so that blur() sees the same neighbourhood it would see in
+ * the whole-image lattice.  keys_host: [count][d] int16, distinct.  vid_host[i] receives the
+ * local vertex id of key i (an existing vertex when this band already has it, else a new id
+ * >= phl_num_local_vertices()).  No reference counterpart: the reference is single-process. */
+int phl_add_vertices(phl_lattice *lat, const int16_t *keys_host, int64_t count, int32_t *vid_host,
+                     phl_stream stream);
+int64_t phl_num_local_vertices(const phl_lattice *lat); /* vertices created by this lattice's own pixels */
+
 /* Pre-size the [M][vd] ping-pong value buffers so that phl_filter allocates nothing
  * (needed before hipGraph capture). */
 int phl_reserve(phl_lattice *lat, int vd);

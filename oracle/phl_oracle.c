@@ -176,6 +176,27 @@ static void simplex_of(const float *position, int d, const float *sf,
     bary[0] += 1.0f + bary[d + 1];
 }
 
+/* blur-neighbour table for all current vertices (:502-522) */
+static void compute_neighbors(phlo_lattice *L)
+{
+    const int d = L->d;
+    int64_t M = L->M;
+    free(L->nbr);
+    L->nbr = (int32_t *)malloc(sizeof(int32_t) * (M > 0 ? M : 1) * (d + 1) * 2);
+    int16_t n1[PHLO_MAX_D + 1], n2[PHLO_MAX_D + 1];
+    for (int j = 0; j <= d; j++) {
+        for (int64_t v = 0; v < M; v++) {
+            const int16_t *k = L->keys + v * d;
+            for (int i = 0; i < d; i++) { n1[i] = k[i] + 1; n2[i] = k[i] - 1; }
+            /* for j == d the written coordinate is the implied (d+1)-th one, outside the
+             * hashed key, so the neighbour is key +- 1 in all d stored coordinates (:508-509) */
+            if (j < d) { n1[j] = k[j] - d; n2[j] = k[j] + d; }
+            L->nbr[((int64_t)j * M + v) * 2 + 0] = table_lookup(L, n1, 0);
+            L->nbr[((int64_t)j * M + v) * 2 + 1] = table_lookup(L, n2, 0);
+        }
+    }
+}
+
 /* Build: the geometry half of splat() for every pixel in order (:376-462 minus the
  * value accumulate), then the blur-neighbour table (:502-522).
  * ref is [n][d] with element strides (rs, cs) so that NCHW views work like the
@@ -218,21 +239,18 @@ phlo_lattice *phlo_build(const float *ref, int64_t n, int d, int64_t rs, int64_t
         }
     }
 
-    int64_t M = L->M;
-    L->nbr = (int32_t *)malloc(sizeof(int32_t) * (M > 0 ? M : 1) * (d + 1) * 2);
-    int16_t n1[PHLO_MAX_D + 1], n2[PHLO_MAX_D + 1];
-    for (int j = 0; j <= d; j++) {
-        for (int64_t v = 0; v < M; v++) {
-            const int16_t *k = L->keys + v * d;
-            for (int i = 0; i < d; i++) { n1[i] = k[i] + 1; n2[i] = k[i] - 1; }
-            /* for j == d the written coordinate is the implied (d+1)-th one, outside the
-             * hashed key, so the neighbour is key +- 1 in all d stored coordinates (:508-509) */
-            if (j < d) { n1[j] = k[j] - d; n2[j] = k[j] + d; }
-            L->nbr[((int64_t)j * M + v) * 2 + 0] = table_lookup(L, n1, 0);
-            L->nbr[((int64_t)j * M + v) * 2 + 1] = table_lookup(L, n2, 0);
-        }
-    }
+    compute_neighbors(L);
     return L;
+}
+
+/* Row-band support (tests of the multi-GPU decomposition): append vertices owned by a
+ * neighbouring band as ghosts; vid_out[i] = local id of key i.  Mirrors phl_add_vertices. */
+void phlo_add_vertices(phlo_lattice *L, const int16_t *keys, int64_t count, int32_t *vid_out)
+{
+    const int d = L->d;
+    L->keys = (int16_t *)realloc(L->keys, sizeof(int16_t) * (size_t)(L->M + count + 1) * d);
+    for (int64_t i = 0; i < count; i++) vid_out[i] = table_lookup(L, keys + i * d, 1);
+    compute_neighbors(L);
 }
 
 void phlo_free(phlo_lattice *L)
@@ -258,31 +276,26 @@ static double now_s(void)
     return t.tv_sec + t.tv_usec * 1e-6;
 }
 
-/* splat values (:454-455) -> blur (:486-548) -> slice (:473-483).
- * src/out are [n][vd] with element strides; dumps (may be NULL) are dense [M][vd].
- * t_stage (may be NULL) receives seconds for {splat, blur, slice}. */
-int phlo_filter(const phlo_lattice *L, const float *src, int vd, int64_t s_rs, int64_t s_cs,
-                float *out, int64_t o_rs, int64_t o_cs,
-                float *splat_dump, float *blur_dump, double *t_stage)
+/* value half of splat(): vert[M][vd] = sum over pixels in order of w*src (:236-238, :454-455) */
+void phlo_splat(const phlo_lattice *L, const float *src, int vd, int64_t s_rs, int64_t s_cs, float *vert)
 {
     const int d = L->d;
-    const int64_t n = L->n, M = L->M;
-    if (vd < 1) return 2;
-    size_t vbytes = sizeof(float) * (size_t)(M > 0 ? M : 1) * vd;
-    float *val = (float *)calloc(1, vbytes);
-    float *tmp = (float *)malloc(vbytes);
-    double t0 = now_s();
-
-    for (int64_t p = 0; p < n; p++)
+    memset(vert, 0, sizeof(float) * (size_t)L->M * vd);
+    for (int64_t p = 0; p < L->n; p++)
         for (int r = 0; r <= d; r++) {
-            float *v = val + (int64_t)L->rvid[p * (d + 1) + r] * vd;
+            float *v = vert + (int64_t)L->rvid[p * (d + 1) + r] * vd;
             float w = L->rw[p * (d + 1) + r];
             for (int c = 0; c < vd; c++) v[c] += (w * src[p * s_rs + c * s_cs]);
         }
-    if (splat_dump) memcpy(splat_dump, val, sizeof(float) * M * vd);
-    double t1 = now_s();
+}
 
-    float *oldv = val, *newv = tmp;
+/* blur() (:486-548): axes 0..d, Jacobi ping-pong, absent neighbour = 0; in place on vert */
+void phlo_blur(const phlo_lattice *L, float *vert, int vd)
+{
+    const int d = L->d;
+    const int64_t M = L->M;
+    float *tmp = (float *)malloc(sizeof(float) * (size_t)(M > 0 ? M : 1) * vd);
+    float *oldv = vert, *newv = tmp;
     for (int j = 0; j <= d; j++) {
         for (int64_t v = 0; v < M; v++) {
             int32_t a = L->nbr[((int64_t)j * M + v) * 2 + 0];
@@ -297,24 +310,48 @@ int phlo_filter(const phlo_lattice *L, const float *src, int vd, int64_t s_rs, i
         }
         float *t = newv; newv = oldv; oldv = t;
     }
-    if (blur_dump) memcpy(blur_dump, oldv, sizeof(float) * M * vd);
-    double t2 = now_s();
+    if (oldv != vert) memcpy(vert, oldv, sizeof(float) * (size_t)M * vd);
+    free(tmp);
+}
 
+/* slice() (:473-483): out[p] = sum_r w_r * vert[v_r] / (1 + 2^-d), term by term */
+void phlo_slice(const phlo_lattice *L, const float *vert, int vd, float *out, int64_t o_rs, int64_t o_cs)
+{
+    const int d = L->d;
     float col[4096];
     float *colp = vd <= 4096 ? col : (float *)malloc(sizeof(float) * vd);
-    for (int64_t p = 0; p < n; p++) {
+    for (int64_t p = 0; p < L->n; p++) {
         for (int c = 0; c < vd; c++) colp[c] = 0;
         for (int r = 0; r <= d; r++) {
-            const float *v = oldv + (int64_t)L->rvid[p * (d + 1) + r] * vd;
+            const float *v = vert + (int64_t)L->rvid[p * (d + 1) + r] * vd;
             float w = L->rw[p * (d + 1) + r];
             for (int c = 0; c < vd; c++) colp[c] += w * v[c] / (1 + powf(2, -d));
         }
         for (int c = 0; c < vd; c++) out[p * o_rs + c * o_cs] = colp[c];
     }
+    if (colp != col) free(colp);
+}
+
+/* splat -> blur -> slice.  src/out are [n][vd] with element strides; dumps (may be NULL) are
+ * dense [M][vd].  t_stage (may be NULL) receives seconds for {splat, blur, slice}. */
+int phlo_filter(const phlo_lattice *L, const float *src, int vd, int64_t s_rs, int64_t s_cs,
+                float *out, int64_t o_rs, int64_t o_cs,
+                float *splat_dump, float *blur_dump, double *t_stage)
+{
+    const int64_t M = L->M;
+    if (vd < 1) return 2;
+    float *val = (float *)malloc(sizeof(float) * (size_t)(M > 0 ? M : 1) * vd);
+    double t0 = now_s();
+    phlo_splat(L, src, vd, s_rs, s_cs, val);
+    if (splat_dump) memcpy(splat_dump, val, sizeof(float) * M * vd);
+    double t1 = now_s();
+    phlo_blur(L, val, vd);
+    if (blur_dump) memcpy(blur_dump, val, sizeof(float) * M * vd);
+    double t2 = now_s();
+    phlo_slice(L, val, vd, out, o_rs, o_cs);
     double t3 = now_s();
     if (t_stage) { t_stage[0] = t1 - t0; t_stage[1] = t2 - t1; t_stage[2] = t3 - t2; }
-    if (colp != col) free(colp);
-    free(val); free(tmp);
+    free(val);
     return L->status;
 }
 

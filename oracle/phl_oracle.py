@@ -62,6 +62,10 @@ def _oracle_lib():
         lib.phlo_filter.argtypes = [C.c_void_p, _f32p, C.c_int, C.c_int64, C.c_int64,
                                     _f32p, C.c_int64, C.c_int64, _f32p, _f32p, _f64p]
         lib.phlo_scale_factors.argtypes = [C.c_int, _f32p]
+        lib.phlo_add_vertices.argtypes = [C.c_void_p, _i16p, C.c_int64, _i32p]
+        lib.phlo_splat.argtypes = [C.c_void_p, _f32p, C.c_int, C.c_int64, C.c_int64, _f32p]
+        lib.phlo_blur.argtypes = [C.c_void_p, _f32p, C.c_int]
+        lib.phlo_slice.argtypes = [C.c_void_p, _f32p, C.c_int, _f32p, C.c_int64, C.c_int64]
         _lib = lib
     return _lib
 
@@ -103,6 +107,32 @@ class Oracle:
     def neighbors(self):
         out = np.empty((self.d + 1, self.M, 2), np.int32)
         _oracle_lib().phlo_get_neighbors(self._h, _ptr(out, _i32p))
+        return out
+
+    # ---- stage API + ghost vertices (same surface as phl.Lattice; used by the row-band tests) ----
+    def add_vertices(self, keys):
+        keys = np.ascontiguousarray(keys, np.int16).reshape(-1, self.d)
+        vid = np.empty(len(keys), np.int32)
+        _oracle_lib().phlo_add_vertices(self._h, _ptr(keys, _i16p), len(keys), _ptr(vid, _i32p))
+        self.M = int(_oracle_lib().phlo_num_vertices(self._h))
+        return vid
+
+    def splat(self, src):
+        src = np.asarray(src, np.float32)
+        vert = np.empty((self.M, src.shape[1]), np.float32)
+        rs, cs = (s // 4 for s in src.strides)
+        _oracle_lib().phlo_splat(self._h, _ptr(src, _f32p), src.shape[1], rs, cs, _ptr(vert, _f32p))
+        return vert
+
+    def blur(self, vert):
+        vert = np.array(vert, np.float32, order="C", copy=True)
+        _oracle_lib().phlo_blur(self._h, _ptr(vert, _f32p), vert.shape[1])
+        return vert
+
+    def slice(self, vert):
+        vert = np.ascontiguousarray(vert, np.float32)
+        out = np.empty((self.n, vert.shape[1]), np.float32)
+        _oracle_lib().phlo_slice(self._h, _ptr(vert, _f32p), vert.shape[1], _ptr(out, _f32p), vert.shape[1], 1)
         return out
 
     def filter(self, src, stages=False, timing=False):

@@ -1,0 +1,110 @@
+"""CPU: the N>1 path.  The row-band decomposition + boundary-vertex exchange of phl/rowtile.py
+run with the CPU oracle as the per-rank engine: (a) all ranks played in one process
+(loopback), (b) two real processes over torch.distributed/gloo, world_size 2.  Both must
+reproduce the single-lattice filter within the north-star tolerance."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+RTOL = 1e-4
+
+
+def make_image(H, W, L, sigma_xy=2.0, seed=0):
+    rng = np.random.default_rng(seed)
+    feat = np.empty((H, W, 5), np.float32)
+    feat[..., 0] = (np.arange(W, dtype=np.float32) / sigma_xy)[None, :]
+    feat[..., 1] = (np.arange(H, dtype=np.float32) / sigma_xy)[:, None]
+    col = rng.random((H // 4 + 1, W // 4 + 1, 3)).astype(np.float32)
+    feat[..., 2:] = np.kron(col, np.ones((4, 4, 1), np.float32))[:H, :W] * 6
+    src = rng.random((H * W, L), dtype=np.float32)
+    return feat, src
+
+
+def rel(a, b):
+    return float((np.abs(a - b) / np.maximum(np.abs(b), 1e-3 * np.abs(b).max())).max())
+
+
+def test_strip_rows_formula():
+    from phl import rowtile
+
+    feat, _ = make_image(40, 8, 1, sigma_xy=2.0)
+    assert rowtile.strip_rows(feat) == int(np.ceil(6.0 / 0.5)) + 1      # d=5: sqrt(6*6)=6 units, g=0.5/row
+    with pytest.raises(ValueError, match="monotone"):
+        rowtile.strip_rows(np.zeros((10, 4, 3), np.float32))
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_loopback_bands_match_single_lattice(world):
+    from oracle import phl_oracle as po
+    from phl import rowtile
+    from _engines import OracleEngine
+
+    H, W, L = 30 * world, 20, 5
+    feat, src = make_image(H, W, L)
+    want = po.oracle_filter(src, feat.reshape(-1, 5))
+    got, bands = rowtile.simulate(feat, torch.from_numpy(src), world, OracleEngine, torch.device("cpu"))
+    assert rel(got.numpy(), want) <= RTOL
+    # the exchange is really needed: without ghosts the cut rows are wrong
+    top = po.oracle_filter(src[:bands[0].n_local], feat[:bands[0].own_rows].reshape(-1, 5))
+    assert rel(top, want[:bands[0].n_local]) > 1e-2
+    assert all(b.M > b.eng._o.M - 1 for b in bands) and bands[0].S == 13
+
+
+def test_too_many_ranks_is_rejected():
+    from phl import rowtile
+    from _engines import OracleEngine
+
+    feat, src = make_image(24, 8, 2)
+    with pytest.raises(ValueError, match="shorter than the lattice support"):
+        rowtile.simulate(feat, torch.from_numpy(src), 4, OracleEngine, torch.device("cpu"))
+
+
+def _worker(rank, world, port, H, W, L, q):
+    sys.path.insert(0, os.path.join(ROOT, "depth-estimation_amd"))
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as dist
+    from phl import rowtile
+    from _engines import OracleEngine
+
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    feat, src = make_image(H, W, L)
+    job = rowtile.RowTileFilter(feat, L, rank, world, torch.device("cpu"), dist, engine_factory=OracleEngine)
+    mine = torch.from_numpy(src[job.row0 * W:(job.row0 + job.own_rows) * W])
+    out1 = job.filter(mine)
+    out2 = job.filter(mine)          # second call: buffers are reused
+    assert torch.equal(out1, out2)
+    q.put((rank, job.row0, out1.numpy(), job.describe()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_over_gloo():
+    from oracle import phl_oracle as po
+
+    H, W, L, world = 64, 16, 4, 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, H, W, L, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    feat, src = make_image(H, W, L)
+    want = po.oracle_filter(src, feat.reshape(-1, 5))
+    got = np.concatenate([r[2] for r in res], 0)
+    assert rel(got, want) <= RTOL
+    info = res[0][3]["rowtile"]
+    assert info["strip_rows"] == 13 and info["exchange_bytes_per_step_per_rank"] > 0
