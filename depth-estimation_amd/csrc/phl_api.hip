@@ -105,6 +105,7 @@ int phl_build(phl_lattice **out, const float *ref_dev, int64_t n, int d, int64_t
     lat->d = d;
     lat->n = n;
     int rc = phl_build_device(lat, ref_dev, rs, cs, (hipStream_t)stream);
+    if (rc == PHL_OK) rc = phl_tiles_build(lat, ref_dev, rs, cs, (hipStream_t)stream);
     if (rc != PHL_OK) {
         phl_destroy(lat);
         return rc;
@@ -117,6 +118,7 @@ int phl_destroy(phl_lattice *lat)
 {
     if (!lat) return PHL_OK;
     device_guard g(lat->device);
+    phl_tiles_free(lat);
     void *ptrs[] = {lat->vkeys, lat->replay, lat->csr_ptr, lat->csr, lat->nbr, lat->table, lat->buf[0], lat->buf[1], lat->stage_in, lat->stage_out};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -131,7 +133,7 @@ int phl_device(const phl_lattice *lat) { return lat ? lat->device : -1; }
 int64_t phl_device_bytes(const phl_lattice *lat)
 {
     if (!lat) return -1;
-    return lat->table_bytes + 2 * lat->buf_elems * (int64_t)sizeof(float) + 2 * lat->stage_elems * (int64_t)sizeof(float);
+    return lat->table_bytes + lat->tile_bytes + lat->partial_elems * (int64_t)sizeof(float) + 2 * lat->buf_elems * (int64_t)sizeof(float) + 2 * lat->stage_elems * (int64_t)sizeof(float);
 }
 
 int64_t phl_num_local_vertices(const phl_lattice *lat) { return lat ? lat->M_local : -1; }
@@ -141,7 +143,37 @@ int phl_add_vertices(phl_lattice *lat, const int16_t *keys_host, int64_t count, 
     if (!lat || count < 0 || (count > 0 && (!keys_host || !vid_host))) { phl_set_error("phl_add_vertices: bad arguments"); return PHL_ERR_INVALID; }
     if (lat->M + count > ((int64_t)1 << 30)) { phl_set_error("phl_add_vertices: too many vertices"); return PHL_ERR_TOO_LARGE; }
     device_guard g(lat->device);
-    return phl_add_vertices_device(lat, keys_host, count, vid_host, (hipStream_t)stream);
+    const int64_t M_before = lat->M;
+    int rc = phl_add_vertices_device(lat, keys_host, count, vid_host, (hipStream_t)stream);
+    if (rc == PHL_OK && lat->M != M_before) rc = phl_tiles_link_vertices(lat, (hipStream_t)stream);
+    return rc;
+}
+
+namespace {
+bool use_tiled_splat(const phl_lattice *lat, int vd, unsigned flags, const void *a, const void *b, int64_t rs)
+{
+    if (flags & (PHL_FILTER_EXACT_ORDER | PHL_FILTER_NO_TILES)) return false;
+    if (phl_tiles_lprs(lat, vd, 0) < 0) return false;
+    if ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) & 15 || rs % 4) return false;
+    return lat->S_multi <= lat->n;   // partial-row traffic must stay below what staging saves
+}
+bool use_tiled_slice(const phl_lattice *lat, int vd, unsigned flags, const void *a, const void *b, const void *c, int64_t rs,
+                     int64_t rs2)
+{
+    if (flags & PHL_FILTER_NO_TILES) return false;
+    if (phl_tiles_lprs(lat, vd, 1) < 0) return false;
+    if ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(c)) & 15 || rs % 4 || rs2 % 4) return false;
+    return lat->S <= 3 * lat->n;
+}
+}  // namespace
+
+int phl_tile_stats(const phl_lattice *lat, int vd, int64_t out[7])
+{
+    if (!lat || !out) { phl_set_error("phl_tile_stats: bad arguments"); return PHL_ERR_INVALID; }
+    out[0] = lat->P; out[1] = lat->nchunks; out[2] = lat->nv_max; out[3] = lat->S; out[4] = lat->S_multi;
+    out[5] = use_tiled_splat(lat, vd, 0, nullptr, nullptr, 0);
+    out[6] = use_tiled_slice(lat, vd, 0, nullptr, nullptr, nullptr, 0, 0);
+    return PHL_OK;
 }
 
 int phl_reserve(phl_lattice *lat, int vd)
@@ -149,7 +181,10 @@ int phl_reserve(phl_lattice *lat, int vd)
     if (!lat || vd < 0) { phl_set_error("phl_reserve: bad arguments"); return PHL_ERR_INVALID; }
     device_guard g(lat->device);
     const int64_t need = lat->M * (int64_t)vd;
-    if (need <= lat->buf_elems) return PHL_OK;
+    if (need <= lat->buf_elems) {
+        if (phl_tiles_lprs(lat, vd, 0) >= 0 && lat->S_multi <= lat->n) return phl_tiles_reserve(lat, vd);
+        return PHL_OK;
+    }
     int64_t cap0 = lat->buf_elems, cap1 = lat->buf_elems;
     int rc = grow(&lat->buf[0], &cap0, need);
     if (rc) { lat->buf_elems = 0; return rc; }
@@ -159,10 +194,18 @@ int phl_reserve(phl_lattice *lat, int vd)
     return PHL_OK;
 }
 
-int phl_splat(phl_lattice *lat, const float *src, int vd, int64_t src_rs, float *vert, phl_stream st)
+[[maybe_unused]] static int reserve_all(phl_lattice *lat, int vd)
+{
+    int rc = phl_reserve(lat, vd);
+    if (rc == PHL_OK && phl_tiles_lprs(lat, vd, 0) >= 0 && lat->S_multi <= lat->n) rc = phl_tiles_reserve(lat, vd);
+    return rc;
+}
+
+int phl_splat(phl_lattice *lat, const float *src, int vd, int64_t src_rs, float *vert, unsigned flags, phl_stream st)
 {
     if (!lat || vd < 0 || (lat->n > 0 && vd > 0 && (!src || !vert))) { phl_set_error("phl_splat: bad arguments"); return PHL_ERR_INVALID; }
     device_guard g(lat->device);
+    if (use_tiled_splat(lat, vd, flags, src, vert, src_rs)) return phl_launch_splat_tiled(lat, src, src_rs, vd, vert, (hipStream_t)st);
     return phl_launch_splat(lat, src, src_rs, vd, vert, (hipStream_t)st);
 }
 
@@ -178,6 +221,8 @@ int phl_slice(phl_lattice *lat, const float *vert, int vd, float *out, int64_t o
 {
     if (!lat || vd < 0) { phl_set_error("phl_slice: bad arguments"); return PHL_ERR_INVALID; }
     device_guard g(lat->device);
+    if (use_tiled_slice(lat, vd, flags, vert, out, sub, out_rs, sub ? sub_rs : 0))
+        return phl_launch_slice_tiled(lat, vert, vd, out, out_rs, sub, sub_rs, flags, (hipStream_t)st);
     return phl_launch_slice(lat, vert, vd, out, out_rs, sub, sub_rs, flags, (hipStream_t)st);
 }
 
@@ -223,7 +268,8 @@ int phl_filter(phl_lattice *lat, const float *src, int vd, int64_t src_rs, int64
         out_eff_rs = vd;
     }
 
-    rc = phl_launch_splat(lat, src_eff, src_eff_rs, vd, lat->buf[0], st);
+    if (use_tiled_splat(lat, vd, flags, src_eff, lat->buf[0], src_eff_rs)) rc = phl_launch_splat_tiled(lat, src_eff, src_eff_rs, vd, lat->buf[0], st);
+    else rc = phl_launch_splat(lat, src_eff, src_eff_rs, vd, lat->buf[0], st);
     if (rc) return rc;
     int cur = 0;
     for (int axis = 0; axis <= lat->d; axis++) {  // axis order 0..d, Jacobi ping-pong (:498, :530-532)
@@ -232,7 +278,10 @@ int phl_filter(phl_lattice *lat, const float *src, int vd, int64_t src_rs, int64
         cur ^= 1;
     }
     const float *sub = (flags & PHL_FILTER_SUBTRACT_INPUT) ? src_eff : nullptr;
-    rc = phl_launch_slice(lat, lat->buf[cur], vd, out_eff, out_eff_rs, sub, src_eff_rs, flags, st);
+    if (use_tiled_slice(lat, vd, flags, lat->buf[cur], out_eff, sub, out_eff_rs, sub ? src_eff_rs : 0))
+        rc = phl_launch_slice_tiled(lat, lat->buf[cur], vd, out_eff, out_eff_rs, sub, src_eff_rs, flags, st);
+    else
+        rc = phl_launch_slice(lat, lat->buf[cur], vd, out_eff, out_eff_rs, sub, src_eff_rs, flags, st);
     if (rc) return rc;
     if (stage_dst) rc = phl_launch_copy2d(lat->stage_out, vd, 1, out, out_rs, out_cs, n, vd, st);
     return rc;

@@ -37,6 +37,25 @@ struct phl_lattice {
     uint32_t table_mask;
     int64_t M_local;        // vertices created by this lattice's own pixels (ghosts come after)
 
+    // pixel chunks ("tiles") for the LDS-staged splat / slice (phl_tiles.hip)
+    int P;                  // pixels per chunk
+    int nchunks;
+    int nv_max;             // max local vertices of any chunk
+    int64_t S;              // total (chunk, local vertex) slots
+    int64_t S_multi;        // slots whose vertex has contributions from several chunks
+    int32_t *pix_order;     // [n] pixels in cell-major order; chunk c = pix_order[c*P ...)
+    int32_t *chunk_vptr;    // [nchunks+1] slot range of each chunk
+    int32_t *slot_vert;     // [S] vertex id (bit 31: this chunk is the vertex's only contributor)
+    int32_t *slot_pidx;     // [S+1] row of the slot in the partial buffer (multi-chunk vertices)
+    int32_t *seg_ptr;       // [S+1] segment of each slot in seg[]
+    phl_contrib_t *seg;     // [N] {pixel index inside the chunk, weight}, ascending pixel per slot
+    unsigned short *lidx;   // [N] local vertex index per (chunk pixel, remainder)
+    int32_t *vs_ptr;        // [M+1] slots of each vertex ...
+    phl_contrib_t *vs;      // [S]   ... ascending (slot index in .pixel)
+    float *partial;         // [S_multi][vd] partial splat sums
+    int64_t partial_elems;
+    int64_t tile_bytes;
+
     // value workspace, grown on demand
     float *buf[2];
     int64_t buf_elems;      // capacity of each buffer in floats
@@ -59,6 +78,16 @@ int phl_hip_fail(hipError_t e, const char *what, const char *file, int line);
 // ---- launchers implemented in phl_build.hip ----
 int phl_build_device(phl_lattice *lat, const float *ref, int64_t rs, int64_t cs, hipStream_t st);
 int phl_add_vertices_device(phl_lattice *lat, const int16_t *keys_host, int64_t count, int32_t *vid_host, hipStream_t st);
+
+// ---- implemented in phl_tiles.hip ----
+int phl_tiles_build(phl_lattice *lat, const float *ref, int64_t rs, int64_t cs, hipStream_t st);
+int phl_tiles_link_vertices(phl_lattice *lat, hipStream_t st);
+int phl_tiles_free(phl_lattice *lat);
+int phl_tiles_lprs(const phl_lattice *lat, int vd, int for_slice);  // -1: LDS-staged path unavailable
+int phl_tiles_reserve(phl_lattice *lat, int vd);
+int phl_launch_splat_tiled(phl_lattice *lat, const float *src, int64_t src_rs, int vd, float *vert, hipStream_t st);
+int phl_launch_slice_tiled(const phl_lattice *lat, const float *vert, int vd, float *out, int64_t out_rs, const float *sub,
+                           int64_t sub_rs, unsigned flags, hipStream_t st);
 
 // ---- launchers implemented in phl_filter.hip ----
 int phl_launch_splat(const phl_lattice *lat, const float *src, int64_t src_rs, int vd, float *vert, hipStream_t st);

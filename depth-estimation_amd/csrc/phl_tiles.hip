@@ -1,0 +1,690 @@
+// phl_tiles.hip -- pixel chunks ("tiles") and the LDS-staged splat / slice kernels.
+//
+// Why: in the plain gather kernels (phl_filter.hip) every pixel row is re-read by its d+1
+// vertices (splat) and every vertex row by all pixels of its cell (slice).  Those re-reads
+// come out of L2 / the Infinity Cache at fabric rate and bound the kernels (round-1 profile:
+// splat moved 19 GB for 3.2 GB of input).  A chunk is a set of <= P pixels that are close in
+// feature space, so they share most of their lattice vertices; a workgroup stages the chunk's
+// rows ONCE in LDS (channel slab by channel slab) and all reuse happens there:
+//
+//   k_splat_tiled   stage Q[chunk pixels][slab] -> every local vertex sums its pixel-sorted
+//                   segment out of LDS -> the vertex row if this chunk is the vertex's only
+//                   contributor, else a partial row; k_splat_reduce then adds a vertex's
+//                   partial rows in ascending chunk order (deterministic, no float atomics)
+//   k_slice_tiled   stage vert[chunk's local vertices][slab] -> every pixel gathers its d+1
+//                   rows from LDS with the reference's per-term arithmetic (bit-exact)
+//
+// Chunks need no image geometry: pixels are ordered by the cell of a uniform 2-D grid laid over
+// the two feature dimensions with the widest range (for an image: x/sigma, y/sigma ->
+// sqrt(P) x sqrt(P) pixel tiles), then cut into runs of P.  Any other data still works, only
+// with less sharing; the host falls back to the gather kernels when sharing is poor.
+//
+// Reference semantics are those of crf/lattice/lite/permutohedral.h:454-455 (splat
+// accumulate) and :473-483 (slice); summation ORDER of multi-chunk vertices differs from the
+// reference's pixel order (partial sums), hence results agree to fp32 rounding (~1e-7), not
+// bit for bit; PHL_FILTER_EXACT_ORDER selects the pixel-ordered gather splat instead.
+#include <math.h>
+#include <stdlib.h>
+
+#include <type_traits>
+#include <vector>
+
+#include "phl_device_utils.h"
+
+namespace {
+
+// ---- feature ranges --------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_minmax(const float *__restrict__ ref, int64_t rs, int64_t cs, int64_t n, int d,
+                                                float *__restrict__ out /* [grid][d][2] */)
+{
+    __shared__ float smin[4][PHL_MAX_D], smax[4][PHL_MAX_D];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int i = 0; i < d; i++) {
+        float lo = INFINITY, hi = -INFINITY;
+        for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (int64_t)gridDim.x * blockDim.x) {
+            const float v = ref[p * rs + i * cs];
+            lo = fminf(lo, v);
+            hi = fmaxf(hi, v);
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            lo = fminf(lo, __shfl_xor(lo, o));
+            hi = fmaxf(hi, __shfl_xor(hi, o));
+        }
+        if (lane == 0) { smin[w][i] = lo; smax[w][i] = hi; }
+    }
+    __syncthreads();
+    if (threadIdx.x < d) {
+        float lo = smin[0][threadIdx.x], hi = smax[0][threadIdx.x];
+        for (int k = 1; k < 4; k++) { lo = fminf(lo, smin[k][threadIdx.x]); hi = fmaxf(hi, smax[k][threadIdx.x]); }
+        out[((int64_t)blockIdx.x * d + threadIdx.x) * 2 + 0] = lo;
+        out[((int64_t)blockIdx.x * d + threadIdx.x) * 2 + 1] = hi;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_cell_ids(const float *__restrict__ ref, int64_t rs, int64_t cs, int64_t n, int da,
+                                                  int db, float lo_a, float lo_b, float inv_t, int nca, int ncb,
+                                                  int *__restrict__ cell, int *cnt)
+{
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    int ca = (int)((ref[p * rs + da * cs] - lo_a) * inv_t);
+    ca = min(max(ca, 0), nca - 1);
+    int cb = 0;
+    if (db >= 0) {
+        cb = (int)((ref[p * rs + db * cs] - lo_b) * inv_t);
+        cb = min(max(cb, 0), ncb - 1);
+    }
+    const int c = cb * nca + ca;   // the wider dimension runs fastest inside a row of cells
+    cell[p] = c;
+    atomicAdd(&cnt[c], 1);
+}
+
+__global__ __launch_bounds__(256) void k_group_fill(const int *__restrict__ key, const int *__restrict__ ptr, int *cursor,
+                                                    int n, phl_contrib_t *__restrict__ tmp)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int k = key[i];
+    phl_contrib_t c;
+    c.pixel = i;
+    c.w = 0.f;
+    tmp[ptr[k] + atomicAdd(&cursor[k], 1)] = c;
+}
+
+__global__ __launch_bounds__(256) void k_extract_index(const phl_contrib_t *__restrict__ in, int n, int *__restrict__ out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = in[i].pixel;
+}
+
+// ---- per-chunk structure: one workgroup sorts the chunk's (vertex, entry) pairs in LDS -----------
+// entry e = k*(d+1)+r of the chunk (k-th pixel in chunk order, remainder r).  After the sort
+// the pairs are grouped by vertex with ascending e, i.e. ascending pixel: exactly the
+// per-vertex segment the splat needs.  WRITE=false only counts the distinct vertices.
+template <int SORTN, bool WRITE>
+__global__ __launch_bounds__(256) void k_chunk_sort(const int *__restrict__ pix_order, int n, int P, int dp1,
+                                                    const phl_replay_t *__restrict__ replay, int *__restrict__ nv_out,
+                                                    const int *__restrict__ vptr, int *__restrict__ slot_vert,
+                                                    int *__restrict__ seg_ptr, phl_contrib_t *__restrict__ seg,
+                                                    unsigned short *__restrict__ lidx)
+{
+    __shared__ unsigned long long keys[SORTN];
+    const int c = blockIdx.x;
+    const int base = c * P;
+    const int cnt = min(P, n - base);
+    const int E = cnt * dp1;
+    for (int e = threadIdx.x; e < SORTN; e += 256) {
+        unsigned long long key = ~0ull;
+        if (e < E) {
+            const int k = e / dp1, r = e - k * dp1;
+            const int p = pix_order[base + k];
+            key = ((unsigned long long)(unsigned)replay[(int64_t)p * dp1 + r].vid << 32) | (unsigned)e;
+        }
+        keys[e] = key;
+    }
+    __syncthreads();
+    for (int k = 2; k <= SORTN; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < SORTN; i += 256) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const unsigned long long a = keys[i], b = keys[ixj];
+                    const bool up = (i & k) == 0;
+                    if ((a > b) == up) { keys[i] = b; keys[ixj] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    // heads = first entry of each distinct vertex; local vertex index = (#heads up to here) - 1
+    constexpr int PER = SORTN / 256;
+    const int i0 = threadIdx.x * PER;
+    int heads = 0;
+#pragma unroll
+    for (int u = 0; u < PER; u++) {
+        const int i = i0 + u;
+        if (i < E && (i == 0 || (unsigned)(keys[i] >> 32) != (unsigned)(keys[i - 1] >> 32))) heads++;
+    }
+    int total;
+    int li = block_exclusive_scan(heads, &total) - 1;
+    if (!WRITE) {
+        if (threadIdx.x == 0) nv_out[c] = total;
+        return;
+    }
+    const int vbase = vptr[c];
+    const int64_t ebase = (int64_t)base * dp1;
+#pragma unroll
+    for (int u = 0; u < PER; u++) {
+        const int i = i0 + u;
+        if (i >= E) break;
+        const unsigned vid = (unsigned)(keys[i] >> 32);
+        const int e = (int)(unsigned)keys[i];
+        const bool head = (i == 0) || vid != (unsigned)(keys[i - 1] >> 32);
+        if (head) {
+            li++;
+            slot_vert[vbase + li] = (int)vid;
+            seg_ptr[vbase + li] = (int)(ebase + i);
+        }
+        const int k = e / dp1, r = e - k * dp1;
+        const int p = pix_order[base + k];
+        phl_contrib_t s;
+        s.pixel = k;
+        s.w = replay[(int64_t)p * dp1 + r].w;
+        seg[ebase + i] = s;
+        lidx[ebase + e] = (unsigned short)li;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_count_slots(const int *__restrict__ slot_vert, int S, int *cnt)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s < S) atomicAdd(&cnt[slot_vert[s]], 1);
+}
+
+// mark slots whose vertex has no other chunk (sole) and flag the others for the partial buffer
+__global__ __launch_bounds__(256) void k_mark_sole(int *__restrict__ slot_vert, int S, const int *__restrict__ vs_ptr,
+                                                   int *__restrict__ multi)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= S) return;
+    const int v = slot_vert[s];
+    const bool sole = (vs_ptr[v + 1] - vs_ptr[v]) == 1;
+    if (sole) slot_vert[s] = v | (int)0x80000000;
+    multi[s] = sole ? 0 : 1;
+}
+
+// ---- hot kernels -----------------------------------------------------------------------------
+__device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+__device__ __forceinline__ void st4(float *p, float4 v) { *reinterpret_cast<float4 *>(p) = v; }
+__device__ __forceinline__ float4 mac4(float4 acc, float w, float4 q)   // mul and add rounded separately (:455)
+{
+    return make_float4(acc.x + w * q.x, acc.y + w * q.y, acc.z + w * q.z, acc.w + w * q.w);
+}
+__device__ __forceinline__ float div_c(float t, float c, float rc)
+{
+    float q = t * rc;
+    float rem = __builtin_fmaf(-q, c, t);
+    return __builtin_fmaf(rem, rc, q);
+}
+__device__ __forceinline__ float4 term4(float4 acc, float w, float4 v, float c, float rc)   // acc + (w*v)/c  (:480)
+{
+    return make_float4(acc.x + div_c(w * v.x, c, rc), acc.y + div_c(w * v.y, c, rc), acc.z + div_c(w * v.z, c, rc),
+                       acc.w + div_c(w * v.w, c, rc));
+}
+__device__ __forceinline__ float4 fma4(float4 acc, float w, float4 v)
+{
+    return make_float4(__builtin_fmaf(w, v.x, acc.x), __builtin_fmaf(w, v.y, acc.y), __builtin_fmaf(w, v.z, acc.z),
+                       __builtin_fmaf(w, v.w, acc.w));
+}
+
+// One workgroup per chunk.  LPRS lanes own one row of a channel slab of SL = 4*LPRS floats.
+template <int LPRS>
+__global__ __launch_bounds__(256) void k_splat_tiled(const float *__restrict__ src, int64_t src_rs, int vd, int n, int P,
+                                                     const int *__restrict__ pix_order, const int *__restrict__ vptr,
+                                                     const int *__restrict__ slot_vert, const int *__restrict__ slot_pidx,
+                                                     const int *__restrict__ seg_ptr,
+                                                     const phl_contrib_t *__restrict__ seg, float *__restrict__ vert,
+                                                     float *__restrict__ partial)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int SL = LPRS * 4;
+    constexpr int G = 256 / LPRS;
+    const int g = threadIdx.x / LPRS, l = threadIdx.x % LPRS;
+    const int c = blockIdx.x;
+    const int base = c * P;
+    const int cnt = min(P, n - base);
+    const int vbase = vptr[c], nv = vptr[c + 1] - vbase;
+    for (int c0 = 0; c0 < vd; c0 += SL) {
+        const int ch = c0 + l * 4;
+        const bool chok = ch < vd;
+        for (int k = g; k < cnt; k += G) {
+            const int p = pix_order[base + k];
+            if (chok) st4(lds + k * SL + l * 4, ld4(src + (int64_t)p * src_rs + ch));
+        }
+        __syncthreads();
+        for (int i = g; i < nv; i += G) {
+            const int s0 = seg_ptr[vbase + i], s1 = seg_ptr[vbase + i + 1];
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            int s = s0;
+            for (; s + 2 <= s1; s += 2) {
+                const phl_contrib_t a = seg[s], b = seg[s + 1];
+                const float4 qa = ld4(lds + a.pixel * SL + l * 4);
+                const float4 qb = ld4(lds + b.pixel * SL + l * 4);
+                acc = mac4(acc, a.w, qa);
+                acc = mac4(acc, b.w, qb);
+            }
+            if (s < s1) {
+                const phl_contrib_t a = seg[s];
+                acc = mac4(acc, a.w, ld4(lds + a.pixel * SL + l * 4));
+            }
+            if (chok) {
+                const int v = slot_vert[vbase + i];
+                float *dst = v < 0 ? vert + (int64_t)(v & 0x7FFFFFFF) * vd : partial + (int64_t)slot_pidx[vbase + i] * vd;
+                st4(dst + ch, acc);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// vertices with != 1 contributing chunk: sum their partial rows in ascending chunk order
+// (0 chunks = ghost vertex of a neighbouring row band: zeros).
+template <int LPR>
+__global__ __launch_bounds__(256) void k_splat_reduce(const float *__restrict__ partial, const int *__restrict__ vs_ptr,
+                                                      const phl_contrib_t *__restrict__ vs,
+                                                      const int *__restrict__ slot_pidx, int M, int vd,
+                                                      float *__restrict__ vert)
+{
+    constexpr int Gw = 64 / LPR;
+    const int lane = threadIdx.x & 63;
+    const int sub = lane / LPR, l = lane % LPR;
+    const int wave = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
+    const int64_t stride = (int64_t)gridDim.x * 4 * Gw;
+    for (int64_t v0 = (int64_t)wave * Gw; v0 < M; v0 += stride) {
+        const int64_t v = v0 + sub;
+        if (v >= M) continue;
+        const int beg = vs_ptr[v], end = vs_ptr[v + 1];
+        if (end - beg == 1) continue;
+        for (int ch = l * 4; ch < vd; ch += LPR * 4) {
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int e = beg; e < end; e++) {
+                const float4 q = ld4(partial + (int64_t)slot_pidx[vs[e].pixel] * vd + ch);
+                acc = make_float4(acc.x + q.x, acc.y + q.y, acc.z + q.z, acc.w + q.w);
+            }
+            st4(vert + v * vd + ch, acc);
+        }
+    }
+}
+
+template <int LPRS, bool EXACT>
+__global__ __launch_bounds__(256) void k_slice_tiled(const float *__restrict__ vert, int vd, int n, int P, int dp1,
+                                                     const int *__restrict__ pix_order, const int *__restrict__ vptr,
+                                                     const int *__restrict__ slot_vert,
+                                                     const unsigned short *__restrict__ lidx,
+                                                     const phl_replay_t *__restrict__ replay, float *__restrict__ out,
+                                                     int64_t out_rs, const float *__restrict__ sub_src, int64_t sub_rs,
+                                                     float cdiv, float rcdiv)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int SL = LPRS * 4;
+    constexpr int G = 256 / LPRS;
+    const int g = threadIdx.x / LPRS, l = threadIdx.x % LPRS;
+    const int c = blockIdx.x;
+    const int base = c * P;
+    const int cnt = min(P, n - base);
+    const int vbase = vptr[c], nv = vptr[c + 1] - vbase;
+    for (int c0 = 0; c0 < vd; c0 += SL) {
+        const int ch = c0 + l * 4;
+        const bool chok = ch < vd;
+        for (int i = g; i < nv; i += G) {
+            const int v = slot_vert[vbase + i] & 0x7FFFFFFF;
+            if (chok) st4(lds + i * SL + l * 4, ld4(vert + (int64_t)v * vd + ch));
+        }
+        __syncthreads();
+        for (int k = g; k < cnt; k += G) {
+            const int p = pix_order[base + k];
+            const phl_replay_t *rp = replay + (int64_t)p * dp1;
+            const unsigned short *li = lidx + (int64_t)(base + k) * dp1;
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            int r = 0;
+            for (; r + 3 <= dp1; r += 3) {
+                const float w0 = rp[r].w, w1 = rp[r + 1].w, w2 = rp[r + 2].w;
+                const float4 q0 = ld4(lds + li[r] * SL + l * 4);
+                const float4 q1 = ld4(lds + li[r + 1] * SL + l * 4);
+                const float4 q2 = ld4(lds + li[r + 2] * SL + l * 4);
+                if (EXACT) {
+                    acc = term4(acc, w0, q0, cdiv, rcdiv);
+                    acc = term4(acc, w1, q1, cdiv, rcdiv);
+                    acc = term4(acc, w2, q2, cdiv, rcdiv);
+                } else {
+                    acc = fma4(acc, w0, q0);
+                    acc = fma4(acc, w1, q1);
+                    acc = fma4(acc, w2, q2);
+                }
+            }
+            for (; r < dp1; r++) {
+                const float w0 = rp[r].w;
+                const float4 q0 = ld4(lds + li[r] * SL + l * 4);
+                if (EXACT) acc = term4(acc, w0, q0, cdiv, rcdiv);
+                else acc = fma4(acc, w0, q0);
+            }
+            if (chok) {
+                if (!EXACT) acc = make_float4(acc.x * rcdiv, acc.y * rcdiv, acc.z * rcdiv, acc.w * rcdiv);
+                if (sub_src) {
+                    const float4 s = ld4(sub_src + (int64_t)p * sub_rs + ch);
+                    acc = make_float4(acc.x - s.x, acc.y - s.y, acc.z - s.z, acc.w - s.w);
+                }
+                st4(out + (int64_t)p * out_rs + ch, acc);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void k_strip_marks(int *slot_vert, int S)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s < S) slot_vert[s] &= 0x7FFFFFFF;
+}
+
+template <typename F>
+inline void dispatch_lprs(int lprs, F &&f)
+{
+    switch (lprs) {
+        case 64: f(std::integral_constant<int, 64>{}); break;
+        case 32: f(std::integral_constant<int, 32>{}); break;
+        case 16: f(std::integral_constant<int, 16>{}); break;
+        case 8: f(std::integral_constant<int, 8>{}); break;
+        default: f(std::integral_constant<int, 4>{}); break;
+    }
+}
+
+int lds_budget()
+{
+    static int b = [] {
+        const char *e = getenv("PHL_TILE_LDS");
+        int v = e ? atoi(e) : 65536;
+        return v < 4096 ? 4096 : (v > 65536 ? 65536 : v);
+    }();
+    return b;
+}
+
+// lanes (of 4 floats) per slab row: as wide as vd, narrowed until `rows` rows fit in LDS;
+// -1 if even the narrowest slab does not fit
+inline int pick_lprs(int vd, int rows)
+{
+    const int need = (vd + 3) / 4;
+    int lprs = 4;
+    while (lprs < 64 && lprs < need) lprs <<= 1;
+    while (lprs > 4 && (int64_t)rows * lprs * 16 > lds_budget()) lprs >>= 1;
+    return (int64_t)rows * lprs * 16 > lds_budget() ? -1 : lprs;
+}
+
+inline int pick_lpr_row(int vd)
+{
+    const int need = (vd + 3) / 4;
+    return need >= 64 ? 64 : need >= 16 ? 16 : need >= 4 ? 4 : 1;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+int phl_tiles_free(phl_lattice *lat)
+{
+    void *ptrs[] = {lat->pix_order, lat->chunk_vptr, lat->slot_vert, lat->slot_pidx, lat->seg_ptr, lat->seg,
+                    lat->lidx, lat->vs_ptr, lat->vs, lat->partial};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    lat->pix_order = lat->chunk_vptr = lat->slot_vert = lat->slot_pidx = lat->seg_ptr = lat->vs_ptr = nullptr;
+    lat->seg = lat->vs = nullptr;
+    lat->lidx = nullptr;
+    lat->partial = nullptr;
+    lat->partial_elems = 0;
+    lat->nchunks = 0;
+    lat->S = lat->S_multi = 0;
+    lat->nv_max = 0;
+    return PHL_OK;
+}
+
+// vertex -> slots lists (ascending slot = ascending chunk), sole marks and partial-row indices.
+// Also called after ghost vertices were appended (M grew, the slots did not change).
+int phl_tiles_link_vertices(phl_lattice *lat, hipStream_t st)
+{
+    const int M = (int)lat->M, S = (int)lat->S;
+    if (lat->vs_ptr) PHL_HIP(hipFree(lat->vs_ptr));
+    if (lat->vs) PHL_HIP(hipFree(lat->vs));
+    if (lat->slot_pidx) PHL_HIP(hipFree(lat->slot_pidx));
+    lat->vs_ptr = nullptr;
+    lat->vs = nullptr;
+    lat->slot_pidx = nullptr;
+    lat->S_multi = 0;
+    PHL_HIP(hipMalloc((void **)&lat->vs_ptr, sizeof(int) * ((size_t)M + 1)));
+    PHL_HIP(hipMalloc((void **)&lat->vs, sizeof(phl_contrib_t) * ((size_t)S + 1)));
+    PHL_HIP(hipMalloc((void **)&lat->slot_pidx, sizeof(int) * ((size_t)S + 1)));
+    if (S == 0) {
+        PHL_HIP(hipMemsetAsync(lat->vs_ptr, 0, sizeof(int) * ((size_t)M + 1), st));
+        PHL_HIP(hipStreamSynchronize(st));
+        return PHL_OK;
+    }
+    temp_pool tmp;
+    int *cnt, *cursor, *multi, *tile_sums;
+    phl_contrib_t *vtmp;
+    PHL_HIP(tmp.get(&cnt, (size_t)M * 2 + 2));
+    PHL_HIP(tmp.get(&multi, (size_t)S + 1));
+    PHL_HIP(tmp.get(&tile_sums, (size_t)(S > M ? S : M) / SCAN_TILE + 2));
+    PHL_HIP(tmp.get(&vtmp, (size_t)S + 1));
+    cursor = cnt + M + 1;
+    PHL_HIP(hipMemsetAsync(cnt, 0, sizeof(int) * ((size_t)M * 2 + 2), st));
+    const unsigned gS = (unsigned)((S + 255) / 256);
+    hipLaunchKernelGGL(k_strip_marks, dim3(gS), dim3(256), 0, st, lat->slot_vert, S);
+    hipLaunchKernelGGL(k_count_slots, dim3(gS), dim3(256), 0, st, lat->slot_vert, S, cnt);
+    PHL_HIP(hipGetLastError());
+    int rc = exclusive_scan(cnt, lat->vs_ptr, M, tile_sums, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_group_fill, dim3(gS), dim3(256), 0, st, lat->slot_vert, lat->vs_ptr, cursor, S, vtmp);
+    {
+        int blocks = (M + 3) / 4;
+        if (blocks > 256 * 16) blocks = 256 * 16;
+        if (blocks < 1) blocks = 1;
+        hipLaunchKernelGGL(k_sort_lists, dim3(blocks), dim3(256), 0, st, vtmp, lat->vs_ptr, M, lat->vs);
+    }
+    hipLaunchKernelGGL(k_mark_sole, dim3(gS), dim3(256), 0, st, lat->slot_vert, S, lat->vs_ptr, multi);
+    PHL_HIP(hipGetLastError());
+    rc = exclusive_scan(multi, lat->slot_pidx, S, tile_sums, st);
+    if (rc) return rc;
+    int s_multi = 0;
+    PHL_HIP(hipMemcpyAsync(&s_multi, lat->slot_pidx + S, sizeof(int), hipMemcpyDeviceToHost, st));
+    PHL_HIP(hipStreamSynchronize(st));
+    lat->S_multi = s_multi;
+    return PHL_OK;
+}
+
+int phl_tiles_build(phl_lattice *lat, const float *ref, int64_t rs, int64_t cs, hipStream_t st)
+{
+    phl_tiles_free(lat);
+    const int d = lat->d, dp1 = d + 1;
+    const int n = (int)lat->n;
+    int P = 2048 / dp1;
+    if (P > 256) P = 256;
+    P &= ~15;
+    lat->P = P;
+    if (n == 0) return phl_tiles_link_vertices(lat, st);
+    int sortn = 512;
+    while (sortn < P * dp1) sortn <<= 1;
+
+    temp_pool tmp;
+    // 1. feature ranges -> the two widest dimensions -> uniform grid with ~P pixels per cell
+    constexpr int MMB = 256;
+    float *mm_dev;
+    PHL_HIP(tmp.get(&mm_dev, (size_t)MMB * d * 2));
+    hipLaunchKernelGGL(k_minmax, dim3(MMB), dim3(256), 0, st, ref, rs, cs, (int64_t)n, d, mm_dev);
+    PHL_HIP(hipGetLastError());
+    std::vector<float> mm((size_t)MMB * d * 2);
+    PHL_HIP(hipMemcpyAsync(mm.data(), mm_dev, sizeof(float) * mm.size(), hipMemcpyDeviceToHost, st));
+    PHL_HIP(hipStreamSynchronize(st));
+    std::vector<float> lo(d, INFINITY), hi(d, -INFINITY);
+    for (int b = 0; b < MMB; b++)
+        for (int i = 0; i < d; i++) {
+            lo[i] = fminf(lo[i], mm[((size_t)b * d + i) * 2]);
+            hi[i] = fmaxf(hi[i], mm[((size_t)b * d + i) * 2 + 1]);
+        }
+    int da = 0, db = -1;
+    for (int i = 1; i < d; i++)
+        if (hi[i] - lo[i] > hi[da] - lo[da]) da = i;
+    for (int i = 0; i < d; i++)
+        if (i != da && (db < 0 || hi[i] - lo[i] > hi[db] - lo[db])) db = i;
+    double ra = (double)hi[da] - lo[da], rb = db >= 0 ? (double)hi[db] - lo[db] : 0.0;
+    if (!(ra > 0) || !isfinite(ra)) ra = 0;
+    if (!(rb > 0) || !isfinite(rb)) { rb = 0; db = -1; }
+    int nca = 1, ncb = 1;
+    float inv_t = 0.f;
+    if (ra > 0 && n > P) {
+        double T = rb > 0 ? sqrt((double)P * ra * rb / n) : (double)P * ra / n;
+        if (T > 0 && isfinite(T)) {
+            nca = (int)fmin(ra / T, 32767.0) + 1;
+            ncb = rb > 0 ? (int)fmin(rb / T, 32767.0) + 1 : 1;
+            while ((int64_t)nca * ncb > (int64_t)4 * n + 1024) {
+                T *= 1.5;
+                nca = (int)fmin(ra / T, 32767.0) + 1;
+                ncb = rb > 0 ? (int)fmin(rb / T, 32767.0) + 1 : 1;
+            }
+            inv_t = (float)(1.0 / T);
+        }
+    }
+    const int ncell = nca * ncb;
+
+    // 2. pixels in cell-major order (ascending pixel inside a cell)
+    int *cell, *ccnt, *cptr, *ccur, *tile_sums;
+    phl_contrib_t *gtmp, *gsorted;
+    PHL_HIP(tmp.get(&cell, (size_t)n));
+    PHL_HIP(tmp.get(&ccnt, (size_t)ncell * 2 + 2));
+    PHL_HIP(tmp.get(&cptr, (size_t)ncell + 1));
+    PHL_HIP(tmp.get(&tile_sums, (size_t)(n > ncell ? n : ncell) / SCAN_TILE + 2));
+    PHL_HIP(tmp.get(&gtmp, (size_t)n));
+    PHL_HIP(tmp.get(&gsorted, (size_t)n));
+    ccur = ccnt + ncell + 1;
+    PHL_HIP(hipMemsetAsync(ccnt, 0, sizeof(int) * ((size_t)ncell * 2 + 2), st));
+    const unsigned gn = (unsigned)((n + 255) / 256);
+    hipLaunchKernelGGL(k_cell_ids, dim3(gn), dim3(256), 0, st, ref, rs, cs, (int64_t)n, da, db, lo[da],
+                       db >= 0 ? lo[db] : 0.f, inv_t, nca, ncb, cell, ccnt);
+    PHL_HIP(hipGetLastError());
+    int rc = exclusive_scan(ccnt, cptr, ncell, tile_sums, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_group_fill, dim3(gn), dim3(256), 0, st, cell, cptr, ccur, n, gtmp);
+    {
+        int blocks = (ncell + 3) / 4;
+        if (blocks > 256 * 16) blocks = 256 * 16;
+        hipLaunchKernelGGL(k_sort_lists, dim3(blocks), dim3(256), 0, st, gtmp, cptr, ncell, gsorted);
+    }
+    PHL_HIP(hipMalloc((void **)&lat->pix_order, sizeof(int) * (size_t)n));
+    hipLaunchKernelGGL(k_extract_index, dim3(gn), dim3(256), 0, st, gsorted, n, lat->pix_order);
+    PHL_HIP(hipGetLastError());
+
+    // 3. per-chunk local vertex lists, segments and local indices
+    const int nchunks = (n + P - 1) / P;
+    lat->nchunks = nchunks;
+    int *nv;
+    PHL_HIP(tmp.get(&nv, (size_t)nchunks + 1));
+    PHL_HIP(hipMalloc((void **)&lat->chunk_vptr, sizeof(int) * ((size_t)nchunks + 1)));
+#define PHL_CHUNK_SORT(WRITE_, ...)                                                                                       \
+    switch (sortn) {                                                                                                      \
+        case 512: hipLaunchKernelGGL((k_chunk_sort<512, WRITE_>), dim3(nchunks), dim3(256), 0, st, __VA_ARGS__); break;   \
+        case 1024: hipLaunchKernelGGL((k_chunk_sort<1024, WRITE_>), dim3(nchunks), dim3(256), 0, st, __VA_ARGS__); break; \
+        default: hipLaunchKernelGGL((k_chunk_sort<2048, WRITE_>), dim3(nchunks), dim3(256), 0, st, __VA_ARGS__); break;   \
+    }
+    PHL_CHUNK_SORT(false, lat->pix_order, n, P, dp1, lat->replay, nv, (const int *)nullptr, (int *)nullptr, (int *)nullptr,
+                   (phl_contrib_t *)nullptr, (unsigned short *)nullptr)
+    PHL_HIP(hipGetLastError());
+    rc = exclusive_scan(nv, lat->chunk_vptr, nchunks, tile_sums, st);
+    if (rc) return rc;
+    std::vector<int> nv_host((size_t)nchunks);
+    PHL_HIP(hipMemcpyAsync(nv_host.data(), nv, sizeof(int) * (size_t)nchunks, hipMemcpyDeviceToHost, st));
+    PHL_HIP(hipStreamSynchronize(st));
+    int64_t S = 0;
+    int nv_max = 0;
+    for (int v : nv_host) {
+        S += v;
+        if (v > nv_max) nv_max = v;
+    }
+    lat->S = S;
+    lat->nv_max = nv_max;
+    const int64_t N = lat->N;
+    PHL_HIP(hipMalloc((void **)&lat->slot_vert, sizeof(int) * ((size_t)S + 1)));
+    PHL_HIP(hipMalloc((void **)&lat->seg_ptr, sizeof(int) * ((size_t)S + 1)));
+    PHL_HIP(hipMalloc((void **)&lat->seg, sizeof(phl_contrib_t) * (size_t)N));
+    PHL_HIP(hipMalloc((void **)&lat->lidx, sizeof(unsigned short) * (size_t)N));
+    PHL_CHUNK_SORT(true, lat->pix_order, n, P, dp1, lat->replay, (int *)nullptr, lat->chunk_vptr, lat->slot_vert,
+                   lat->seg_ptr, lat->seg, lat->lidx)
+#undef PHL_CHUNK_SORT
+    PHL_HIP(hipGetLastError());
+    const int Nint = (int)N;
+    PHL_HIP(hipMemcpyAsync(lat->seg_ptr + S, &Nint, sizeof(int), hipMemcpyHostToDevice, st));
+    PHL_HIP(hipStreamSynchronize(st));
+    rc = phl_tiles_link_vertices(lat, st);
+    if (rc) return rc;
+    lat->tile_bytes = (int64_t)(sizeof(int) * ((size_t)n + nchunks + 1 + 3 * ((size_t)S + 1) + (size_t)lat->M + 1) +
+                                sizeof(phl_contrib_t) * ((size_t)N + S + 1) + sizeof(unsigned short) * (size_t)N);
+    return PHL_OK;
+}
+
+// Is the LDS-staged path available for this channel count?
+int phl_tiles_lprs(const phl_lattice *lat, int vd, int for_slice)
+{
+    if (lat->nchunks == 0 || vd % 4 != 0) return -1;
+    return pick_lprs(vd, for_slice ? lat->nv_max : lat->P);
+}
+
+int phl_tiles_reserve(phl_lattice *lat, int vd)
+{
+    const int64_t need = lat->S_multi * (int64_t)vd;
+    if (need <= lat->partial_elems) return PHL_OK;
+    if (lat->partial) PHL_HIP(hipFree(lat->partial));
+    lat->partial = nullptr;
+    lat->partial_elems = 0;
+    PHL_HIP(hipMalloc((void **)&lat->partial, sizeof(float) * (size_t)(need ? need : 1)));
+    lat->partial_elems = need;
+    return PHL_OK;
+}
+
+int phl_launch_splat_tiled(phl_lattice *lat, const float *src, int64_t src_rs, int vd, float *vert, hipStream_t st)
+{
+    const int M = (int)lat->M;
+    if (M == 0 || vd == 0) return PHL_OK;
+    const int lprs = pick_lprs(vd, lat->P);
+    if (lprs < 0) {
+        phl_set_error("tiled splat: chunk does not fit LDS");
+        return PHL_ERR_UNSUPPORTED;
+    }
+    int rc = phl_tiles_reserve(lat, vd);
+    if (rc) return rc;
+    const size_t lds = (size_t)lat->P * lprs * 16;
+    dispatch_lprs(lprs, [&](auto L) {
+        constexpr int LPRS = decltype(L)::value;
+        k_splat_tiled<LPRS><<<dim3(lat->nchunks), dim3(256), lds, st>>>(
+            src, src_rs, vd, (int)lat->n, lat->P, lat->pix_order, lat->chunk_vptr, lat->slot_vert, lat->slot_pidx,
+            lat->seg_ptr, lat->seg, vert, lat->partial);
+    });
+    const int lpr = pick_lpr_row(vd);
+    int64_t waves = ((int64_t)M + (64 / lpr) - 1) / (64 / lpr);
+    int64_t blocks = (waves + 3) / 4;
+    if (blocks > 2048) blocks = 2048;
+#define PHL_RED(LPR_)                                                                                                  \
+    k_splat_reduce<LPR_><<<dim3((unsigned)blocks), dim3(256), 0, st>>>(lat->partial, lat->vs_ptr, lat->vs, lat->slot_pidx, \
+                                                                       M, vd, vert)
+    switch (lpr) {
+        case 64: PHL_RED(64); break;
+        case 16: PHL_RED(16); break;
+        case 4: PHL_RED(4); break;
+        default: PHL_RED(1); break;
+    }
+#undef PHL_RED
+    PHL_HIP(hipGetLastError());
+    return PHL_OK;
+}
+
+int phl_launch_slice_tiled(const phl_lattice *lat, const float *vert, int vd, float *out, int64_t out_rs, const float *sub,
+                           int64_t sub_rs, unsigned flags, hipStream_t st)
+{
+    if (lat->n == 0 || vd == 0) return PHL_OK;
+    const int lprs = pick_lprs(vd, lat->nv_max);
+    if (lprs < 0) {
+        phl_set_error("tiled slice: chunk does not fit LDS");
+        return PHL_ERR_UNSUPPORTED;
+    }
+    const float cdiv = 1 + powf(2, -lat->d);  // permutohedral.h:480
+    const float rcdiv = 1.0f / cdiv;
+    const size_t lds = (size_t)lat->nv_max * lprs * 16;
+    const bool exact = !(flags & PHL_FILTER_FAST_SLICE);
+    dispatch_lprs(lprs, [&](auto L) {
+        constexpr int LPRS = decltype(L)::value;
+        if (exact)
+            k_slice_tiled<LPRS, true><<<dim3(lat->nchunks), dim3(256), lds, st>>>(
+                vert, vd, (int)lat->n, lat->P, lat->d + 1, lat->pix_order, lat->chunk_vptr, lat->slot_vert, lat->lidx,
+                lat->replay, out, out_rs, sub, sub_rs, cdiv, rcdiv);
+        else
+            k_slice_tiled<LPRS, false><<<dim3(lat->nchunks), dim3(256), lds, st>>>(
+                vert, vd, (int)lat->n, lat->P, lat->d + 1, lat->pix_order, lat->chunk_vptr, lat->slot_vert, lat->lidx,
+                lat->replay, out, out_rs, sub, sub_rs, cdiv, rcdiv);
+    });
+    PHL_HIP(hipGetLastError());
+    return PHL_OK;
+}

@@ -25,6 +25,8 @@ LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libphl.so")
 
 SUBTRACT_INPUT = 1
 FAST_SLICE = 2
+EXACT_ORDER = 4
+NO_TILES = 8
 
 _f32p = C.c_void_p
 _lib = None
@@ -67,7 +69,8 @@ def load_library():
         lib.phl_num_local_vertices.argtypes = [vp]
         lib.phl_filter.argtypes = [vp, vp, i32, i64, i64, vp, i64, i64, u32, vp]
         lib.phl_filter_once.argtypes = [vp, i32, i64, i64, vp, i32, i64, i64, i64, vp, i64, i64, u32, i32, vp]
-        lib.phl_splat.argtypes = [vp, vp, i32, i64, vp, vp]
+        lib.phl_splat.argtypes = [vp, vp, i32, i64, vp, u32, vp]
+        lib.phl_tile_stats.argtypes = [vp, i32, vp]
         lib.phl_blur_axis.argtypes = [vp, i32, vp, vp, i32, vp]
         lib.phl_slice.argtypes = [vp, vp, i32, vp, i64, vp, i64, u32, vp]
         lib.phl_get_keys.argtypes = [vp, vp]
@@ -138,8 +141,11 @@ class Lattice:
         _check(load_library().phl_reserve(self._h, int(vd)))
 
     # ---- hot path ---------------------------------------------------------------------------
-    def filter(self, src, subtract_input=False, fast_slice=False, out=None):
-        """``lattice.filter(src, ref)`` of the reference; result lives on ``src``'s device."""
+    def filter(self, src, subtract_input=False, fast_slice=False, out=None, exact_order=False, no_tiles=False):
+        """``lattice.filter(src, ref)`` of the reference; result lives on ``src``'s device.
+
+        exact_order: splat sums in the reference's pixel order (bit-identical to the CPU path);
+        the default LDS-staged splat agrees to fp32 rounding.  no_tiles: plain gather kernels."""
         if src.dim() != 2 or src.shape[0] != self.n:
             # same text as the reference's assert (gaussian_matrix.py:429-430)
             raise AssertionError("Incompatible shapes {}, and {}".format(tuple(src.shape), (self.n, self.d)))
@@ -147,7 +153,8 @@ class Lattice:
         vd = int(src_d.shape[1])
         res = out if (out is not None and out.device == self.device) else torch.empty(
             (self.n, vd), dtype=torch.float32, device=self.device)
-        flags = (SUBTRACT_INPUT if subtract_input else 0) | (FAST_SLICE if fast_slice else 0)
+        flags = ((SUBTRACT_INPUT if subtract_input else 0) | (FAST_SLICE if fast_slice else 0) |
+                 (EXACT_ORDER if exact_order else 0) | (NO_TILES if no_tiles else 0))
         with torch.cuda.device(self.device):
             _check(load_library().phl_filter(self._h, C.c_void_p(src_d.data_ptr()), vd, src_d.stride(0),
                                              src_d.stride(1), C.c_void_p(res.data_ptr()), res.stride(0),
@@ -158,14 +165,16 @@ class Lattice:
         return res if src.device == self.device else res.to(src.device)
 
     # ---- stages (profiling / parity of intermediates) ---------------------------------------
-    def splat(self, src):
+    def splat(self, src, exact_order=False, no_tiles=False):
         src_d = _as_device(src.detach(), self.device)
         assert src_d.stride(1) == 1, "stage API takes pixel-major rows"
         vd = int(src_d.shape[1])
         vert = torch.empty((self.M, vd), dtype=torch.float32, device=self.device)
         with torch.cuda.device(self.device):
             _check(load_library().phl_splat(self._h, C.c_void_p(src_d.data_ptr()), vd, src_d.stride(0),
-                                            C.c_void_p(vert.data_ptr()), _stream(self.device)))
+                                            C.c_void_p(vert.data_ptr()),
+                                            (EXACT_ORDER if exact_order else 0) | (NO_TILES if no_tiles else 0),
+                                            _stream(self.device)))
         return vert
 
     def blur_axis(self, axis, vin, vout=None):
@@ -184,15 +193,24 @@ class Lattice:
             a, b = b, a
         return a
 
-    def slice(self, vert, sub=None, fast_slice=False, out=None):
+    def slice(self, vert, sub=None, fast_slice=False, out=None, no_tiles=False):
         vd = int(vert.shape[1])
         out = torch.empty((self.n, vd), dtype=torch.float32, device=self.device) if out is None else out
         with torch.cuda.device(self.device):
             _check(load_library().phl_slice(self._h, C.c_void_p(vert.data_ptr()), vd, C.c_void_p(out.data_ptr()),
                                             out.stride(0), C.c_void_p(sub.data_ptr()) if sub is not None else None,
                                             sub.stride(0) if sub is not None else 0,
-                                            FAST_SLICE if fast_slice else 0, _stream(self.device)))
+                                            (FAST_SLICE if fast_slice else 0) | (NO_TILES if no_tiles else 0),
+                                            _stream(self.device)))
         return out
+
+    def tile_stats(self, vd):
+        """Chunk statistics of the LDS-staged path (see phl_tile_stats in include/phl.h)."""
+        out = np.zeros(7, np.int64)
+        _check(load_library().phl_tile_stats(self._h, int(vd), out.ctypes.data_as(C.c_void_p)))
+        keys = ("pixels_per_chunk", "chunks", "max_local_vertices", "slots", "multi_chunk_slots", "staged_splat",
+                "staged_slice")
+        return dict(zip(keys, (int(x) for x in out)))
 
     def add_vertices(self, keys):
         """Row-band support: append neighbouring-band vertices (distinct int16 keys [K, d]) as

@@ -59,7 +59,13 @@ enum phl_filter_flags {
     PHL_FILTER_SUBTRACT_INPUT = 1,
     /* sum_i w_i*v_i * 1/(1+2^-d) with one final multiply instead of the reference's
        per-term divide (permutohedral.h:480); differs in the last bit only */
-    PHL_FILTER_FAST_SLICE = 2
+    PHL_FILTER_FAST_SLICE = 2,
+    /* splat with the reference's exact summation order (ascending pixel per vertex, gather
+       kernel): bit-identical to the CPU path.  Default is the LDS-staged chunk splat, which
+       adds per-chunk partial sums and agrees to fp32 rounding (~1e-7 relative) */
+    PHL_FILTER_EXACT_ORDER = 4,
+    /* do not use the LDS-staged chunk kernels at all (plain gather splat and slice) */
+    PHL_FILTER_NO_TILES = 8
 };
 
 /* Limits. */
@@ -121,7 +127,7 @@ int phl_filter_once(const float *src_dev, int vd, int64_t src_row_stride, int64_
  * vert buffers are dense [M][vd] fp32 device arrays owned by the caller. */
 /* value half of splat(): vert[v] = sum over (pixel,weight) of w*src[pixel]   (:454-455) */
 int phl_splat(phl_lattice *lat, const float *src_dev, int vd, int64_t src_row_stride,
-              float *vert_dev, phl_stream stream);
+              float *vert_dev, unsigned flags, phl_stream stream);
 /* one blur axis, Jacobi: dst[v] = 2*(1/4 src[n1] + 1/2 src[v] + 1/4 src[n2])   (:498-533) */
 int phl_blur_axis(phl_lattice *lat, int axis, const float *vert_src_dev, float *vert_dst_dev, int vd,
                   phl_stream stream);
@@ -129,6 +135,11 @@ int phl_blur_axis(phl_lattice *lat, int axis, const float *vert_src_dev, float *
 int phl_slice(phl_lattice *lat, const float *vert_dev, int vd, float *out_dev, int64_t out_row_stride,
               const float *sub_dev /* NULL or src to subtract */, int64_t sub_row_stride, unsigned flags,
               phl_stream stream);
+
+/* Chunk ("tile") statistics of the LDS-staged path: out[0]=pixels per chunk, [1]=#chunks,
+ * [2]=max local vertices per chunk, [3]=(chunk,vertex) slots S, [4]=slots of vertices fed by
+ * several chunks, [5]=1 if the staged splat / [6]=slice would be chosen for this vd. */
+int phl_tile_stats(const phl_lattice *lat, int vd, int64_t out[7]);
 
 /* ---- introspection for parity tests (synchronous device->host copies) --------------------- */
 int phl_get_keys(phl_lattice *lat, int16_t *keys_host /* [M][d] */);
