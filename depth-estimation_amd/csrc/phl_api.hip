@@ -152,7 +152,7 @@ int phl_add_vertices(phl_lattice *lat, const int16_t *keys_host, int64_t count, 
 namespace {
 bool use_tiled_splat(const phl_lattice *lat, int vd, unsigned flags, const void *a, const void *b, int64_t rs)
 {
-    if (flags & (PHL_FILTER_EXACT_ORDER | PHL_FILTER_NO_TILES)) return false;
+    if (flags & (PHL_FILTER_EXACT | PHL_FILTER_NO_TILES)) return false;
     if (phl_tiles_lprs(lat, vd, 0) < 0) return false;
     if ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) & 15 || rs % 4) return false;
     return lat->S_multi <= lat->n;   // partial-row traffic must stay below what staging saves

@@ -155,19 +155,22 @@ __global__ __launch_bounds__(256) void k_blur(const float *__restrict__ vin, flo
             nb[u] = v[u] < M ? nbr[v[u]] : make_int2(-1, -1);
         }
         for (int c = l * VEC; c < vd; c += LPR * VEC) {
+            // unconditional loads from clamped rows + selects: a load under a divergent `if`
+            // makes hipcc wait vmcnt(0) per load and serialises the gather
             V a[U], s[U], b[U];
 #pragma unroll
             for (int u = 0; u < U; u++) {
-                a[u] = s[u] = b[u] = vzero<VEC>();
-                if (v[u] < M) {
-                    s[u] = vload(vin + v[u] * vd + c, V());
-                    if (nb[u].x >= 0) a[u] = vload(vin + (int64_t)nb[u].x * vd + c, V());
-                    if (nb[u].y >= 0) b[u] = vload(vin + (int64_t)nb[u].y * vd + c, V());
-                }
+                const int64_t vc = v[u] < M ? v[u] : (int64_t)M - 1;
+                s[u] = vload(vin + vc * vd + c, V());
+                a[u] = vload(vin + (int64_t)max(nb[u].x, 0) * vd + c, V());
+                b[u] = vload(vin + (int64_t)max(nb[u].y, 0) * vd + c, V());
             }
 #pragma unroll
-            for (int u = 0; u < U; u++)
+            for (int u = 0; u < U; u++) {
+                if (nb[u].x < 0) a[u] = vzero<VEC>();
+                if (nb[u].y < 0) b[u] = vzero<VEC>();
                 if (v[u] < M) vstore(vout + v[u] * vd + c, blur3(a[u], s[u], b[u]));
+            }
         }
     }
 }
@@ -329,7 +332,7 @@ int phl_launch_slice(const phl_lattice *lat, const float *vert, int vd, float *o
                     (!sub || ((sub_rs % 4 == 0) && aligned16(sub)));
     const int lpr = pick_lpr(vd, v4 ? 4 : 1);
     const unsigned grid = grid_for(n, 64 / lpr);
-    const bool exact = !(flags & PHL_FILTER_FAST_SLICE);
+    const bool exact = (flags & PHL_FILTER_EXACT) != 0;
     dispatch_lpr(lpr, [&](auto L) {
         constexpr int LPR = decltype(L)::value;
 #define PHL_SLICE_ARGS vert, vd, lat->replay, dp1, n, out, out_rs, sub, sub_rs, cdiv, rcdiv

@@ -22,7 +22,7 @@
 // Reference semantics are those of crf/lattice/lite/permutohedral.h:454-455 (splat
 // accumulate) and :473-483 (slice); summation ORDER of multi-chunk vertices differs from the
 // reference's pixel order (partial sums), hence results agree to fp32 rounding (~1e-7), not
-// bit for bit; PHL_FILTER_EXACT_ORDER selects the pixel-ordered gather splat instead.
+// bit for bit; PHL_FILTER_EXACT selects the pixel-ordered gather splat instead.
 #include <math.h>
 #include <stdlib.h>
 
@@ -216,53 +216,126 @@ __device__ __forceinline__ float4 fma4(float4 acc, float w, float4 v)
                        __builtin_fmaf(w, v.w, acc.w));
 }
 
-// One workgroup per chunk.  LPRS lanes own one row of a channel slab of SL = 4*LPRS floats.
+// One workgroup (TPB threads) per chunk.  LPRS lanes own one row of a channel slab of
+// SL = 4*LPRS floats.  LDS: [rows x SL] staged rows | per-entry {LDS byte offset, weight} |
+// chunk pixel ids | local segment pointers | destination of each local vertex.  Index data
+// is staged ONCE per chunk; inside the slab loop global memory is touched only for value rows,
+// and the rows of slab s+1 are prefetched into registers while slab s is being summed.
+// A wavefront owns one local vertex at a time; its 64/LPRS lane groups take every
+// (64/LPRS)-th entry of the vertex's segment and the group sums are combined with a fixed
+// xor-butterfly: a wavefront-level segmented reduction, deterministic, no atomics.
+constexpr int TPB = 512;
+
 template <int LPRS>
-__global__ __launch_bounds__(256) void k_splat_tiled(const float *__restrict__ src, int64_t src_rs, int vd, int n, int P,
-                                                     const int *__restrict__ pix_order, const int *__restrict__ vptr,
-                                                     const int *__restrict__ slot_vert, const int *__restrict__ slot_pidx,
-                                                     const int *__restrict__ seg_ptr,
+__global__ __launch_bounds__(TPB) void k_splat_tiled(const float *__restrict__ src, int64_t src_rs, int vd, int n, int P,
+                                                     int dp1, int nv_cap, const int *__restrict__ pix_order,
+                                                     const int *__restrict__ vptr, const int *__restrict__ slot_vert,
+                                                     const int *__restrict__ slot_pidx, const int *__restrict__ seg_ptr,
                                                      const phl_contrib_t *__restrict__ seg, float *__restrict__ vert,
                                                      float *__restrict__ partial)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int SL = LPRS * 4;
-    constexpr int G = 256 / LPRS;
+    constexpr int G = TPB / LPRS;          // row groups of the workgroup (staging)
+    constexpr int Q = 64 / LPRS;           // lane groups of a wavefront (entry-parallel)
+    constexpr int NW = TPB / 64;
+    constexpr int PF = (256 / G) < 8 ? (256 / G) : 8;   // rows prefetched per thread
     const int g = threadIdx.x / LPRS, l = threadIdx.x % LPRS;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int q = lane / LPRS;
     const int c = blockIdx.x;
     const int base = c * P;
     const int cnt = min(P, n - base);
+    const int E = cnt * dp1;
+    const int64_t ebase = (int64_t)base * dp1;
     const int vbase = vptr[c], nv = vptr[c + 1] - vbase;
+    float *rows = lds;
+    uint2 *ent = reinterpret_cast<uint2 *>(lds + (size_t)P * SL);
+    int *pixl = reinterpret_cast<int *>(ent + P * dp1);
+    int *spl = pixl + P;                   // [nv_cap + 1]
+    int *dvl = spl + nv_cap + 1;           // [nv_cap] slot_vert
+    int *dpl = dvl + nv_cap;               // [nv_cap] slot_pidx
+    for (int e = threadIdx.x; e < E; e += TPB) {
+        const phl_contrib_t s = seg[ebase + e];
+        ent[e] = make_uint2((unsigned)(s.pixel * SL * 4), __float_as_uint(s.w));
+    }
+    for (int k = threadIdx.x; k < cnt; k += TPB) pixl[k] = pix_order[base + k];
+    for (int i = threadIdx.x; i <= nv; i += TPB) spl[i] = (int)(seg_ptr[vbase + i] - ebase);
+    for (int i = threadIdx.x; i < nv; i += TPB) {
+        dvl[i] = slot_vert[vbase + i];
+        dpl[i] = slot_pidx[vbase + i];
+    }
+    __syncthreads();
+    const char *rbase = reinterpret_cast<const char *>(rows) + l * 16;
+    float4 pf[PF];
+    // Loads are issued UNCONDITIONALLY from clamped (always valid) addresses and only the LDS
+    // stores are predicated: a load under a divergent `if` makes hipcc wait vmcnt(0) per load.
+    const int kclamp = cnt - 1;
+    // slab 0 is staged synchronously
+    {
+        const bool chok = l * 4 < vd;
+        const int chc = chok ? l * 4 : 0;
+        for (int k0 = g; k0 < cnt; k0 += PF * G) {
+#pragma unroll
+            for (int u = 0; u < PF; u++) pf[u] = ld4(src + (int64_t)pixl[min(k0 + u * G, kclamp)] * src_rs + chc);
+#pragma unroll
+            for (int u = 0; u < PF; u++)
+                if (chok && k0 + u * G < cnt) st4(rows + (k0 + u * G) * SL + l * 4, pf[u]);
+        }
+    }
     for (int c0 = 0; c0 < vd; c0 += SL) {
         const int ch = c0 + l * 4;
         const bool chok = ch < vd;
-        for (int k = g; k < cnt; k += G) {
-            const int p = pix_order[base + k];
-            if (chok) st4(lds + k * SL + l * 4, ld4(src + (int64_t)p * src_rs + ch));
+        __syncthreads();                   // rows of this slab are in LDS
+        const int chn = ch + SL;
+        const bool more = c0 + SL < vd;    // wave-uniform
+        const bool chnok = more && chn < vd;
+        const int chnc = chnok ? chn : 0;
+        if (more) {
+#pragma unroll
+            for (int u = 0; u < PF; u++) pf[u] = ld4(src + (int64_t)pixl[min(g + u * G, kclamp)] * src_rs + chnc);
         }
-        __syncthreads();
-        for (int i = g; i < nv; i += G) {
-            const int s0 = seg_ptr[vbase + i], s1 = seg_ptr[vbase + i + 1];
+        for (int i = wave; i < nv; i += NW) {
+            const int s0 = spl[i], s1 = spl[i + 1];
             float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-            int s = s0;
-            for (; s + 2 <= s1; s += 2) {
-                const phl_contrib_t a = seg[s], b = seg[s + 1];
-                const float4 qa = ld4(lds + a.pixel * SL + l * 4);
-                const float4 qb = ld4(lds + b.pixel * SL + l * 4);
-                acc = mac4(acc, a.w, qa);
-                acc = mac4(acc, b.w, qb);
+            int s = s0 + q;
+            for (; s + Q < s1; s += 2 * Q) {
+                const uint2 e0 = ent[s], e1 = ent[s + Q];
+                const float4 q0 = *reinterpret_cast<const float4 *>(rbase + e0.x);
+                const float4 q1 = *reinterpret_cast<const float4 *>(rbase + e1.x);
+                acc = mac4(acc, __uint_as_float(e0.y), q0);
+                acc = mac4(acc, __uint_as_float(e1.y), q1);
             }
             if (s < s1) {
-                const phl_contrib_t a = seg[s];
-                acc = mac4(acc, a.w, ld4(lds + a.pixel * SL + l * 4));
+                const uint2 e0 = ent[s];
+                acc = mac4(acc, __uint_as_float(e0.y), *reinterpret_cast<const float4 *>(rbase + e0.x));
             }
-            if (chok) {
-                const int v = slot_vert[vbase + i];
-                float *dst = v < 0 ? vert + (int64_t)(v & 0x7FFFFFFF) * vd : partial + (int64_t)slot_pidx[vbase + i] * vd;
+#pragma unroll
+            for (int off = LPRS; off < 64; off <<= 1) {
+                acc.x += __shfl_xor(acc.x, off);
+                acc.y += __shfl_xor(acc.y, off);
+                acc.z += __shfl_xor(acc.z, off);
+                acc.w += __shfl_xor(acc.w, off);
+            }
+            if (q == 0 && chok) {
+                const int v = dvl[i];
+                float *dst = v < 0 ? vert + (int64_t)(v & 0x7FFFFFFF) * vd : partial + (int64_t)dpl[i] * vd;
                 st4(dst + ch, acc);
             }
         }
-        __syncthreads();
+        __syncthreads();                   // everyone is done reading this slab
+        if (more) {
+#pragma unroll
+            for (int u = 0; u < PF; u++)
+                if (chnok && g + u * G < cnt) st4(rows + (g + u * G) * SL + l * 4, pf[u]);
+            for (int k0 = g + PF * G; k0 < cnt; k0 += PF * G) {   // rows beyond the prefetch depth (wide slabs)
+#pragma unroll
+                for (int u = 0; u < PF; u++) pf[u] = ld4(src + (int64_t)pixl[min(k0 + u * G, kclamp)] * src_rs + chnc);
+#pragma unroll
+                for (int u = 0; u < PF; u++)
+                    if (chnok && k0 + u * G < cnt) st4(rows + (k0 + u * G) * SL + l * 4, pf[u]);
+            }
+        }
     }
 }
 
@@ -286,9 +359,16 @@ __global__ __launch_bounds__(256) void k_splat_reduce(const float *__restrict__ 
         if (end - beg == 1) continue;
         for (int ch = l * 4; ch < vd; ch += LPR * 4) {
             float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-            for (int e = beg; e < end; e++) {
-                const float4 q = ld4(partial + (int64_t)slot_pidx[vs[e].pixel] * vd + ch);
-                acc = make_float4(acc.x + q.x, acc.y + q.y, acc.z + q.z, acc.w + q.w);
+            int e = beg;
+            for (; e + 2 <= end; e += 2) {
+                const float4 q0 = ld4(partial + (int64_t)slot_pidx[vs[e].pixel] * vd + ch);
+                const float4 q1 = ld4(partial + (int64_t)slot_pidx[vs[e + 1].pixel] * vd + ch);
+                acc = make_float4(acc.x + q0.x, acc.y + q0.y, acc.z + q0.z, acc.w + q0.w);
+                acc = make_float4(acc.x + q1.x, acc.y + q1.y, acc.z + q1.z, acc.w + q1.w);
+            }
+            if (e < end) {
+                const float4 q0 = ld4(partial + (int64_t)slot_pidx[vs[e].pixel] * vd + ch);
+                acc = make_float4(acc.x + q0.x, acc.y + q0.y, acc.z + q0.z, acc.w + q0.w);
             }
             st4(vert + v * vd + ch, acc);
         }
@@ -296,9 +376,9 @@ __global__ __launch_bounds__(256) void k_splat_reduce(const float *__restrict__ 
 }
 
 template <int LPRS, bool EXACT>
-__global__ __launch_bounds__(256) void k_slice_tiled(const float *__restrict__ vert, int vd, int n, int P, int dp1,
-                                                     const int *__restrict__ pix_order, const int *__restrict__ vptr,
-                                                     const int *__restrict__ slot_vert,
+__global__ __launch_bounds__(TPB) void k_slice_tiled(const float *__restrict__ vert, int vd, int n, int P, int dp1,
+                                                     int rows_cap, const int *__restrict__ pix_order,
+                                                     const int *__restrict__ vptr, const int *__restrict__ slot_vert,
                                                      const unsigned short *__restrict__ lidx,
                                                      const phl_replay_t *__restrict__ replay, float *__restrict__ out,
                                                      int64_t out_rs, const float *__restrict__ sub_src, int64_t sub_rs,
@@ -306,48 +386,70 @@ __global__ __launch_bounds__(256) void k_slice_tiled(const float *__restrict__ v
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int SL = LPRS * 4;
-    constexpr int G = 256 / LPRS;
+    constexpr int G = TPB / LPRS;
     const int g = threadIdx.x / LPRS, l = threadIdx.x % LPRS;
     const int c = blockIdx.x;
     const int base = c * P;
     const int cnt = min(P, n - base);
+    const int E = cnt * dp1;
+    const int64_t ebase = (int64_t)base * dp1;
     const int vbase = vptr[c], nv = vptr[c + 1] - vbase;
+    float *rows = lds;
+    uint2 *ent = reinterpret_cast<uint2 *>(lds + (size_t)rows_cap * SL);
+    int *pixl = reinterpret_cast<int *>(ent + P * dp1);
+    int *vl = pixl + P;
+    for (int k = threadIdx.x; k < cnt; k += TPB) pixl[k] = pix_order[base + k];
+    for (int i = threadIdx.x; i < nv; i += TPB) vl[i] = slot_vert[vbase + i] & 0x7FFFFFFF;
+    for (int e = threadIdx.x; e < E; e += TPB) {
+        const int k = e / dp1, r = e - k * dp1;
+        const int p = pix_order[base + k];
+        ent[e] = make_uint2((unsigned)lidx[ebase + e] * (SL * 4), __float_as_uint(replay[(int64_t)p * dp1 + r].w));
+    }
+    __syncthreads();
     for (int c0 = 0; c0 < vd; c0 += SL) {
         const int ch = c0 + l * 4;
         const bool chok = ch < vd;
-        for (int i = g; i < nv; i += G) {
-            const int v = slot_vert[vbase + i] & 0x7FFFFFFF;
-            if (chok) st4(lds + i * SL + l * 4, ld4(vert + (int64_t)v * vd + ch));
+        {
+            const int chc = chok ? ch : 0;
+            const int iclamp = nv - 1;
+            for (int i0 = g; i0 < nv; i0 += 8 * G) {
+                float4 q[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) q[u] = ld4(vert + (int64_t)vl[min(i0 + u * G, iclamp)] * vd + chc);
+#pragma unroll
+                for (int u = 0; u < 8; u++)
+                    if (chok && i0 + u * G < nv) st4(rows + (i0 + u * G) * SL + l * 4, q[u]);
+            }
         }
         __syncthreads();
+        const char *rbase = reinterpret_cast<const char *>(rows) + l * 16;
         for (int k = g; k < cnt; k += G) {
-            const int p = pix_order[base + k];
-            const phl_replay_t *rp = replay + (int64_t)p * dp1;
-            const unsigned short *li = lidx + (int64_t)(base + k) * dp1;
+            const uint2 *ek = ent + k * dp1;
             float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
             int r = 0;
             for (; r + 3 <= dp1; r += 3) {
-                const float w0 = rp[r].w, w1 = rp[r + 1].w, w2 = rp[r + 2].w;
-                const float4 q0 = ld4(lds + li[r] * SL + l * 4);
-                const float4 q1 = ld4(lds + li[r + 1] * SL + l * 4);
-                const float4 q2 = ld4(lds + li[r + 2] * SL + l * 4);
+                const uint2 e0 = ek[r], e1 = ek[r + 1], e2 = ek[r + 2];
+                const float4 q0 = *reinterpret_cast<const float4 *>(rbase + e0.x);
+                const float4 q1 = *reinterpret_cast<const float4 *>(rbase + e1.x);
+                const float4 q2 = *reinterpret_cast<const float4 *>(rbase + e2.x);
                 if (EXACT) {
-                    acc = term4(acc, w0, q0, cdiv, rcdiv);
-                    acc = term4(acc, w1, q1, cdiv, rcdiv);
-                    acc = term4(acc, w2, q2, cdiv, rcdiv);
+                    acc = term4(acc, __uint_as_float(e0.y), q0, cdiv, rcdiv);
+                    acc = term4(acc, __uint_as_float(e1.y), q1, cdiv, rcdiv);
+                    acc = term4(acc, __uint_as_float(e2.y), q2, cdiv, rcdiv);
                 } else {
-                    acc = fma4(acc, w0, q0);
-                    acc = fma4(acc, w1, q1);
-                    acc = fma4(acc, w2, q2);
+                    acc = fma4(acc, __uint_as_float(e0.y), q0);
+                    acc = fma4(acc, __uint_as_float(e1.y), q1);
+                    acc = fma4(acc, __uint_as_float(e2.y), q2);
                 }
             }
             for (; r < dp1; r++) {
-                const float w0 = rp[r].w;
-                const float4 q0 = ld4(lds + li[r] * SL + l * 4);
-                if (EXACT) acc = term4(acc, w0, q0, cdiv, rcdiv);
-                else acc = fma4(acc, w0, q0);
+                const uint2 e0 = ek[r];
+                const float4 q0 = *reinterpret_cast<const float4 *>(rbase + e0.x);
+                if (EXACT) acc = term4(acc, __uint_as_float(e0.y), q0, cdiv, rcdiv);
+                else acc = fma4(acc, __uint_as_float(e0.y), q0);
             }
             if (chok) {
+                const int p = pixl[k];
                 if (!EXACT) acc = make_float4(acc.x * rcdiv, acc.y * rcdiv, acc.z * rcdiv, acc.w * rcdiv);
                 if (sub_src) {
                     const float4 s = ld4(sub_src + (int64_t)p * sub_rs + ch);
@@ -378,25 +480,37 @@ inline void dispatch_lprs(int lprs, F &&f)
     }
 }
 
+// LDS per workgroup: default 80 KiB -> two workgroups per CU (160 KiB LDS per CU on gfx950)
 int lds_budget()
 {
     static int b = [] {
         const char *e = getenv("PHL_TILE_LDS");
-        int v = e ? atoi(e) : 65536;
-        return v < 4096 ? 4096 : (v > 65536 ? 65536 : v);
+        int v = e ? atoi(e) : 80 * 1024;
+        return v < 8192 ? 8192 : (v > 160 * 1024 ? 160 * 1024 : v);
     }();
     return b;
 }
 
-// lanes (of 4 floats) per slab row: as wide as vd, narrowed until `rows` rows fit in LDS;
-// -1 if even the narrowest slab does not fit
-inline int pick_lprs(int vd, int rows)
+// bytes of index data staged next to the rows (entries, pixel ids, local pointers)
+inline int64_t lds_extra(int P, int dp1, int nv_max) { return (int64_t)P * dp1 * 8 + (int64_t)P * 4 + ((int64_t)nv_max + 1) * 12 + 16; }
+
+// lanes (of 4 floats) per slab row: as wide as vd, narrowed until `rows` rows + index data fit
+// in LDS; -1 if even the narrowest slab does not fit
+inline int pick_lprs(int vd, int rows, int64_t extra)
 {
     const int need = (vd + 3) / 4;
     int lprs = 4;
     while (lprs < 64 && lprs < need) lprs <<= 1;
-    while (lprs > 4 && (int64_t)rows * lprs * 16 > lds_budget()) lprs >>= 1;
-    return (int64_t)rows * lprs * 16 > lds_budget() ? -1 : lprs;
+    while (lprs > 4 && (int64_t)rows * lprs * 16 + extra > lds_budget()) lprs >>= 1;
+    return (int64_t)rows * lprs * 16 + extra > lds_budget() ? -1 : lprs;
+}
+
+template <typename K>
+inline int allow_lds(K kernel, size_t bytes)
+{
+    if (bytes <= 64 * 1024) return PHL_OK;
+    PHL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    return PHL_OK;
 }
 
 inline int pick_lpr_row(int vd)
@@ -610,7 +724,7 @@ int phl_tiles_build(phl_lattice *lat, const float *ref, int64_t rs, int64_t cs, 
 int phl_tiles_lprs(const phl_lattice *lat, int vd, int for_slice)
 {
     if (lat->nchunks == 0 || vd % 4 != 0) return -1;
-    return pick_lprs(vd, for_slice ? lat->nv_max : lat->P);
+    return pick_lprs(vd, for_slice ? lat->nv_max : lat->P, lds_extra(lat->P, lat->d + 1, lat->nv_max));
 }
 
 int phl_tiles_reserve(phl_lattice *lat, int vd)
@@ -629,20 +743,23 @@ int phl_launch_splat_tiled(phl_lattice *lat, const float *src, int64_t src_rs, i
 {
     const int M = (int)lat->M;
     if (M == 0 || vd == 0) return PHL_OK;
-    const int lprs = pick_lprs(vd, lat->P);
+    const int64_t extra = lds_extra(lat->P, lat->d + 1, lat->nv_max);
+    const int lprs = pick_lprs(vd, lat->P, extra);
     if (lprs < 0) {
         phl_set_error("tiled splat: chunk does not fit LDS");
         return PHL_ERR_UNSUPPORTED;
     }
     int rc = phl_tiles_reserve(lat, vd);
     if (rc) return rc;
-    const size_t lds = (size_t)lat->P * lprs * 16;
+    const size_t lds = (size_t)lat->P * lprs * 16 + (size_t)extra;
     dispatch_lprs(lprs, [&](auto L) {
         constexpr int LPRS = decltype(L)::value;
-        k_splat_tiled<LPRS><<<dim3(lat->nchunks), dim3(256), lds, st>>>(
-            src, src_rs, vd, (int)lat->n, lat->P, lat->pix_order, lat->chunk_vptr, lat->slot_vert, lat->slot_pidx,
-            lat->seg_ptr, lat->seg, vert, lat->partial);
+        if ((rc = allow_lds(k_splat_tiled<LPRS>, lds)) != PHL_OK) return;
+        k_splat_tiled<LPRS><<<dim3(lat->nchunks), dim3(TPB), lds, st>>>(
+            src, src_rs, vd, (int)lat->n, lat->P, lat->d + 1, lat->nv_max, lat->pix_order, lat->chunk_vptr, lat->slot_vert,
+            lat->slot_pidx, lat->seg_ptr, lat->seg, vert, lat->partial);
     });
+    if (rc) return rc;
     const int lpr = pick_lpr_row(vd);
     int64_t waves = ((int64_t)M + (64 / lpr) - 1) / (64 / lpr);
     int64_t blocks = (waves + 3) / 4;
@@ -665,26 +782,32 @@ int phl_launch_slice_tiled(const phl_lattice *lat, const float *vert, int vd, fl
                            int64_t sub_rs, unsigned flags, hipStream_t st)
 {
     if (lat->n == 0 || vd == 0) return PHL_OK;
-    const int lprs = pick_lprs(vd, lat->nv_max);
+    const int64_t extra = lds_extra(lat->P, lat->d + 1, lat->nv_max);
+    const int lprs = pick_lprs(vd, lat->nv_max, extra);
     if (lprs < 0) {
         phl_set_error("tiled slice: chunk does not fit LDS");
         return PHL_ERR_UNSUPPORTED;
     }
     const float cdiv = 1 + powf(2, -lat->d);  // permutohedral.h:480
     const float rcdiv = 1.0f / cdiv;
-    const size_t lds = (size_t)lat->nv_max * lprs * 16;
-    const bool exact = !(flags & PHL_FILTER_FAST_SLICE);
+    const size_t lds = (size_t)lat->nv_max * lprs * 16 + (size_t)extra;
+    const bool exact = (flags & PHL_FILTER_EXACT) != 0;
+    int rc = PHL_OK;
     dispatch_lprs(lprs, [&](auto L) {
         constexpr int LPRS = decltype(L)::value;
-        if (exact)
-            k_slice_tiled<LPRS, true><<<dim3(lat->nchunks), dim3(256), lds, st>>>(
-                vert, vd, (int)lat->n, lat->P, lat->d + 1, lat->pix_order, lat->chunk_vptr, lat->slot_vert, lat->lidx,
-                lat->replay, out, out_rs, sub, sub_rs, cdiv, rcdiv);
-        else
-            k_slice_tiled<LPRS, false><<<dim3(lat->nchunks), dim3(256), lds, st>>>(
-                vert, vd, (int)lat->n, lat->P, lat->d + 1, lat->pix_order, lat->chunk_vptr, lat->slot_vert, lat->lidx,
-                lat->replay, out, out_rs, sub, sub_rs, cdiv, rcdiv);
+        if (exact) {
+            if ((rc = allow_lds(k_slice_tiled<LPRS, true>, lds)) != PHL_OK) return;
+            k_slice_tiled<LPRS, true><<<dim3(lat->nchunks), dim3(TPB), lds, st>>>(
+                vert, vd, (int)lat->n, lat->P, lat->d + 1, lat->nv_max, lat->pix_order, lat->chunk_vptr, lat->slot_vert,
+                lat->lidx, lat->replay, out, out_rs, sub, sub_rs, cdiv, rcdiv);
+        } else {
+            if ((rc = allow_lds(k_slice_tiled<LPRS, false>, lds)) != PHL_OK) return;
+            k_slice_tiled<LPRS, false><<<dim3(lat->nchunks), dim3(TPB), lds, st>>>(
+                vert, vd, (int)lat->n, lat->P, lat->d + 1, lat->nv_max, lat->pix_order, lat->chunk_vptr, lat->slot_vert,
+                lat->lidx, lat->replay, out, out_rs, sub, sub_rs, cdiv, rcdiv);
+        }
     });
+    if (rc) return rc;
     PHL_HIP(hipGetLastError());
     return PHL_OK;
 }

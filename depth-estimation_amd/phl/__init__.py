@@ -24,8 +24,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libphl.so")
 
 SUBTRACT_INPUT = 1
-FAST_SLICE = 2
-EXACT_ORDER = 4
+EXACT = 4
 NO_TILES = 8
 
 _f32p = C.c_void_p
@@ -141,11 +140,12 @@ class Lattice:
         _check(load_library().phl_reserve(self._h, int(vd)))
 
     # ---- hot path ---------------------------------------------------------------------------
-    def filter(self, src, subtract_input=False, fast_slice=False, out=None, exact_order=False, no_tiles=False):
+    def filter(self, src, subtract_input=False, out=None, exact=False, no_tiles=False):
         """``lattice.filter(src, ref)`` of the reference; result lives on ``src``'s device.
 
-        exact_order: splat sums in the reference's pixel order (bit-identical to the CPU path);
-        the default LDS-staged splat agrees to fp32 rounding.  no_tiles: plain gather kernels."""
+        exact: reference-exact arithmetic (pixel-ordered splat sums, per-term divide in slice):
+        bit-identical to the reference's CPU path.  The default LDS-staged path agrees to fp32
+        rounding (~1e-7 relative).  no_tiles: plain gather kernels (A/B)."""
         if src.dim() != 2 or src.shape[0] != self.n:
             # same text as the reference's assert (gaussian_matrix.py:429-430)
             raise AssertionError("Incompatible shapes {}, and {}".format(tuple(src.shape), (self.n, self.d)))
@@ -153,8 +153,7 @@ class Lattice:
         vd = int(src_d.shape[1])
         res = out if (out is not None and out.device == self.device) else torch.empty(
             (self.n, vd), dtype=torch.float32, device=self.device)
-        flags = ((SUBTRACT_INPUT if subtract_input else 0) | (FAST_SLICE if fast_slice else 0) |
-                 (EXACT_ORDER if exact_order else 0) | (NO_TILES if no_tiles else 0))
+        flags = (SUBTRACT_INPUT if subtract_input else 0) | (EXACT if exact else 0) | (NO_TILES if no_tiles else 0)
         with torch.cuda.device(self.device):
             _check(load_library().phl_filter(self._h, C.c_void_p(src_d.data_ptr()), vd, src_d.stride(0),
                                              src_d.stride(1), C.c_void_p(res.data_ptr()), res.stride(0),
@@ -165,7 +164,7 @@ class Lattice:
         return res if src.device == self.device else res.to(src.device)
 
     # ---- stages (profiling / parity of intermediates) ---------------------------------------
-    def splat(self, src, exact_order=False, no_tiles=False):
+    def splat(self, src, exact=False, no_tiles=False):
         src_d = _as_device(src.detach(), self.device)
         assert src_d.stride(1) == 1, "stage API takes pixel-major rows"
         vd = int(src_d.shape[1])
@@ -173,7 +172,7 @@ class Lattice:
         with torch.cuda.device(self.device):
             _check(load_library().phl_splat(self._h, C.c_void_p(src_d.data_ptr()), vd, src_d.stride(0),
                                             C.c_void_p(vert.data_ptr()),
-                                            (EXACT_ORDER if exact_order else 0) | (NO_TILES if no_tiles else 0),
+                                            (EXACT if exact else 0) | (NO_TILES if no_tiles else 0),
                                             _stream(self.device)))
         return vert
 
@@ -193,14 +192,14 @@ class Lattice:
             a, b = b, a
         return a
 
-    def slice(self, vert, sub=None, fast_slice=False, out=None, no_tiles=False):
+    def slice(self, vert, sub=None, exact=False, out=None, no_tiles=False):
         vd = int(vert.shape[1])
         out = torch.empty((self.n, vd), dtype=torch.float32, device=self.device) if out is None else out
         with torch.cuda.device(self.device):
             _check(load_library().phl_slice(self._h, C.c_void_p(vert.data_ptr()), vd, C.c_void_p(out.data_ptr()),
                                             out.stride(0), C.c_void_p(sub.data_ptr()) if sub is not None else None,
                                             sub.stride(0) if sub is not None else 0,
-                                            (FAST_SLICE if fast_slice else 0) | (NO_TILES if no_tiles else 0),
+                                            (EXACT if exact else 0) | (NO_TILES if no_tiles else 0),
                                             _stream(self.device)))
         return out
 

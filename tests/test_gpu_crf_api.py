@@ -50,7 +50,7 @@ def test_lattice_filter_backward(golden_dir, name):
     src = torch.from_numpy(g["src"]).to(dev).requires_grad_(True)
     gout = torch.from_numpy(g["gout"]).to(dev)
     out = LatticeFilter.apply(src, ref)
-    assert rel(out.detach().cpu().numpy(), g["out"]) <= 1e-5
+    assert np.abs(out.detach().cpu().numpy() - g["out"]).max() <= 1e-5 * np.abs(g["out"]).max()
     out.backward(gout)
     assert rel(src.grad.cpu().numpy(), g["grad_src"]) <= RTOL
     assert rel(ref.grad.cpu().numpy(), g["grad_ref"]) <= 5e-4      # reference's own gradcheck rtol (gaussian_matrix.py:516)

@@ -45,7 +45,7 @@ def test_add_vertices_semantics():
     assert np.array_equal(ids[:10], np.arange(10, 20)) and np.array_equal(ids[10:13], np.arange(M0, M0 + 3))
     assert np.array_equal(L.keys(), O.keys()) and np.array_equal(L.neighbors(), O.neighbors())
     src = rng.standard_normal((3000, 8)).astype(np.float32)
-    a = L.filter(torch.from_numpy(src).cuda(), exact_order=True).cpu().numpy()
+    a = L.filter(torch.from_numpy(src).cuda(), exact=True).cpu().numpy()
     assert np.array_equal(a.view(np.uint32), O.filter(src).view(np.uint32))
     v = L.splat(torch.from_numpy(src).cuda())
     assert v.shape[0] == M0 + 3 and float(v[M0:].abs().max()) == 0.0               # ghosts receive nothing locally
