@@ -216,6 +216,23 @@ __device__ __forceinline__ float4 fma4(float4 acc, float w, float4 v)
                        __builtin_fmaf(w, v.w, acc.w));
 }
 
+// x + (x of the lane 16 / 32 positions away): gfx950 VALU lane-swap instructions
+// (v_permlane16_swap swaps the odd 16-lane rows of its first operand with the even rows of the
+// second; v_permlane32_swap the upper half of the first with the lower half of the second), so
+// with both operands = x the two results are the two butterfly partners.
+__device__ __forceinline__ float xsum16(float x)
+{
+    const unsigned u = __float_as_uint(x);
+    const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float xsum32(float x)
+{
+    const unsigned u = __float_as_uint(x);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
 // One workgroup (TPB threads) per chunk.  LPRS lanes own one row of a channel slab of
 // SL = 4*LPRS floats.  LDS: [rows x SL] staged rows | per-entry {LDS byte offset, weight} |
 // chunk pixel ids | local segment pointers | destination of each local vertex.  Index data
@@ -255,6 +272,8 @@ __global__ __launch_bounds__(TPB) void k_splat_tiled(const float *__restrict__ s
     int *spl = pixl + P;                   // [nv_cap + 1]
     int *dvl = spl + nv_cap + 1;           // [nv_cap] slot_vert
     int *dpl = dvl + nv_cap;               // [nv_cap] slot_pidx
+    int *ctr = dpl + nv_cap;               // one work counter per slab (dynamic vertex scheduling)
+    if (threadIdx.x < 64) ctr[threadIdx.x] = NW;
     for (int e = threadIdx.x; e < E; e += TPB) {
         const phl_contrib_t s = seg[ebase + e];
         ent[e] = make_uint2((unsigned)(s.pixel * SL * 4), __float_as_uint(s.w));
@@ -295,23 +314,33 @@ __global__ __launch_bounds__(TPB) void k_splat_tiled(const float *__restrict__ s
 #pragma unroll
             for (int u = 0; u < PF; u++) pf[u] = ld4(src + (int64_t)pixl[min(g + u * G, kclamp)] * src_rs + chnc);
         }
-        for (int i = wave; i < nv; i += NW) {
+        // waves take vertices from a shared counter: segment lengths vary from 1 to P, a static
+        // round-robin leaves waves idle at the barrier
+        int *slab_ctr = ctr + (c0 / SL);
+        for (int i = wave; i < nv;) {
             const int s0 = spl[i], s1 = spl[i + 1];
             float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
             int s = s0 + q;
-            for (; s + Q < s1; s += 2 * Q) {
-                const uint2 e0 = ent[s], e1 = ent[s + Q];
+            for (; s + 3 * Q < s1; s += 4 * Q) {
+                const uint2 e0 = ent[s], e1 = ent[s + Q], e2 = ent[s + 2 * Q], e3 = ent[s + 3 * Q];
                 const float4 q0 = *reinterpret_cast<const float4 *>(rbase + e0.x);
                 const float4 q1 = *reinterpret_cast<const float4 *>(rbase + e1.x);
-                acc = mac4(acc, __uint_as_float(e0.y), q0);
-                acc = mac4(acc, __uint_as_float(e1.y), q1);
+                const float4 q2 = *reinterpret_cast<const float4 *>(rbase + e2.x);
+                const float4 q3 = *reinterpret_cast<const float4 *>(rbase + e3.x);
+                acc = fma4(acc, __uint_as_float(e0.y), q0);
+                acc = fma4(acc, __uint_as_float(e1.y), q1);
+                acc = fma4(acc, __uint_as_float(e2.y), q2);
+                acc = fma4(acc, __uint_as_float(e3.y), q3);
             }
-            if (s < s1) {
+            for (; s < s1; s += Q) {
                 const uint2 e0 = ent[s];
-                acc = mac4(acc, __uint_as_float(e0.y), *reinterpret_cast<const float4 *>(rbase + e0.x));
+                acc = fma4(acc, __uint_as_float(e0.y), *reinterpret_cast<const float4 *>(rbase + e0.x));
             }
+            // combine the lane groups' sums with a fixed butterfly (VALU lane swaps, no LDS)
+            if (LPRS <= 16) { acc.x = xsum16(acc.x); acc.y = xsum16(acc.y); acc.z = xsum16(acc.z); acc.w = xsum16(acc.w); }
+            if (LPRS <= 32) { acc.x = xsum32(acc.x); acc.y = xsum32(acc.y); acc.z = xsum32(acc.z); acc.w = xsum32(acc.w); }
 #pragma unroll
-            for (int off = LPRS; off < 64; off <<= 1) {
+            for (int off = LPRS; off < 16; off <<= 1) {    // narrow slabs (< 16 lanes per row): in-row shuffles
                 acc.x += __shfl_xor(acc.x, off);
                 acc.y += __shfl_xor(acc.y, off);
                 acc.z += __shfl_xor(acc.z, off);
@@ -322,6 +351,9 @@ __global__ __launch_bounds__(TPB) void k_splat_tiled(const float *__restrict__ s
                 float *dst = v < 0 ? vert + (int64_t)(v & 0x7FFFFFFF) * vd : partial + (int64_t)dpl[i] * vd;
                 st4(dst + ch, acc);
             }
+            int nxt = 0;
+            if (lane == 0) nxt = atomicAdd(slab_ctr, 1);
+            i = __builtin_amdgcn_readfirstlane(nxt);
         }
         __syncthreads();                   // everyone is done reading this slab
         if (more) {
@@ -492,7 +524,7 @@ int lds_budget()
 }
 
 // bytes of index data staged next to the rows (entries, pixel ids, local pointers)
-inline int64_t lds_extra(int P, int dp1, int nv_max) { return (int64_t)P * dp1 * 8 + (int64_t)P * 4 + ((int64_t)nv_max + 1) * 12 + 16; }
+inline int64_t lds_extra(int P, int dp1, int nv_max) { return (int64_t)P * dp1 * 8 + (int64_t)P * 4 + ((int64_t)nv_max + 1) * 12 + 16 + 256; }
 
 // lanes (of 4 floats) per slab row: as wide as vd, narrowed until `rows` rows + index data fit
 // in LDS; -1 if even the narrowest slab does not fit
