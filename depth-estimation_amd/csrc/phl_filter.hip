@@ -19,6 +19,8 @@
 //   slice  col += w * vert / (1 + 2^-d) per term                      (:480)
 // so the device results are bit-identical to the CPU path wherever the summation order is
 // defined by the algorithm (which is everywhere: the splat lists are pixel-sorted).
+#include <stdlib.h>
+
 #include <type_traits>
 
 #include "phl_internal.h"
@@ -137,7 +139,7 @@ __global__ __launch_bounds__(256) void k_splat(const float *__restrict__ src, in
 // absent neighbour = 0 (the reference never creates vertices in blur, :516-522).
 template <int VEC, int LPR>
 __global__ __launch_bounds__(256) void k_blur(const float *__restrict__ vin, float *__restrict__ vout,
-                                              const int2 *__restrict__ nbr, int M, int vd)
+                                              const int2 *__restrict__ nbr, int M, int vd, int xcd_chunk)
 {
     using V = typename vec_of<VEC>::type;
     constexpr int G = 64 / LPR;
@@ -145,8 +147,15 @@ __global__ __launch_bounds__(256) void k_blur(const float *__restrict__ vin, flo
     const int lane = threadIdx.x & 63;
     const int sub = lane / LPR;
     const int l = lane % LPR;
-    const int64_t stride = (int64_t)waves_in_grid() * G * U;
-    for (int64_t v0 = (int64_t)wave_in_grid() * G * U; v0 < M; v0 += stride) {
+    // XCD-aware block order: workgroups are dealt round-robin to the 8 XCDs, so blocks b and
+    // b+8 share an L2.  Giving every XCD one CONTIGUOUS eighth of the vertex range makes a
+    // vertex's blur neighbours (a few thousand rows away at most in first-touch order) land in
+    // the same L2 instead of being re-fetched by another XCD.  Speed only, never correctness.
+    const int lb = xcd_chunk > 0 ? (int)(blockIdx.x & 7) * xcd_chunk + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    const int wv = lb * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    {
+        const int64_t v0 = (int64_t)wv * G * U;
+        if (v0 >= M) return;
         int64_t v[U];
         int2 nb[U];
 #pragma unroll
@@ -309,11 +318,19 @@ int phl_launch_blur(const phl_lattice *lat, int axis, const float *vin, float *v
     const int2 *nbr = reinterpret_cast<const int2 *>(lat->nbr) + (int64_t)axis * M;
     const bool v4 = (vd % 4 == 0) && aligned16(vin) && aligned16(vout);
     const int lpr = pick_lpr(vd, v4 ? 4 : 1);
-    const unsigned grid = grid_for(M, (64 / lpr) * 4);
+    const int rows_per_block = (64 / lpr) * 4 * 4;
+    int64_t blocks = ((int64_t)M + rows_per_block - 1) / rows_per_block;
+    static const bool xcd = !(getenv("PHL_XCD") && atoi(getenv("PHL_XCD")) == 0);
+    int xcd_chunk = 0;
+    if (xcd && blocks >= 64) {
+        blocks = (blocks + 7) / 8 * 8;
+        xcd_chunk = (int)(blocks / 8);
+    }
+    const unsigned grid = (unsigned)blocks;
     dispatch_lpr(lpr, [&](auto L) {
         constexpr int LPR = decltype(L)::value;
-        if (v4) k_blur<4, LPR><<<dim3(grid), dim3(256), 0, st>>>(vin, vout, nbr, M, vd);
-        else k_blur<1, LPR><<<dim3(grid), dim3(256), 0, st>>>(vin, vout, nbr, M, vd);
+        if (v4) k_blur<4, LPR><<<dim3(grid), dim3(256), 0, st>>>(vin, vout, nbr, M, vd, xcd_chunk);
+        else k_blur<1, LPR><<<dim3(grid), dim3(256), 0, st>>>(vin, vout, nbr, M, vd, xcd_chunk);
     });
     PHL_HIP(hipGetLastError());
     return PHL_OK;

@@ -249,7 +249,7 @@ __global__ __launch_bounds__(TPB) void k_splat_tiled(const float *__restrict__ s
                                                      const int *__restrict__ vptr, const int *__restrict__ slot_vert,
                                                      const int *__restrict__ slot_pidx, const int *__restrict__ seg_ptr,
                                                      const phl_contrib_t *__restrict__ seg, float *__restrict__ vert,
-                                                     float *__restrict__ partial)
+                                                     float *__restrict__ partial, int nchunks, int xcd_chunk)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int SL = LPRS * 4;
@@ -260,7 +260,9 @@ __global__ __launch_bounds__(TPB) void k_splat_tiled(const float *__restrict__ s
     const int g = threadIdx.x / LPRS, l = threadIdx.x % LPRS;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int q = lane / LPRS;
-    const int c = blockIdx.x;
+    // XCD-aware chunk order (see k_blur): neighbouring chunks share boundary vertices
+    const int c = xcd_chunk > 0 ? (int)(blockIdx.x & 7) * xcd_chunk + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    if (c >= nchunks) return;
     const int base = c * P;
     const int cnt = min(P, n - base);
     const int E = cnt * dp1;
@@ -414,13 +416,15 @@ __global__ __launch_bounds__(TPB) void k_slice_tiled(const float *__restrict__ v
                                                      const unsigned short *__restrict__ lidx,
                                                      const phl_replay_t *__restrict__ replay, float *__restrict__ out,
                                                      int64_t out_rs, const float *__restrict__ sub_src, int64_t sub_rs,
-                                                     float cdiv, float rcdiv)
+                                                     float cdiv, float rcdiv, int nchunks, int xcd_chunk)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int SL = LPRS * 4;
     constexpr int G = TPB / LPRS;
     const int g = threadIdx.x / LPRS, l = threadIdx.x % LPRS;
-    const int c = blockIdx.x;
+    // XCD-aware chunk order (see k_blur): neighbouring chunks share boundary vertices
+    const int c = xcd_chunk > 0 ? (int)(blockIdx.x & 7) * xcd_chunk + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    if (c >= nchunks) return;
     const int base = c * P;
     const int cnt = min(P, n - base);
     const int E = cnt * dp1;
@@ -543,6 +547,19 @@ inline int allow_lds(K kernel, size_t bytes)
     if (bytes <= 64 * 1024) return PHL_OK;
     PHL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
     return PHL_OK;
+}
+
+// grid size and per-XCD chunk count for the XCD-aware chunk order
+inline void chunk_grid(int nchunks, unsigned *grid, int *xcd_chunk)
+{
+    static const bool xcd = !(getenv("PHL_XCD") && atoi(getenv("PHL_XCD")) == 0);
+    if (xcd && nchunks >= 64) {
+        *grid = (unsigned)((nchunks + 7) / 8 * 8);
+        *xcd_chunk = (int)(*grid / 8);
+    } else {
+        *grid = (unsigned)nchunks;
+        *xcd_chunk = 0;
+    }
 }
 
 inline int pick_lpr_row(int vd)
@@ -784,12 +801,15 @@ int phl_launch_splat_tiled(phl_lattice *lat, const float *src, int64_t src_rs, i
     int rc = phl_tiles_reserve(lat, vd);
     if (rc) return rc;
     const size_t lds = (size_t)lat->P * lprs * 16 + (size_t)extra;
+    unsigned cgrid;
+    int xcd_chunk;
+    chunk_grid(lat->nchunks, &cgrid, &xcd_chunk);
     dispatch_lprs(lprs, [&](auto L) {
         constexpr int LPRS = decltype(L)::value;
         if ((rc = allow_lds(k_splat_tiled<LPRS>, lds)) != PHL_OK) return;
-        k_splat_tiled<LPRS><<<dim3(lat->nchunks), dim3(TPB), lds, st>>>(
+        k_splat_tiled<LPRS><<<dim3(cgrid), dim3(TPB), lds, st>>>(
             src, src_rs, vd, (int)lat->n, lat->P, lat->d + 1, lat->nv_max, lat->pix_order, lat->chunk_vptr, lat->slot_vert,
-            lat->slot_pidx, lat->seg_ptr, lat->seg, vert, lat->partial);
+            lat->slot_pidx, lat->seg_ptr, lat->seg, vert, lat->partial, lat->nchunks, xcd_chunk);
     });
     if (rc) return rc;
     const int lpr = pick_lpr_row(vd);
@@ -825,18 +845,21 @@ int phl_launch_slice_tiled(const phl_lattice *lat, const float *vert, int vd, fl
     const size_t lds = (size_t)lat->nv_max * lprs * 16 + (size_t)extra;
     const bool exact = (flags & PHL_FILTER_EXACT) != 0;
     int rc = PHL_OK;
+    unsigned cgrid;
+    int xcd_chunk;
+    chunk_grid(lat->nchunks, &cgrid, &xcd_chunk);
     dispatch_lprs(lprs, [&](auto L) {
         constexpr int LPRS = decltype(L)::value;
         if (exact) {
             if ((rc = allow_lds(k_slice_tiled<LPRS, true>, lds)) != PHL_OK) return;
-            k_slice_tiled<LPRS, true><<<dim3(lat->nchunks), dim3(TPB), lds, st>>>(
+            k_slice_tiled<LPRS, true><<<dim3(cgrid), dim3(TPB), lds, st>>>(
                 vert, vd, (int)lat->n, lat->P, lat->d + 1, lat->nv_max, lat->pix_order, lat->chunk_vptr, lat->slot_vert,
-                lat->lidx, lat->replay, out, out_rs, sub, sub_rs, cdiv, rcdiv);
+                lat->lidx, lat->replay, out, out_rs, sub, sub_rs, cdiv, rcdiv, lat->nchunks, xcd_chunk);
         } else {
             if ((rc = allow_lds(k_slice_tiled<LPRS, false>, lds)) != PHL_OK) return;
-            k_slice_tiled<LPRS, false><<<dim3(lat->nchunks), dim3(TPB), lds, st>>>(
+            k_slice_tiled<LPRS, false><<<dim3(cgrid), dim3(TPB), lds, st>>>(
                 vert, vd, (int)lat->n, lat->P, lat->d + 1, lat->nv_max, lat->pix_order, lat->chunk_vptr, lat->slot_vert,
-                lat->lidx, lat->replay, out, out_rs, sub, sub_rs, cdiv, rcdiv);
+                lat->lidx, lat->replay, out, out_rs, sub, sub_rs, cdiv, rcdiv, lat->nchunks, xcd_chunk);
         }
     });
     if (rc) return rc;

@@ -49,3 +49,58 @@ def test_add_vertices_semantics():
     assert np.array_equal(a.view(np.uint32), O.filter(src).view(np.uint32))
     v = L.splat(torch.from_numpy(src).cuda())
     assert v.shape[0] == M0 + 3 and float(v[M0:].abs().max()) == 0.0               # ghosts receive nothing locally
+
+
+def _gpu_worker(rank, world, port, H, W, L, q):
+    import os
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (os.path.join(root, "depth-estimation_amd"), root, os.path.join(root, "tests")):
+        sys.path.insert(0, p)
+    import torch.distributed as dist
+    from phl import rowtile
+    from test_rowtile_cpu import make_image
+
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    dev = torch.device("cuda", 0)
+    feat, src = make_image(H, W, L, sigma_xy=3.0)
+    job = rowtile.RowTileFilter(feat, L, rank, world, dev, dist)          # HIP engine, exchange staged through gloo
+    mine = torch.from_numpy(src[job.row0 * W:(job.row0 + job.own_rows) * W]).to(dev)
+    out = job.filter(mine)
+    out2 = job.filter(mine)
+    assert torch.equal(out, out2)
+    q.put((rank, out.cpu().numpy(), job.describe()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_processes_share_the_gpu_over_gloo():
+    """The torch.distributed driver (RowTileFilter) with the HIP engine in two real processes.
+    One GPU box cannot host two RCCL ranks, so the payloads travel through gloo here; the rank
+    logic, ghost import and index maps are the ones the RCCL run uses."""
+    import socket
+
+    import torch.multiprocessing as mp
+
+    import phl
+    from test_rowtile_cpu import make_image
+
+    H, W, L, world = 96, 64, 8, 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_gpu_worker, args=(r, world, port, H, W, L, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    feat, src = make_image(H, W, L, sigma_xy=3.0)
+    want = phl.Lattice(torch.from_numpy(feat.reshape(-1, 5)).cuda()).filter(torch.from_numpy(src).cuda()).cpu().numpy()
+    got = np.concatenate([r[1] for r in res], 0)
+    assert rel(got, want) <= RTOL
