@@ -130,6 +130,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-tiles", action="store_true", help="plain gather kernels (A/B against the LDS-staged chunk path)")
     ap.add_argument("--exact", action="store_true", help="reference-exact arithmetic (bit-identical to the CPU path)")
+    ap.add_argument("--force-rowtile", action="store_true", help="debug: run the row-band driver even with one rank")
     args = ap.parse_args()
 
     import torch
@@ -146,10 +147,13 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_rowtile:
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=device)
+        if not (os.environ.get("MASTER_ADDR") and os.environ.get("MASTER_PORT")):
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     import phl
 
@@ -158,7 +162,10 @@ def main():
     feat = synthetic_features(H, W)
     n_total = H * W
 
-    if world > 1:
+    rowtiled = world > 1 or args.force_rowtile
+    if rowtiled and args.workload == "c5":
+        rowtiled = False      # BASELINE configs[4]: independent volumes, one per GPU, no exchange
+    if rowtiled:
         from phl import rowtile
 
         job = rowtile.RowTileFilter(feat, L, rank, world, device, dist)
@@ -200,12 +207,13 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ms_per_step = dt / args.steps * 1e3
-    value = n_total * L / (dt / args.steps) / 1e6
+    volumes = world if (world > 1 and not rowtiled) else 1     # independent volumes: one per rank
+    value = volumes * n_total * L / (dt / args.steps) / 1e6
 
     # ---- per-kernel timing with HIP events on the launch stream (rank-local lattice) ---------
     roofline = None
     stage_ms = {}
-    if world == 1:
+    if not rowtiled:
         ev = lambda: torch.cuda.Event(enable_timing=True)
         reps = max(3, min(args.steps, 10))
         acc = {"splat": 0.0, "blur_axis": 0.0, "slice": 0.0}
@@ -245,7 +253,7 @@ def main():
                     "blur_read_frac_of_peak": round(4 * M * L / (stage_ms["blur_axis"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
 
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not rowtiled and not args.no_cpu_baseline:
         cpu = cpu_baseline(feat, H, W, L, d, torch)
 
     if rank == 0:
@@ -253,13 +261,15 @@ def main():
             "metric": "Mpixel-labels/s per CRF mean-field iter (splat+blur+slice)",
             "value": round(value, 1), "unit": "Mpixel-labels/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
-            "scaling": "strong" if world > 1 else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "strong" if (world > 1 and rowtiled) else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {desc}", "H": H, "W": W, "L": L, "d": d, "sigma_xy": SIGMA_XY,
                        "sigma_c": SIGMA_C, "n": n_total, "M": int(M), "M_over_n": round(M / n_local, 4),
-                       "parallelism": "single GPU" if world == 1 else f"row bands x{world} + RCCL halo exchange",
+                       "parallelism": ("single GPU" if world == 1 and not rowtiled else
+                                       f"row bands x{world} + RCCL boundary-vertex exchange" if rowtiled else
+                                       f"{world} independent volumes, one per GPU, no collective"),
                        "arithmetic": "reference-exact (bit-identical to the CPU path)" if args.exact else "default (fp32-rounding-equivalent, ~1e-7 rel)"},
             "lattice_build_ms": round(build_ms, 2),
-            "value_rebuild_each_iter": round(n_total * L / ((ms_per_step + build_ms) * 1e-3) / 1e6, 1),
+            "value_rebuild_each_iter": round(volumes * n_total * L / ((ms_per_step + build_ms) * 1e-3) / 1e6, 1),
             "roofline": roofline, "cpu_baseline": cpu,
         }
         line.update(extra)

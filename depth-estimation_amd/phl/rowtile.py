@@ -105,15 +105,15 @@ class RowBand:
 
     # -- filter phases --------------------------------------------------------------------------
     def splat_outbox(self, src):
-        self._vert = self.eng.splat(src)
-        return {peer: self._vert.index_select(0, s["send_idx"]) for peer, s in self.sides.items()}
+        """src [n_local, C] (any channel subset, unit column stride) -> (vertex sums, {peer: rows to send})"""
+        vert = self.eng.splat(src)
+        return vert, {peer: vert.index_select(0, s["send_idx"]) for peer, s in self.sides.items()}
 
-    def finish(self, inbox):
-        vert = self._vert
+    def finish(self, vert, inbox, out=None):
         for peer in sorted(inbox):
             vert.index_add_(0, self.sides[peer]["map_idx"], inbox[peer])   # distinct rows: deterministic
-        self._vert = None
-        return self.eng.slice(self.eng.blur(vert))
+        vert = self.eng.blur(vert)
+        return self.eng.slice(vert) if out is None else self.eng.slice(vert, out=out)
 
     @property
     def M(self):
@@ -124,9 +124,13 @@ class RowBand:
 
 
 class RowTileFilter:
-    """torch.distributed driver: one RowBand per rank, exchanges by batched isend/irecv."""
+    """torch.distributed driver: one RowBand per rank, exchanges by batched isend/irecv.
 
-    def __init__(self, feat, L, rank, world, device, dist, engine_factory=None):
+    The filter is channel-wise, so a call is pipelined over `groups` channel groups: the boundary
+    rows of group g travel over xGMI (RCCL runs on its own stream) while group g+1 is being
+    splatted, and group g is blurred/sliced while group g+1's rows are still in flight."""
+
+    def __init__(self, feat, L, rank, world, device, dist, engine_factory=None, groups=None):
         if engine_factory is None:
             import phl
             engine_factory = phl.Lattice
@@ -144,10 +148,13 @@ class RowTileFilter:
             torch.cuda.synchronize(device)
         self.build_ms = (time.time() - t0) * 1e3
         self.row0, self.own_rows, self.n_local = self.band.row0, self.band.own_rows, self.band.n_local
-        self._rbuf = {p: torch.empty((self.band.recv_rows(p), L), dtype=torch.float32, device=self.comm_device)
-                      for p in self.band.sides}
+        if groups is None:
+            groups = 2 if (world > 1 and L % 8 == 0 and L >= 64) else 1
+        self.groups = [(g * L // groups, (g + 1) * L // groups) for g in range(groups)]
+        self._rbuf = [{p: torch.empty((self.band.recv_rows(p), c1 - c0), dtype=torch.float32, device=self.comm_device)
+                       for p in self.band.sides} for c0, c1 in self.groups]
         if hasattr(self.band.eng, "reserve"):
-            self.band.eng.reserve(L)
+            self.band.eng.reserve(max(c1 - c0 for c0, c1 in self.groups))
 
     @property
     def M(self):
@@ -174,25 +181,33 @@ class RowTileFilter:
 
     def filter(self, src):
         """src: this rank's rows, [own_rows*W, L] on the engine device -> same shape."""
-        out = self.band.splat_outbox(src)
         dist = self.dist
-        ops, keep = [], []
-        for peer in sorted(out):
-            snd = out[peer] if out[peer].device == self.comm_device else out[peer].to(self.comm_device)
-            keep.append(snd)
-            ops.append(dist.P2POp(dist.isend, snd.contiguous(), peer))
-            ops.append(dist.P2POp(dist.irecv, self._rbuf[peer], peer))
-        if ops:
-            for req in dist.batch_isend_irecv(ops):
+        out = torch.empty((self.band.n_local, self.L), dtype=torch.float32, device=self.band.device)
+        pending = []
+        for gi, (c0, c1) in enumerate(self.groups):
+            vert, outbox = self.band.splat_outbox(src[:, c0:c1])
+            ops, keep = [], []
+            for peer in sorted(outbox):
+                snd = outbox[peer] if outbox[peer].device == self.comm_device else outbox[peer].to(self.comm_device)
+                keep.append(snd)
+                ops.append(dist.P2POp(dist.isend, snd.contiguous(), peer))
+                ops.append(dist.P2POp(dist.irecv, self._rbuf[gi][peer], peer))
+            reqs = dist.batch_isend_irecv(ops) if ops else []
+            pending.append((vert, reqs, keep))
+        for gi, (c0, c1) in enumerate(self.groups):
+            vert, reqs, _ = pending[gi]
+            for req in reqs:
                 req.wait()
-        inbox = {p: (b if b.device == self.band.device else b.to(self.band.device)) for p, b in self._rbuf.items()}
-        return self.band.finish(inbox)
+            inbox = {p: (b if b.device == self.band.device else b.to(self.band.device)) for p, b in self._rbuf[gi].items()}
+            self.band.finish(vert, inbox, out=out[:, c0:c1])
+        return out
 
     def describe(self):
         b = self.band
         rows = {str(p): b.recv_rows(p) for p in b.sides}
         return {"rowtile": {"rows_per_rank": b.own_rows, "strip_rows": b.S, "M_local_plus_ghosts": int(b.M),
                             "boundary_vertices_recv": rows,
+                            "channel_groups": len(self.groups),
                             "exchange_bytes_per_step_per_rank": int(sum(rows.values()) * self.L * 4 * 2)}}
 
 
@@ -205,5 +220,5 @@ def simulate(feat, src_full, world, engine_factory, device):
     for r, b in enumerate(bands):
         b.build_inbox({p: out[p][r] for p in b.sides})
     outs = [b.splat_outbox(src_full[b.row0 * W:b.row1 * W]) for b in bands]
-    res = [b.finish({p: outs[p][r] for p in b.sides}) for r, b in enumerate(bands)]
+    res = [b.finish(outs[r][0], {p: outs[p][1][r] for p in b.sides}) for r, b in enumerate(bands)]
     return torch.cat(res, 0), bands

@@ -30,5 +30,9 @@ class OracleEngine:
     def blur(self, vert):
         return torch.from_numpy(self._o.blur(vert.cpu().numpy()))
 
-    def slice(self, vert):
-        return torch.from_numpy(self._o.slice(vert.cpu().numpy()))
+    def slice(self, vert, out=None):
+        res = torch.from_numpy(self._o.slice(vert.cpu().numpy()))
+        if out is not None:
+            out.copy_(res)
+            return out
+        return res

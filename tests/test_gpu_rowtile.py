@@ -65,7 +65,7 @@ def _gpu_worker(rank, world, port, H, W, L, q):
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
     dev = torch.device("cuda", 0)
     feat, src = make_image(H, W, L, sigma_xy=3.0)
-    job = rowtile.RowTileFilter(feat, L, rank, world, dev, dist)          # HIP engine, exchange staged through gloo
+    job = rowtile.RowTileFilter(feat, L, rank, world, dev, dist, groups=2)   # HIP engine; payloads staged through gloo
     mine = torch.from_numpy(src[job.row0 * W:(job.row0 + job.own_rows) * W]).to(dev)
     out = job.filter(mine)
     out2 = job.filter(mine)

@@ -75,7 +75,7 @@ def _worker(rank, world, port, H, W, L, q):
 
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
     feat, src = make_image(H, W, L)
-    job = rowtile.RowTileFilter(feat, L, rank, world, torch.device("cpu"), dist, engine_factory=OracleEngine)
+    job = rowtile.RowTileFilter(feat, L, rank, world, torch.device("cpu"), dist, engine_factory=OracleEngine, groups=2)
     mine = torch.from_numpy(src[job.row0 * W:(job.row0 + job.own_rows) * W])
     out1 = job.filter(mine)
     out2 = job.filter(mine)          # second call: buffers are reused
@@ -107,4 +107,4 @@ def test_two_ranks_over_gloo():
     got = np.concatenate([r[2] for r in res], 0)
     assert rel(got, want) <= RTOL
     info = res[0][3]["rowtile"]
-    assert info["strip_rows"] == 13 and info["exchange_bytes_per_step_per_rank"] > 0
+    assert info["strip_rows"] == 13 and info["exchange_bytes_per_step_per_rank"] > 0 and info["channel_groups"] == 2
