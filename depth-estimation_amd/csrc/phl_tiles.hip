@@ -243,8 +243,10 @@ __device__ __forceinline__ float xsum32(float x)
 // xor-butterfly: a wavefront-level segmented reduction, deterministic, no atomics.
 constexpr int TPB = 512;
 
+constexpr int TPB_S = 512;   // splat: more waves hide the LDS latency of the segmented sums
+
 template <int LPRS>
-__global__ __launch_bounds__(TPB) void k_splat_tiled(const float *__restrict__ src, int64_t src_rs, int vd, int n, int P,
+__global__ __launch_bounds__(TPB_S) void k_splat_tiled(const float *__restrict__ src, int64_t src_rs, int vd, int n, int P,
                                                      int dp1, int nv_cap, const int *__restrict__ pix_order,
                                                      const int *__restrict__ vptr, const int *__restrict__ slot_vert,
                                                      const int *__restrict__ slot_pidx, const int *__restrict__ seg_ptr,
@@ -253,9 +255,9 @@ __global__ __launch_bounds__(TPB) void k_splat_tiled(const float *__restrict__ s
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int SL = LPRS * 4;
-    constexpr int G = TPB / LPRS;          // row groups of the workgroup (staging)
+    constexpr int G = TPB_S / LPRS;          // row groups of the workgroup (staging)
     constexpr int Q = 64 / LPRS;           // lane groups of a wavefront (entry-parallel)
-    constexpr int NW = TPB / 64;
+    constexpr int NW = TPB_S / 64;
     constexpr int PF = (256 / G) < 8 ? (256 / G) : 8;   // rows prefetched per thread
     const int g = threadIdx.x / LPRS, l = threadIdx.x % LPRS;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -270,22 +272,18 @@ __global__ __launch_bounds__(TPB) void k_splat_tiled(const float *__restrict__ s
     const int vbase = vptr[c], nv = vptr[c + 1] - vbase;
     float *rows = lds;
     uint2 *ent = reinterpret_cast<uint2 *>(lds + (size_t)P * SL);
-    int *pixl = reinterpret_cast<int *>(ent + P * dp1);
-    int *spl = pixl + P;                   // [nv_cap + 1]
-    int *dvl = spl + nv_cap + 1;           // [nv_cap] slot_vert
-    int *dpl = dvl + nv_cap;               // [nv_cap] slot_pidx
-    int *ctr = dpl + nv_cap;               // one work counter per slab (dynamic vertex scheduling)
-    if (threadIdx.x < 64) ctr[threadIdx.x] = NW;
-    for (int e = threadIdx.x; e < E; e += TPB) {
+    int4 *meta = reinterpret_cast<int4 *>(ent + P * dp1);          // [nv_cap] {seg begin, seg end, slot_vert, slot_pidx}
+    int *pixl = reinterpret_cast<int *>(meta + nv_cap);           // [P]
+    int *ctr = pixl + P;                                           // one work counter per slab
+    for (int e = threadIdx.x; e < E; e += TPB_S) {
         const phl_contrib_t s = seg[ebase + e];
         ent[e] = make_uint2((unsigned)(s.pixel * SL * 4), __float_as_uint(s.w));
     }
-    for (int k = threadIdx.x; k < cnt; k += TPB) pixl[k] = pix_order[base + k];
-    for (int i = threadIdx.x; i <= nv; i += TPB) spl[i] = (int)(seg_ptr[vbase + i] - ebase);
-    for (int i = threadIdx.x; i < nv; i += TPB) {
-        dvl[i] = slot_vert[vbase + i];
-        dpl[i] = slot_pidx[vbase + i];
-    }
+    for (int k = threadIdx.x; k < cnt; k += TPB_S) pixl[k] = pix_order[base + k];
+    for (int i = threadIdx.x; i < nv; i += TPB_S)
+        meta[i] = make_int4((int)(seg_ptr[vbase + i] - ebase), (int)(seg_ptr[vbase + i + 1] - ebase), slot_vert[vbase + i],
+                            slot_pidx[vbase + i]);
+    if (threadIdx.x < 64) ctr[threadIdx.x] = NW;
     __syncthreads();
     const char *rbase = reinterpret_cast<const char *>(rows) + l * 16;
     float4 pf[PF];
@@ -320,9 +318,12 @@ __global__ __launch_bounds__(TPB) void k_splat_tiled(const float *__restrict__ s
         // round-robin leaves waves idle at the barrier
         int *slab_ctr = ctr + (c0 / SL);
         for (int i = wave; i < nv;) {
-            const int s0 = spl[i], s1 = spl[i + 1];
+            const int4 m = meta[i];
+            int nxt = 0;
+            if (lane == 0) nxt = atomicAdd(slab_ctr, 1);       // next vertex, fetched under this one's work
+            const int s1 = m.y;
             float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-            int s = s0 + q;
+            int s = m.x + q;
             for (; s + 3 * Q < s1; s += 4 * Q) {
                 const uint2 e0 = ent[s], e1 = ent[s + Q], e2 = ent[s + 2 * Q], e3 = ent[s + 3 * Q];
                 const float4 q0 = *reinterpret_cast<const float4 *>(rbase + e0.x);
@@ -334,9 +335,20 @@ __global__ __launch_bounds__(TPB) void k_splat_tiled(const float *__restrict__ s
                 acc = fma4(acc, __uint_as_float(e2.y), q2);
                 acc = fma4(acc, __uint_as_float(e3.y), q3);
             }
-            for (; s < s1; s += Q) {
-                const uint2 e0 = ent[s];
-                acc = fma4(acc, __uint_as_float(e0.y), *reinterpret_cast<const float4 *>(rbase + e0.x));
+            {   // tail (< 4 entries per lane group) as ONE padded batch: out-of-range slots re-read
+                // the segment's last entry with weight 0, which adds exactly nothing
+                uint2 e[3];
+#pragma unroll
+                for (int u = 0; u < 3; u++) {
+                    const int idx = s + u * Q;
+                    e[u] = ent[min(idx, s1 - 1)];
+                    if (idx >= s1) e[u].y = 0u;
+                }
+                float4 r[3];
+#pragma unroll
+                for (int u = 0; u < 3; u++) r[u] = *reinterpret_cast<const float4 *>(rbase + e[u].x);
+#pragma unroll
+                for (int u = 0; u < 3; u++) acc = fma4(acc, __uint_as_float(e[u].y), r[u]);
             }
             // combine the lane groups' sums with a fixed butterfly (VALU lane swaps, no LDS)
             if (LPRS <= 16) { acc.x = xsum16(acc.x); acc.y = xsum16(acc.y); acc.z = xsum16(acc.z); acc.w = xsum16(acc.w); }
@@ -349,12 +361,9 @@ __global__ __launch_bounds__(TPB) void k_splat_tiled(const float *__restrict__ s
                 acc.w += __shfl_xor(acc.w, off);
             }
             if (q == 0 && chok) {
-                const int v = dvl[i];
-                float *dst = v < 0 ? vert + (int64_t)(v & 0x7FFFFFFF) * vd : partial + (int64_t)dpl[i] * vd;
+                float *dst = m.z < 0 ? vert + (int64_t)(m.z & 0x7FFFFFFF) * vd : partial + (int64_t)m.w * vd;
                 st4(dst + ch, acc);
             }
-            int nxt = 0;
-            if (lane == 0) nxt = atomicAdd(slab_ctr, 1);
             i = __builtin_amdgcn_readfirstlane(nxt);
         }
         __syncthreads();                   // everyone is done reading this slab
@@ -528,7 +537,7 @@ int lds_budget()
 }
 
 // bytes of index data staged next to the rows (entries, pixel ids, local pointers)
-inline int64_t lds_extra(int P, int dp1, int nv_max) { return (int64_t)P * dp1 * 8 + (int64_t)P * 4 + ((int64_t)nv_max + 1) * 12 + 16 + 256; }
+inline int64_t lds_extra(int P, int dp1, int nv_max) { return (int64_t)P * dp1 * 8 + (int64_t)P * 4 + ((int64_t)nv_max + 1) * 16 + 16 + 256; }
 
 // lanes (of 4 floats) per slab row: as wide as vd, narrowed until `rows` rows + index data fit
 // in LDS; -1 if even the narrowest slab does not fit
@@ -807,7 +816,7 @@ int phl_launch_splat_tiled(phl_lattice *lat, const float *src, int64_t src_rs, i
     dispatch_lprs(lprs, [&](auto L) {
         constexpr int LPRS = decltype(L)::value;
         if ((rc = allow_lds(k_splat_tiled<LPRS>, lds)) != PHL_OK) return;
-        k_splat_tiled<LPRS><<<dim3(cgrid), dim3(TPB), lds, st>>>(
+        k_splat_tiled<LPRS><<<dim3(cgrid), dim3(TPB_S), lds, st>>>(
             src, src_rs, vd, (int)lat->n, lat->P, lat->d + 1, lat->nv_max, lat->pix_order, lat->chunk_vptr, lat->slot_vert,
             lat->slot_pidx, lat->seg_ptr, lat->seg, vert, lat->partial, lat->nchunks, xcd_chunk);
     });
