@@ -91,6 +91,23 @@ def algorithmic_bytes(n, M, L, d):
     }
 
 
+def pmc_traffic(kernel_names, workload):
+    """HBM bytes per launch of the named kernel(s) from the committed rocprofv3 --pmc summary
+    (counters cannot be collected from inside the timed process; FETCH_SIZE is doubled there as
+    MI355X_MICROARCH.md prescribes for gfx950).  Only valid for the workload it was taken on."""
+    path = os.path.join(ROOT, "profiles", "r01_final_pmc_traffic.json")
+    if workload != "c3" or not os.path.exists(path):
+        return None, None
+    k = json.load(open(path))["kernels"]
+    total = 0
+    for name in kernel_names.split("+"):
+        hit = [v for kk, v in k.items() if kk.split("<")[0] == name]
+        if not hit:
+            return None, None
+        total += hit[0]["hbm_bytes_per_launch"]
+    return int(total), "profiles/r01_final_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, same command)"
+
+
 def cpu_baseline(feat, H, W, L, d, torch):
     """Reference engine (oracle/_ref, the reference's own C++) or our C port, one thread, on a
     bounded crop of the same workload.  Reported beside the GPU number; not a target."""
@@ -243,9 +260,10 @@ def main():
         staged_sl = extra["tiles"]["staged_slice"] and not args.no_tiles
         kname = {"splat": "k_splat_tiled+k_splat_reduce" if staged else "k_splat", "blur_axis": "k_blur",
                  "slice": "k_slice_tiled" if staged_sl else "k_slice"}
+        traffic, traffic_src = pmc_traffic(kname[dom], args.workload)
         roofline = {"bound": "hbm", "kernel": kname[dom],
                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                     "algorithmic_bytes_per_launch": int(ab[dom]), "avg_launch_ms": round(stage_ms[dom], 4),
                     "per_stage": {k: {"ms": round(stage_ms[k], 4), "launches_per_step": (d + 1 if k == "blur_axis" else 1),
                                       "algorithmic_GBps": round(ab[k] / (stage_ms[k] * 1e-3) / 1e9, 1)} for k in stage_ms},
