@@ -34,6 +34,7 @@ WORKLOADS = {
     "c2": (1110, 1390, 256, "Middlebury-sized 1390x1110x256, d=5 (BASELINE configs[1], synthetic features)"),
     "c5": (1024, 1024, 128, "1024x1024x128 volume, d=5 (BASELINE configs[4], one volume per GPU)"),
     "c1": (288, 384, 16, "Tsukuba-sized 384x288x16, d=5 (BASELINE configs[0])"),
+    "band8": (192, 2048, 256, "one eighth of c3 (192 rows): the per-rank share of an 8-GPU row-band run, for overhead studies"),
 }
 SIGMA_XY, SIGMA_C = 8.0, 0.1
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec

@@ -50,8 +50,27 @@ def compatibility_matrix(compat, labels):
     return compat(labels[:, None], labels[None, :])
 
 
+def _fused_ok(E_0, Mu):
+    return (E_0.is_cuda and E_0.dtype == torch.float32 and E_0.dim() == 2 and E_0.stride(1) == 1
+            and not (torch.is_grad_enabled() and (E_0.requires_grad or Mu.requires_grad)))
+
+
 def mean_field_infer(E_0, W, Mu, niters=10):
-    """[E_0] n x L unaries, [W] n x n operator, [Mu] L x L compatibility -> Q n x L (crf_module.py:41-53)."""
+    """[E_0] n x L unaries, [W] n x n operator, [Mu] L x L compatibility -> Q n x L (crf_module.py:41-53).
+
+    On the GPU inference path the elementwise half of an iteration (add, negate, softmax: ~7
+    sweeps over [n, L] in torch) is one fused HIP pass (phl.softmax_neg_add); the compatibility
+    product stays a library GEMM.  With autograd or CPU tensors the plain torch ops run."""
+    if _fused_ok(E_0, Mu):
+        import phl
+
+        Q = phl.softmax_neg_add(E_0)
+        for _ in range(niters):
+            G = (W @ Q) @ Mu
+            if not (G.is_cuda and G.dtype == torch.float32 and G.stride(1) == 1):
+                G = G.to(E_0.device, torch.float32).contiguous()
+            Q = phl.softmax_neg_add(E_0, G, out=Q)
+        return Q
     Q = F.softmax(-E_0, dim=1)
     for _ in range(niters):
         Q = F.softmax(-(E_0 + (W @ Q) @ Mu), dim=1)

@@ -72,6 +72,8 @@ def load_library():
         lib.phl_tile_stats.argtypes = [vp, i32, vp]
         lib.phl_blur_axis.argtypes = [vp, i32, vp, vp, i32, vp]
         lib.phl_slice.argtypes = [vp, vp, i32, vp, i64, vp, i64, u32, vp]
+        lib.phl_softmax_neg_add.argtypes = [vp, i64, vp, i64, vp, i64, i64, i32, vp]
+        lib.phl_expected_value.argtypes = [vp, i64, vp, vp, i64, i32, vp]
         lib.phl_get_keys.argtypes = [vp, vp]
         lib.phl_get_replay.argtypes = [vp, vp, vp]
         lib.phl_get_neighbors.argtypes = [vp, vp]
@@ -127,8 +129,11 @@ class Lattice:
 
     def close(self):
         h, self._h = getattr(self, "_h", None), None
-        if h:
-            load_library().phl_destroy(h)
+        if h and _lib is not None:          # at interpreter shutdown the module globals may be gone
+            try:
+                _lib.phl_destroy(h)
+            except Exception:
+                pass
 
     __del__ = close
 
@@ -250,6 +255,38 @@ class Lattice:
         _check(load_library().phl_get_splat_lists(self._h, ptr.ctypes.data_as(C.c_void_p),
                                                   pix.ctypes.data_as(C.c_void_p), w.ctypes.data_as(C.c_void_p)))
         return ptr, pix, w
+
+
+# ---------------------------------------------------------------------------------------------
+# fused elementwise steps of the mean-field iteration (crf/crf_module.py:49-52)
+def _rowmajor(t):
+    return t.is_cuda and t.dtype == torch.float32 and t.dim() == 2 and t.stride(1) == 1
+
+
+def softmax_neg_add(E0, G=None, out=None):
+    """softmax(-(E0 + G), dim=1) in one pass over HBM (G optional).  CUDA fp32 [n, L] only."""
+    if not _rowmajor(E0) or (G is not None and (not _rowmajor(G) or G.shape != E0.shape)):
+        raise TypeError("softmax_neg_add: expects fp32 CUDA [n, L] tensors with unit channel stride")
+    n, L = E0.shape
+    if out is None:
+        out = torch.empty((n, L), dtype=torch.float32, device=E0.device)
+    with torch.cuda.device(E0.device):
+        _check(load_library().phl_softmax_neg_add(
+            C.c_void_p(E0.data_ptr()), E0.stride(0), C.c_void_p(G.data_ptr()) if G is not None else None,
+            G.stride(0) if G is not None else 0, C.c_void_p(out.data_ptr()), out.stride(0), n, L, _stream(E0.device)))
+    return out
+
+
+def expected_value(Q, labels):
+    """Q @ labels (expected disparity per pixel) for CUDA fp32 Q [n, L], labels [L]."""
+    if not _rowmajor(Q) or labels.dtype != torch.float32 or labels.numel() != Q.shape[1]:
+        raise TypeError("expected_value: expects fp32 CUDA Q [n, L] and labels [L]")
+    labels = labels.to(Q.device).contiguous()
+    out = torch.empty((Q.shape[0],), dtype=torch.float32, device=Q.device)
+    with torch.cuda.device(Q.device):
+        _check(load_library().phl_expected_value(C.c_void_p(Q.data_ptr()), Q.stride(0), C.c_void_p(labels.data_ptr()),
+                                                 C.c_void_p(out.data_ptr()), Q.shape[0], Q.shape[1], _stream(Q.device)))
+    return out
 
 
 # ---------------------------------------------------------------------------------------------

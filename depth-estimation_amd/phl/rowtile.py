@@ -32,6 +32,7 @@ tests, where the engine is the CPU oracle) and under an in-process loopback that
 on one GPU (tests/test_gpu_rowtile.py).
 """
 import math
+import os
 import time
 
 import numpy as np
@@ -149,7 +150,7 @@ class RowTileFilter:
         self.build_ms = (time.time() - t0) * 1e3
         self.row0, self.own_rows, self.n_local = self.band.row0, self.band.own_rows, self.band.n_local
         if groups is None:
-            groups = 2 if (world > 1 and L % 8 == 0 and L >= 64) else 1
+            groups = int(os.environ.get("PHL_ROWTILE_GROUPS", "0")) or (2 if (world > 1 and L % 8 == 0 and L >= 64) else 1)
         self.groups = [(g * L // groups, (g + 1) * L // groups) for g in range(groups)]
         self._rbuf = [{p: torch.empty((self.band.recv_rows(p), c1 - c0), dtype=torch.float32, device=self.comm_device)
                        for p in self.band.sides} for c0, c1 in self.groups]

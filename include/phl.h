@@ -135,6 +135,17 @@ int phl_slice(phl_lattice *lat, const float *vert_dev, int vd, float *out_dev, i
               const float *sub_dev /* NULL or src to subtract */, int64_t sub_row_stride, unsigned flags,
               phl_stream stream);
 
+/* ---- mean-field elementwise steps around the filter ----------------------
+ * out[p,:] = softmax(-(E0[p,:] + G[p,:])) over the L labels of every pixel; G may be NULL.
+ * Fuses `E = E_0 + (W@Q)@Mu; Q = softmax(-E, dim=1)` of mean_field_infer (crf/crf_module.py:49-52)
+ * into one pass.  Rows are pixel-major with unit channel stride; row strides in elements. */
+int phl_softmax_neg_add(const float *E0_dev, int64_t e0_row_stride, const float *G_dev, int64_t g_row_stride,
+                        float *out_dev, int64_t out_row_stride, int64_t n, int L, phl_stream stream);
+/* out[p] = sum_c Q[p,c]*labels[c] : the expected disparity `mf @ labels`
+ * (Experiments/DenseCrf.ipynb cell 11). */
+int phl_expected_value(const float *Q_dev, int64_t q_row_stride, const float *labels_dev, float *out_dev,
+                       int64_t n, int L, phl_stream stream);
+
 /* Chunk ("tile") statistics of the LDS-staged path: out[0]=pixels per chunk, [1]=#chunks,
  * [2]=max local vertices per chunk, [3]=(chunk,vertex) slots S, [4]=slots of vertices fed by
  * several chunks, [5]=1 if the staged splat / [6]=slice would be chosen for this vd. */

@@ -97,3 +97,30 @@ def test_crf_as_rnn_lattice_runs():
     assert out.shape == logits.shape and torch.isfinite(out).all()
     out.sum().backward()
     assert torch.isfinite(logits.grad).all()
+
+
+@pytest.mark.parametrize("n,L", [(1000, 16), (4097, 256), (300, 300), (257, 1000), (64, 3), (50, 2048)])
+def test_fused_softmax_neg_add_and_expected_value(n, L):
+    """phl.softmax_neg_add == softmax(-(E0 + G)) of crf_module.py:49-52; fp32 tolerance (different
+    exp / reduction order than torch), rows sum to 1."""
+    import phl
+
+    g = torch.Generator(device="cuda").manual_seed(n + L)
+    E0 = torch.rand((n, L), device="cuda", generator=g) * 20
+    G = torch.randn((n, L), device="cuda", generator=g) * 5
+    want = torch.softmax(-(E0.double() + G.double()), dim=1)
+    got = phl.softmax_neg_add(E0, G)
+    # the fp32 sum E0+G carries ~1e-6 absolute rounding into the exponent, same as torch's fp32 path
+    assert float((got.double() - want).abs().max()) <= 2e-6
+    ref32 = torch.softmax(-(E0 + G), dim=1)
+    big = ref32 > 1e-20
+    assert float(((got - ref32).abs() / ref32.clamp_min(1e-30))[big].max()) <= 1e-5
+    assert float((got.sum(1) - 1).abs().max()) <= 1e-5
+    assert float((phl.softmax_neg_add(E0).double() - torch.softmax(-E0.double(), 1)).abs().max()) <= 2e-6
+    # row-padded views take the same path
+    pad = torch.zeros((n, L + 4), device="cuda")
+    pad[:, :L] = E0
+    assert torch.equal(phl.softmax_neg_add(pad[:, :L], G), got)
+    labels = torch.arange(L, dtype=torch.float32, device="cuda") * 0.5
+    ev = phl.expected_value(got, labels)
+    assert float((ev.double() - got.double() @ labels.double()).abs().max()) <= 1e-4 * float(labels.max() + 1)
