@@ -107,6 +107,18 @@ __global__ __launch_bounds__(256) void k_expected_value(const float *__restrict_
     }
 }
 
+// float4 streaming copy: the measured HBM ceiling the roofline fractions are quoted against
+__global__ __launch_bounds__(256) void k_stream_copy(const float4 *__restrict__ src, float4 *__restrict__ dst, int64_t n4)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i + 3 * stride < n4; i += 4 * stride) {
+        const float4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
+        dst[i] = a; dst[i + stride] = b; dst[i + 2 * stride] = c; dst[i + 3 * stride] = d;
+    }
+    for (; i < n4; i += stride) dst[i] = src[i];
+}
+
 inline unsigned rows_grid(int64_t n)
 {
     int64_t b = (n + 3) / 4;
@@ -131,6 +143,15 @@ int phl_softmax_neg_add(const float *E0, int64_t e_rs, const float *G, int64_t g
     else if (v4 && L <= 512) k_softmax_neg_add<2><<<dim3(grid), dim3(256), 0, st>>>(E0, e_rs, G, g_rs, out, o_rs, n, L);
     else if (v4 && L <= 1024) k_softmax_neg_add<4><<<dim3(grid), dim3(256), 0, st>>>(E0, e_rs, G, g_rs, out, o_rs, n, L);
     else k_softmax_neg_add_generic<<<dim3(grid), dim3(256), 0, st>>>(E0, e_rs, G, g_rs, out, o_rs, n, L);
+    PHL_HIP(hipGetLastError());
+    return PHL_OK;
+}
+
+int phl_stream_copy(const float *src, float *dst, int64_t n_floats, phl_stream stream)
+{
+    if (n_floats < 0 || n_floats % 4 || ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15)) { phl_set_error("phl_stream_copy: needs 16-byte aligned buffers, n % 4 == 0"); return PHL_ERR_INVALID; }
+    if (n_floats == 0) return PHL_OK;
+    k_stream_copy<<<dim3(256 * 8), dim3(256), 0, (hipStream_t)stream>>>(reinterpret_cast<const float4 *>(src), reinterpret_cast<float4 *>(dst), n_floats / 4);
     PHL_HIP(hipGetLastError());
     return PHL_OK;
 }

@@ -74,6 +74,7 @@ def load_library():
         lib.phl_slice.argtypes = [vp, vp, i32, vp, i64, vp, i64, u32, vp]
         lib.phl_softmax_neg_add.argtypes = [vp, i64, vp, i64, vp, i64, i64, i32, vp]
         lib.phl_expected_value.argtypes = [vp, i64, vp, vp, i64, i32, vp]
+        lib.phl_stream_copy.argtypes = [vp, vp, i64, vp]
         lib.phl_get_keys.argtypes = [vp, vp]
         lib.phl_get_replay.argtypes = [vp, vp, vp]
         lib.phl_get_neighbors.argtypes = [vp, vp]
@@ -275,6 +276,15 @@ def softmax_neg_add(E0, G=None, out=None):
             C.c_void_p(E0.data_ptr()), E0.stride(0), C.c_void_p(G.data_ptr()) if G is not None else None,
             G.stride(0) if G is not None else 0, C.c_void_p(out.data_ptr()), out.stride(0), n, L, _stream(E0.device)))
     return out
+
+
+def stream_copy(dst, src):
+    """float4 streaming copy (HBM ceiling probe for bench.py)."""
+    assert dst.is_contiguous() and src.is_contiguous() and dst.numel() == src.numel()
+    with torch.cuda.device(src.device):
+        _check(load_library().phl_stream_copy(C.c_void_p(src.data_ptr()), C.c_void_p(dst.data_ptr()), src.numel(),
+                                              _stream(src.device)))
+    return dst
 
 
 def expected_value(Q, labels):

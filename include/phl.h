@@ -146,6 +146,10 @@ int phl_softmax_neg_add(const float *E0_dev, int64_t e0_row_stride, const float 
 int phl_expected_value(const float *Q_dev, int64_t q_row_stride, const float *labels_dev, float *out_dev,
                        int64_t n, int L, phl_stream stream);
 
+/* Plain float4 streaming copy dst <- src (n_floats % 4 == 0, 16-byte aligned): measures the
+ * HBM read+write ceiling of the box that the roofline fractions are compared with. */
+int phl_stream_copy(const float *src_dev, float *dst_dev, int64_t n_floats, phl_stream stream);
+
 /* Chunk ("tile") statistics of the LDS-staged path: out[0]=pixels per chunk, [1]=#chunks,
  * [2]=max local vertices per chunk, [3]=(chunk,vertex) slots S, [4]=slots of vertices fed by
  * several chunks, [5]=1 if the staged splat / [6]=slice would be chosen for this vd. */
