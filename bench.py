@@ -114,7 +114,7 @@ def cpu_baseline(feat, H, W, L, d, torch):
     bounded crop of the same workload.  Reported beside the GPU number; not a target."""
     from oracle import phl_oracle as po
 
-    ch, cw = min(H, 768), min(W, 1024)
+    ch, cw = min(H, 1024), min(W, 1536)      # ~10 s of single-thread CPU work at L=256
     ref = np.ascontiguousarray(feat[:ch, :cw].reshape(-1, d))
     rng = np.random.default_rng(4321)
     src = rng.random((ch * cw, L), dtype=np.float32)

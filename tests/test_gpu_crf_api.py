@@ -124,3 +124,28 @@ def test_fused_softmax_neg_add_and_expected_value(n, L):
     labels = torch.arange(L, dtype=torch.float32, device="cuda") * 0.5
     ev = phl.expected_value(got, labels)
     assert float((ev.double() - got.double() @ labels.double()).abs().max()) <= 1e-4 * float(labels.max() + 1)
+
+
+def test_torch_cpp_extension_binding():
+    """lib/lattice_ext.so: pybind `filter(src, ref)` with the reference's signature
+    (crf/lattice/lite/lattice.cpp:6-15) forwarding to phl_filter_once."""
+    import importlib.util
+    import os
+
+    import phl
+
+    path = os.path.join(os.path.dirname(phl.LIB_PATH), "lattice_ext.so")
+    if not os.path.exists(path):
+        pytest.skip("lattice_ext.so not built")
+    spec = importlib.util.spec_from_file_location("lattice_ext", path)
+    ext = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ext)
+    src = torch.rand(3000, 12, device="cuda")
+    ref = torch.rand(3000, 5, device="cuda") * 4
+    a = ext.filter(src, ref)
+    b = phl.filter(src, ref)
+    assert a.is_cuda and torch.equal(a, b)
+    c = ext.filter(src.cpu(), ref.cpu())                    # CPU tensors in, CPU tensor out
+    assert not c.is_cuda and torch.equal(c, b.cpu())
+    with pytest.raises(RuntimeError, match="Incompatible shapes"):
+        ext.filter(src[:10], ref)
