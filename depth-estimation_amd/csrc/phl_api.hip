@@ -194,13 +194,6 @@ int phl_reserve(phl_lattice *lat, int vd)
     return PHL_OK;
 }
 
-[[maybe_unused]] static int reserve_all(phl_lattice *lat, int vd)
-{
-    int rc = phl_reserve(lat, vd);
-    if (rc == PHL_OK && phl_tiles_lprs(lat, vd, 0) >= 0 && lat->S_multi <= lat->n) rc = phl_tiles_reserve(lat, vd);
-    return rc;
-}
-
 int phl_splat(phl_lattice *lat, const float *src, int vd, int64_t src_rs, float *vert, unsigned flags, phl_stream st)
 {
     if (!lat || vd < 0 || (lat->n > 0 && vd > 0 && (!src || !vert))) { phl_set_error("phl_splat: bad arguments"); return PHL_ERR_INVALID; }

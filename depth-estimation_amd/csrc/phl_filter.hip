@@ -1,7 +1,12 @@
-// phl_filter.hip -- the hot path: splat -> blur (d+1 axes) -> slice on gfx950.
+// phl_filter.hip -- blur (all modes) and the gather forms of splat / slice on gfx950.
 //
-// All three stages are HBM/L2-bound row gathers over fp32 rows of `vd` channels (no MFMA:
-// arithmetic intensity < 1 flop/byte).  Common shape of every kernel:
+// k_blur is the blur of every filter call.  k_splat / k_slice are the plain gather kernels:
+// they carry PHL_FILTER_EXACT (reference-exact summation order) and every case the LDS-staged
+// chunk kernels of phl_tiles.hip do not take (vd % 4 != 0, unaligned rows, chunks that share
+// too few vertices).  The default fast path for splat and slice lives in phl_tiles.hip.
+//
+// All stages are HBM/L2-bound row gathers over fp32 rows of `vd` channels (no MFMA:
+// arithmetic intensity < 1 flop/byte).  Common shape of every kernel here:
 //
 //   * a row (one lattice vertex or one pixel, vd channels) is owned by a group of LPR lanes,
 //     each lane moving VEC=4 consecutive channels with one 16-byte global_load/store_dwordx4
@@ -17,8 +22,9 @@
 //   splat  vert[v] += w * src[p]   in ascending pixel order           (:236-238, :454-455)
 //   blur   2*(0.25*a + 0.5*s + 0.25*b), Jacobi per axis               (:526, :530-532)
 //   slice  col += w * vert / (1 + 2^-d) per term                      (:480)
-// so the device results are bit-identical to the CPU path wherever the summation order is
-// defined by the algorithm (which is everywhere: the splat lists are pixel-sorted).
+// so with PHL_FILTER_EXACT the device results are bit-identical to the CPU path (the splat lists
+// are pixel-sorted, so the summation order is the reference's everywhere).  Without the flag
+// slice uses fma + one final multiply by 1/(1+2^-d).
 #include <stdlib.h>
 
 #include <type_traits>
