@@ -8,6 +8,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <mutex>
 #include <vector>
 
 #include "phl_internal.h"
@@ -40,6 +41,54 @@ int grow(float **p, int64_t *cap, int64_t need)
     return PHL_OK;
 }
 }  // namespace
+
+// ---- cached scratch block for build temporaries -------------------------------------------------
+namespace {
+std::mutex g_scratch_mu;
+void *g_scratch = nullptr;
+size_t g_scratch_cap = 0;
+int g_scratch_dev = -1;
+bool g_scratch_busy = false;
+}  // namespace
+
+bool phl_scratch_acquire(void **base, size_t *cap)
+{
+    std::lock_guard<std::mutex> lk(g_scratch_mu);
+    if (g_scratch_busy) return false;
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
+    if (g_scratch && dev != g_scratch_dev) {   // lattices are being built on another device now
+        int prev = dev;
+        (void)hipSetDevice(g_scratch_dev);
+        (void)hipFree(g_scratch);
+        (void)hipSetDevice(prev);
+        g_scratch = nullptr;
+        g_scratch_cap = 0;
+    }
+    g_scratch_dev = dev;
+    g_scratch_busy = true;
+    *base = g_scratch;
+    *cap = g_scratch_cap;
+    return true;
+}
+
+void phl_scratch_release(size_t wanted)
+{
+    std::lock_guard<std::mutex> lk(g_scratch_mu);
+    g_scratch_busy = false;
+    static const size_t limit = [] {
+        const char *e = getenv("PHL_SCRATCH_MAX_MB");   // 0 disables the cache
+        return (size_t)(e ? atoll(e) : 4096) << 20;
+    }();
+    if (wanted > g_scratch_cap && wanted <= limit) {
+        if (g_scratch) (void)hipFree(g_scratch);
+        g_scratch = nullptr;
+        g_scratch_cap = 0;
+        const size_t want = wanted + (wanted >> 3);
+        if (hipMalloc(&g_scratch, want) == hipSuccess) g_scratch_cap = want;
+        else (void)hipGetLastError();
+    }
+}
 
 void phl_set_error(const char *fmt, ...)
 {
@@ -75,6 +124,22 @@ const char *phl_status_string(int s)
         case PHL_ERR_UNSUPPORTED: return "unsupported";
         default: return "unknown";
     }
+}
+
+int phl_trim_scratch(void)
+{
+    std::lock_guard<std::mutex> lk(g_scratch_mu);
+    if (g_scratch_busy) return PHL_OK;
+    if (g_scratch) {
+        int prev = -1;
+        (void)hipGetDevice(&prev);
+        (void)hipSetDevice(g_scratch_dev);
+        (void)hipFree(g_scratch);
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+    g_scratch = nullptr;
+    g_scratch_cap = 0;
+    return PHL_OK;
 }
 
 int phl_device_count(void)

@@ -34,7 +34,7 @@ __global__ __launch_bounds__(256) void k_sort_lists(const phl_contrib_t *__restr
     }
 }
 
-__global__ void k_fill_i32(int *p, int64_t n, int value)
+__attribute__((unused)) __global__ void k_fill_i32(int *p, int64_t n, int value)
 {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -130,17 +130,33 @@ int exclusive_scan(const int *in, int *out /* n+1 */, int n, int *tile_sums, hip
     return PHL_OK;
 }
 
+// Temporaries of one build phase.  Requests are carved out of a cached, grow-only device scratch
+// block (phl_scratch_*, phl_api.hip) so that a warm build performs no hipMalloc/hipFree for its
+// ~25 work arrays; whatever does not fit falls back to hipMalloc, and the block is re-sized to the
+// phase's total on release so the next build fits.
 struct temp_pool {
     std::vector<void *> ptrs;
+    char *base = nullptr;
+    size_t cap = 0, off = 0, wanted = 0;
+    bool have_cache = false;
+    temp_pool() { have_cache = phl_scratch_acquire((void **)&base, &cap); }
     ~temp_pool()
     {
         for (void *p : ptrs) (void)hipFree(p);
+        if (have_cache) phl_scratch_release(wanted);
     }
     template <typename T>
     hipError_t get(T **out, size_t count)
     {
+        const size_t bytes = (((count ? count : 1) * sizeof(T)) + 255) & ~(size_t)255;
+        wanted += bytes;
+        if (have_cache && off + bytes <= cap) {
+            *out = (T *)(base + off);
+            off += bytes;
+            return hipSuccess;
+        }
         void *p = nullptr;
-        hipError_t e = hipMalloc(&p, (count ? count : 1) * sizeof(T));
+        hipError_t e = hipMalloc(&p, bytes);
         if (e == hipSuccess) ptrs.push_back(p);
         *out = (T *)p;
         return e;

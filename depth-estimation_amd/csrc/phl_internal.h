@@ -75,6 +75,10 @@ int phl_hip_fail(hipError_t e, const char *what, const char *file, int line);
         if (e__ != hipSuccess) return phl_hip_fail(e__, #call, __FILE__, __LINE__); \
     } while (0)
 
+// cached device scratch for build temporaries (phl_api.hip); one user at a time per process
+bool phl_scratch_acquire(void **base, size_t *cap);
+void phl_scratch_release(size_t wanted_bytes);
+
 // ---- launchers implemented in phl_build.hip ----
 int phl_build_device(phl_lattice *lat, const float *ref, int64_t rs, int64_t cs, hipStream_t st);
 int phl_add_vertices_device(phl_lattice *lat, const int16_t *keys_host, int64_t count, int32_t *vid_host, hipStream_t st);

@@ -195,10 +195,6 @@ __global__ __launch_bounds__(256) void k_mark_sole(int *__restrict__ slot_vert, 
 // ---- hot kernels -----------------------------------------------------------------------------
 __device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
 __device__ __forceinline__ void st4(float *p, float4 v) { *reinterpret_cast<float4 *>(p) = v; }
-__device__ __forceinline__ float4 mac4(float4 acc, float w, float4 q)   // mul and add rounded separately (:455)
-{
-    return make_float4(acc.x + w * q.x, acc.y + w * q.y, acc.z + w * q.z, acc.w + w * q.w);
-}
 __device__ __forceinline__ float div_c(float t, float c, float rc)
 {
     float q = t * rc;
@@ -663,6 +659,11 @@ int phl_tiles_build(phl_lattice *lat, const float *ref, int64_t rs, int64_t cs, 
     int sortn = 512;
     while (sortn < P * dp1) sortn <<= 1;
 
+    int rc = PHL_OK;
+    int nchunks = 0;
+    int64_t S = 0;
+    const int64_t N = lat->N;
+    {   // temporaries of the chunk build go back to the scratch cache before the vertex lists are linked
     temp_pool tmp;
     // 1. feature ranges -> the two widest dimensions -> uniform grid with ~P pixels per cell
     constexpr int MMB = 256;
@@ -719,7 +720,7 @@ int phl_tiles_build(phl_lattice *lat, const float *ref, int64_t rs, int64_t cs, 
     hipLaunchKernelGGL(k_cell_ids, dim3(gn), dim3(256), 0, st, ref, rs, cs, (int64_t)n, da, db, lo[da],
                        db >= 0 ? lo[db] : 0.f, inv_t, nca, ncb, cell, ccnt);
     PHL_HIP(hipGetLastError());
-    int rc = exclusive_scan(ccnt, cptr, ncell, tile_sums, st);
+    rc = exclusive_scan(ccnt, cptr, ncell, tile_sums, st);
     if (rc) return rc;
     hipLaunchKernelGGL(k_group_fill, dim3(gn), dim3(256), 0, st, cell, cptr, ccur, n, gtmp);
     {
@@ -732,7 +733,7 @@ int phl_tiles_build(phl_lattice *lat, const float *ref, int64_t rs, int64_t cs, 
     PHL_HIP(hipGetLastError());
 
     // 3. per-chunk local vertex lists, segments and local indices
-    const int nchunks = (n + P - 1) / P;
+    nchunks = (n + P - 1) / P;
     lat->nchunks = nchunks;
     int *nv;
     PHL_HIP(tmp.get(&nv, (size_t)nchunks + 1));
@@ -751,7 +752,6 @@ int phl_tiles_build(phl_lattice *lat, const float *ref, int64_t rs, int64_t cs, 
     std::vector<int> nv_host((size_t)nchunks);
     PHL_HIP(hipMemcpyAsync(nv_host.data(), nv, sizeof(int) * (size_t)nchunks, hipMemcpyDeviceToHost, st));
     PHL_HIP(hipStreamSynchronize(st));
-    int64_t S = 0;
     int nv_max = 0;
     for (int v : nv_host) {
         S += v;
@@ -759,7 +759,6 @@ int phl_tiles_build(phl_lattice *lat, const float *ref, int64_t rs, int64_t cs, 
     }
     lat->S = S;
     lat->nv_max = nv_max;
-    const int64_t N = lat->N;
     PHL_HIP(hipMalloc((void **)&lat->slot_vert, sizeof(int) * ((size_t)S + 1)));
     PHL_HIP(hipMalloc((void **)&lat->seg_ptr, sizeof(int) * ((size_t)S + 1)));
     PHL_HIP(hipMalloc((void **)&lat->seg, sizeof(phl_contrib_t) * (size_t)N));
@@ -771,6 +770,7 @@ int phl_tiles_build(phl_lattice *lat, const float *ref, int64_t rs, int64_t cs, 
     const int Nint = (int)N;
     PHL_HIP(hipMemcpyAsync(lat->seg_ptr + S, &Nint, sizeof(int), hipMemcpyHostToDevice, st));
     PHL_HIP(hipStreamSynchronize(st));
+    }
     rc = phl_tiles_link_vertices(lat, st);
     if (rc) return rc;
     lat->tile_bytes = (int64_t)(sizeof(int) * ((size_t)n + nchunks + 1 + 3 * ((size_t)S + 1) + (size_t)lat->M + 1) +

@@ -93,6 +93,11 @@ int phl_device(const phl_lattice *lat);
 /* Device bytes held by the lattice (tables + value workspace). */
 int64_t phl_device_bytes(const phl_lattice *lat);
 
+/* phl_build keeps one grow-only device scratch block for its temporaries (so that building a
+ * lattice per video frame performs no hipMalloc for work arrays; PHL_SCRATCH_MAX_MB caps it,
+ * 0 disables).  phl_trim_scratch() gives the block back. */
+int phl_trim_scratch(void);
+
 /* ---- row-band multi-GPU support -------------------------------------------------------------
  * Append vertices that exist in a NEIGHBOURING row band of the same image ("ghost" vertices:
  * no local pixel splats into them) so that blur() sees the same neighbourhood it would see in
