@@ -47,7 +47,7 @@ struct phl_lattice {
     int32_t *chunk_vptr;    // [nchunks+1] slot range of each chunk
     int32_t *slot_vert;     // [S] vertex id (bit 31: this chunk is the vertex's only contributor)
     int32_t *slot_pidx;     // [S+1] row of the slot in the partial buffer (multi-chunk vertices)
-    int32_t *seg_ptr;       // [S+1] segment of each slot in seg[]
+    int2 *seg_rng;          // [S] {begin, end} of each slot's segment in seg[]
     phl_contrib_t *seg;     // [N] {pixel index inside the chunk, weight}, ascending pixel per slot
     unsigned short *lidx;   // [N] local vertex index per (chunk pixel, remainder)
     int32_t *vs_ptr;        // [M+1] slots of each vertex ...

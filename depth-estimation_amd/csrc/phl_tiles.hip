@@ -24,6 +24,7 @@
 // reference's pixel order (partial sums), hence results agree to fp32 rounding (~1e-7), not
 // bit for bit; PHL_FILTER_EXACT selects the pixel-ordered gather splat instead.
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 
 #include <type_traits>
@@ -105,7 +106,7 @@ template <int SORTN, bool WRITE>
 __global__ __launch_bounds__(256) void k_chunk_sort(const int *__restrict__ pix_order, int n, int P, int dp1,
                                                     const phl_replay_t *__restrict__ replay, int *__restrict__ nv_out,
                                                     const int *__restrict__ vptr, int *__restrict__ slot_vert,
-                                                    int *__restrict__ seg_ptr, phl_contrib_t *__restrict__ seg,
+                                                    int2 *__restrict__ seg_rng, phl_contrib_t *__restrict__ seg,
                                                     unsigned short *__restrict__ lidx)
 {
     __shared__ unsigned long long keys[SORTN];
@@ -150,8 +151,46 @@ __global__ __launch_bounds__(256) void k_chunk_sort(const int *__restrict__ pix_
         if (threadIdx.x == 0) nv_out[c] = total;
         return;
     }
+    // Local vertices are renumbered by DESCENDING segment length (counting sort in LDS): the
+    // splat kernel hands neighbouring local vertices to the lane groups of one wavefront, which
+    // then run loops of nearly equal length, and takes groups longest-first.
+    __shared__ int hpos[SORTN + 1];   // start position of the segment of vid-order vertex j
+    __shared__ int newidx[SORTN];     // vid-order index -> length-order index
+    __shared__ int lbin[258];         // histogram over segment lengths 1..P (P <= 256)
     const int vbase = vptr[c];
     const int64_t ebase = (int64_t)base * dp1;
+    for (int j = threadIdx.x; j < 258; j += 256) lbin[j] = 0;
+    {
+        int lj = li;
+#pragma unroll
+        for (int u = 0; u < PER; u++) {
+            const int i = i0 + u;
+            if (i < E && (i == 0 || (unsigned)(keys[i] >> 32) != (unsigned)(keys[i - 1] >> 32))) hpos[++lj] = i;
+        }
+    }
+    if (threadIdx.x == 0) hpos[total] = E;
+    __syncthreads();
+    for (int j = threadIdx.x; j < total; j += 256) atomicAdd(&lbin[256 - min(hpos[j + 1] - hpos[j], 256)], 1);   // bin 0 = longest
+    __syncthreads();
+    if (threadIdx.x < 64) {           // exclusive scan of the 257 bins by one wavefront
+        int carry = 0;
+        for (int b0 = 0; b0 < 257; b0 += 64) {
+            const int b = b0 + (int)threadIdx.x;
+            const int x = b < 257 ? lbin[b] : 0;
+            int incl = x;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int y = __shfl_up(incl, o);
+                if ((int)threadIdx.x >= o) incl += y;
+            }
+            if (b < 257) lbin[b] = carry + incl - x;
+            carry += __shfl(incl, 63);
+        }
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < total; j += 256)
+        newidx[j] = atomicAdd(&lbin[256 - min(hpos[j + 1] - hpos[j], 256)], 1);
+    __syncthreads();
 #pragma unroll
     for (int u = 0; u < PER; u++) {
         const int i = i0 + u;
@@ -161,8 +200,9 @@ __global__ __launch_bounds__(256) void k_chunk_sort(const int *__restrict__ pix_
         const bool head = (i == 0) || vid != (unsigned)(keys[i - 1] >> 32);
         if (head) {
             li++;
-            slot_vert[vbase + li] = (int)vid;
-            seg_ptr[vbase + li] = (int)(ebase + i);
+            const int slot = vbase + newidx[li];
+            slot_vert[slot] = (int)vid;
+            seg_rng[slot] = make_int2((int)(ebase + i), (int)(ebase + hpos[li + 1]));
         }
         const int k = e / dp1, r = e - k * dp1;
         const int p = pix_order[base + k];
@@ -170,7 +210,7 @@ __global__ __launch_bounds__(256) void k_chunk_sort(const int *__restrict__ pix_
         s.pixel = k;
         s.w = replay[(int64_t)p * dp1 + r].w;
         seg[ebase + i] = s;
-        lidx[ebase + e] = (unsigned short)li;
+        lidx[ebase + e] = (unsigned short)newidx[li];
     }
 }
 
@@ -212,31 +252,14 @@ __device__ __forceinline__ float4 fma4(float4 acc, float w, float4 v)
                        __builtin_fmaf(w, v.w, acc.w));
 }
 
-// x + (x of the lane 16 / 32 positions away): gfx950 VALU lane-swap instructions
-// (v_permlane16_swap swaps the odd 16-lane rows of its first operand with the even rows of the
-// second; v_permlane32_swap the upper half of the first with the lower half of the second), so
-// with both operands = x the two results are the two butterfly partners.
-__device__ __forceinline__ float xsum16(float x)
-{
-    const unsigned u = __float_as_uint(x);
-    const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
-    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
-}
-__device__ __forceinline__ float xsum32(float x)
-{
-    const unsigned u = __float_as_uint(x);
-    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
-}
-
 // One workgroup (TPB threads) per chunk.  LPRS lanes own one row of a channel slab of
 // SL = 4*LPRS floats.  LDS: [rows x SL] staged rows | per-entry {LDS byte offset, weight} |
 // chunk pixel ids | local segment pointers | destination of each local vertex.  Index data
 // is staged ONCE per chunk; inside the slab loop global memory is touched only for value rows,
 // and the rows of slab s+1 are prefetched into registers while slab s is being summed.
-// A wavefront owns one local vertex at a time; its 64/LPRS lane groups take every
-// (64/LPRS)-th entry of the vertex's segment and the group sums are combined with a fixed
-// xor-butterfly: a wavefront-level segmented reduction, deterministic, no atomics.
+// Each of a wavefront's 64/LPRS lane groups owns one local vertex and sums its pixel-sorted
+// segment sequentially out of LDS: a segmented reduction with one segment per lane group,
+// deterministic, no atomics (details at the loop).
 constexpr int TPB = 512;
 
 constexpr int TPB_S = 512;   // splat: more waves hide the LDS latency of the segmented sums
@@ -245,7 +268,7 @@ template <int LPRS>
 __global__ __launch_bounds__(TPB_S) void k_splat_tiled(const float *__restrict__ src, int64_t src_rs, int vd, int n, int P,
                                                      int dp1, int nv_cap, const int *__restrict__ pix_order,
                                                      const int *__restrict__ vptr, const int *__restrict__ slot_vert,
-                                                     const int *__restrict__ slot_pidx, const int *__restrict__ seg_ptr,
+                                                     const int *__restrict__ slot_pidx, const int2 *__restrict__ seg_rng,
                                                      const phl_contrib_t *__restrict__ seg, float *__restrict__ vert,
                                                      float *__restrict__ partial, int nchunks, int xcd_chunk)
 {
@@ -277,7 +300,7 @@ __global__ __launch_bounds__(TPB_S) void k_splat_tiled(const float *__restrict__
     }
     for (int k = threadIdx.x; k < cnt; k += TPB_S) pixl[k] = pix_order[base + k];
     for (int i = threadIdx.x; i < nv; i += TPB_S)
-        meta[i] = make_int4((int)(seg_ptr[vbase + i] - ebase), (int)(seg_ptr[vbase + i + 1] - ebase), slot_vert[vbase + i],
+        meta[i] = make_int4((int)(seg_rng[vbase + i].x - ebase), (int)(seg_rng[vbase + i].y - ebase), slot_vert[vbase + i],
                             slot_pidx[vbase + i]);
     if (threadIdx.x < 64) ctr[threadIdx.x] = NW;
     __syncthreads();
@@ -310,18 +333,24 @@ __global__ __launch_bounds__(TPB_S) void k_splat_tiled(const float *__restrict__
 #pragma unroll
             for (int u = 0; u < PF; u++) pf[u] = ld4(src + (int64_t)pixl[min(g + u * G, kclamp)] * src_rs + chnc);
         }
-        // waves take vertices from a shared counter: segment lengths vary from 1 to P, a static
-        // round-robin leaves waves idle at the barrier
+        // Each of the wavefront's Q lane groups sums ONE local vertex (its pixel-sorted segment,
+        // sequentially, out of LDS).  Local vertices are numbered by descending segment length
+        // (k_chunk_sort), so the Q vertices of a group have nearly equal loops, and the waves take
+        // groups longest-first from a shared counter: no cross-lane combine, no padding, and the
+        // per-vertex bookkeeping is paid once per Q vertices.
         int *slab_ctr = ctr + (c0 / SL);
-        for (int i = wave; i < nv;) {
-            const int4 m = meta[i];
+        const int ngroups = (nv + Q - 1) / Q;
+        for (int gi = wave; gi < ngroups;) {
+            const int i = gi * Q + q;
+            int4 m = make_int4(0, 0, 0, 0);
+            if (i < nv) m = meta[i];
             int nxt = 0;
-            if (lane == 0) nxt = atomicAdd(slab_ctr, 1);       // next vertex, fetched under this one's work
+            if (lane == 0) nxt = atomicAdd(slab_ctr, 1);       // next group, fetched under this one's work
             const int s1 = m.y;
             float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-            int s = m.x + q;
-            for (; s + 3 * Q < s1; s += 4 * Q) {
-                const uint2 e0 = ent[s], e1 = ent[s + Q], e2 = ent[s + 2 * Q], e3 = ent[s + 3 * Q];
+            int s = m.x;
+            for (; s + 4 <= s1; s += 4) {
+                const uint2 e0 = ent[s], e1 = ent[s + 1], e2 = ent[s + 2], e3 = ent[s + 3];
                 const float4 q0 = *reinterpret_cast<const float4 *>(rbase + e0.x);
                 const float4 q1 = *reinterpret_cast<const float4 *>(rbase + e1.x);
                 const float4 q2 = *reinterpret_cast<const float4 *>(rbase + e2.x);
@@ -331,36 +360,15 @@ __global__ __launch_bounds__(TPB_S) void k_splat_tiled(const float *__restrict__
                 acc = fma4(acc, __uint_as_float(e2.y), q2);
                 acc = fma4(acc, __uint_as_float(e3.y), q3);
             }
-            {   // tail (< 4 entries per lane group) as ONE padded batch: out-of-range slots re-read
-                // the segment's last entry with weight 0, which adds exactly nothing
-                uint2 e[3];
-#pragma unroll
-                for (int u = 0; u < 3; u++) {
-                    const int idx = s + u * Q;
-                    e[u] = ent[min(idx, s1 - 1)];
-                    if (idx >= s1) e[u].y = 0u;
-                }
-                float4 r[3];
-#pragma unroll
-                for (int u = 0; u < 3; u++) r[u] = *reinterpret_cast<const float4 *>(rbase + e[u].x);
-#pragma unroll
-                for (int u = 0; u < 3; u++) acc = fma4(acc, __uint_as_float(e[u].y), r[u]);
+            for (; s < s1; s++) {
+                const uint2 e0 = ent[s];
+                acc = fma4(acc, __uint_as_float(e0.y), *reinterpret_cast<const float4 *>(rbase + e0.x));
             }
-            // combine the lane groups' sums with a fixed butterfly (VALU lane swaps, no LDS)
-            if (LPRS <= 16) { acc.x = xsum16(acc.x); acc.y = xsum16(acc.y); acc.z = xsum16(acc.z); acc.w = xsum16(acc.w); }
-            if (LPRS <= 32) { acc.x = xsum32(acc.x); acc.y = xsum32(acc.y); acc.z = xsum32(acc.z); acc.w = xsum32(acc.w); }
-#pragma unroll
-            for (int off = LPRS; off < 16; off <<= 1) {    // narrow slabs (< 16 lanes per row): in-row shuffles
-                acc.x += __shfl_xor(acc.x, off);
-                acc.y += __shfl_xor(acc.y, off);
-                acc.z += __shfl_xor(acc.z, off);
-                acc.w += __shfl_xor(acc.w, off);
-            }
-            if (q == 0 && chok) {
+            if (i < nv && chok) {
                 float *dst = m.z < 0 ? vert + (int64_t)(m.z & 0x7FFFFFFF) * vd : partial + (int64_t)m.w * vd;
                 st4(dst + ch, acc);
             }
-            i = __builtin_amdgcn_readfirstlane(nxt);
+            gi = __builtin_amdgcn_readfirstlane(nxt);
         }
         __syncthreads();                   // everyone is done reading this slab
         if (more) {
@@ -547,10 +555,16 @@ inline int pick_lprs(int vd, int rows, int64_t extra)
 }
 
 template <typename K>
-inline int allow_lds(K kernel, size_t bytes)
+inline int allow_lds(K kernel, size_t bytes, int threads = 512)
 {
-    if (bytes <= 64 * 1024) return PHL_OK;
-    PHL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    if (bytes > 64 * 1024)
+        PHL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    static const bool dbg = getenv("PHL_DEBUG") != nullptr;
+    if (dbg) {
+        int nb = -1;
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(kernel), threads, bytes);
+        fprintf(stderr, "[phl] chunk kernel: %d threads, %zu B LDS -> %d workgroups per CU (occupancy API)\n", threads, bytes, nb);
+    }
     return PHL_OK;
 }
 
@@ -578,11 +592,12 @@ inline int pick_lpr_row(int vd)
 // ------------------------------------------------------------------------------------------------
 int phl_tiles_free(phl_lattice *lat)
 {
-    void *ptrs[] = {lat->pix_order, lat->chunk_vptr, lat->slot_vert, lat->slot_pidx, lat->seg_ptr, lat->seg,
+    void *ptrs[] = {lat->pix_order, lat->chunk_vptr, lat->slot_vert, lat->slot_pidx, lat->seg_rng, lat->seg,
                     lat->lidx, lat->vs_ptr, lat->vs, lat->partial};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
-    lat->pix_order = lat->chunk_vptr = lat->slot_vert = lat->slot_pidx = lat->seg_ptr = lat->vs_ptr = nullptr;
+    lat->pix_order = lat->chunk_vptr = lat->slot_vert = lat->slot_pidx = lat->vs_ptr = nullptr;
+    lat->seg_rng = nullptr;
     lat->seg = lat->vs = nullptr;
     lat->lidx = nullptr;
     lat->partial = nullptr;
@@ -654,6 +669,10 @@ int phl_tiles_build(phl_lattice *lat, const float *ref, int64_t rs, int64_t cs, 
     int P = 2048 / dp1;
     if (P > 256) P = 256;
     P &= ~15;
+    if (const char *e = getenv("PHL_TILE_P")) {   // experiments: smaller chunks leave LDS headroom
+        const int v = atoi(e) & ~15;
+        if (v >= 16 && v <= P) P = v;
+    }
     lat->P = P;
     if (n == 0) return phl_tiles_link_vertices(lat, st);
     int sortn = 512;
@@ -744,7 +763,7 @@ int phl_tiles_build(phl_lattice *lat, const float *ref, int64_t rs, int64_t cs, 
         case 1024: hipLaunchKernelGGL((k_chunk_sort<1024, WRITE_>), dim3(nchunks), dim3(256), 0, st, __VA_ARGS__); break; \
         default: hipLaunchKernelGGL((k_chunk_sort<2048, WRITE_>), dim3(nchunks), dim3(256), 0, st, __VA_ARGS__); break;   \
     }
-    PHL_CHUNK_SORT(false, lat->pix_order, n, P, dp1, lat->replay, nv, (const int *)nullptr, (int *)nullptr, (int *)nullptr,
+    PHL_CHUNK_SORT(false, lat->pix_order, n, P, dp1, lat->replay, nv, (const int *)nullptr, (int *)nullptr, (int2 *)nullptr,
                    (phl_contrib_t *)nullptr, (unsigned short *)nullptr)
     PHL_HIP(hipGetLastError());
     rc = exclusive_scan(nv, lat->chunk_vptr, nchunks, tile_sums, st);
@@ -760,15 +779,13 @@ int phl_tiles_build(phl_lattice *lat, const float *ref, int64_t rs, int64_t cs, 
     lat->S = S;
     lat->nv_max = nv_max;
     PHL_HIP(hipMalloc((void **)&lat->slot_vert, sizeof(int) * ((size_t)S + 1)));
-    PHL_HIP(hipMalloc((void **)&lat->seg_ptr, sizeof(int) * ((size_t)S + 1)));
+    PHL_HIP(hipMalloc((void **)&lat->seg_rng, sizeof(int2) * ((size_t)S + 1)));
     PHL_HIP(hipMalloc((void **)&lat->seg, sizeof(phl_contrib_t) * (size_t)N));
     PHL_HIP(hipMalloc((void **)&lat->lidx, sizeof(unsigned short) * (size_t)N));
     PHL_CHUNK_SORT(true, lat->pix_order, n, P, dp1, lat->replay, (int *)nullptr, lat->chunk_vptr, lat->slot_vert,
-                   lat->seg_ptr, lat->seg, lat->lidx)
+                   lat->seg_rng, lat->seg, lat->lidx)
 #undef PHL_CHUNK_SORT
     PHL_HIP(hipGetLastError());
-    const int Nint = (int)N;
-    PHL_HIP(hipMemcpyAsync(lat->seg_ptr + S, &Nint, sizeof(int), hipMemcpyHostToDevice, st));
     PHL_HIP(hipStreamSynchronize(st));
     }
     rc = phl_tiles_link_vertices(lat, st);
@@ -818,7 +835,7 @@ int phl_launch_splat_tiled(phl_lattice *lat, const float *src, int64_t src_rs, i
         if ((rc = allow_lds(k_splat_tiled<LPRS>, lds)) != PHL_OK) return;
         k_splat_tiled<LPRS><<<dim3(cgrid), dim3(TPB_S), lds, st>>>(
             src, src_rs, vd, (int)lat->n, lat->P, lat->d + 1, lat->nv_max, lat->pix_order, lat->chunk_vptr, lat->slot_vert,
-            lat->slot_pidx, lat->seg_ptr, lat->seg, vert, lat->partial, lat->nchunks, xcd_chunk);
+            lat->slot_pidx, lat->seg_rng, lat->seg, vert, lat->partial, lat->nchunks, xcd_chunk);
     });
     if (rc) return rc;
     const int lpr = pick_lpr_row(vd);
