@@ -349,8 +349,23 @@ __global__ __launch_bounds__(TPB_S) void k_splat_tiled(const float *__restrict__
             const int s1 = m.y;
             float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
             int s = m.x;
-            for (; s + 4 <= s1; s += 4) {
-                const uint2 e0 = ent[s], e1 = ent[s + 1], e2 = ent[s + 2], e3 = ent[s + 3];
+            // software pipeline: the index reads of batch b+1 are issued before the row reads of
+            // batch b are consumed, so a batch costs one LDS round trip instead of two (LDS returns
+            // in order: waiting for the rows leaves the next indices in flight)
+            if (s + 4 <= s1) {
+                uint2 e0 = ent[s], e1 = ent[s + 1], e2 = ent[s + 2], e3 = ent[s + 3];
+                for (; s + 8 <= s1; s += 4) {
+                    const float4 q0 = *reinterpret_cast<const float4 *>(rbase + e0.x);
+                    const float4 q1 = *reinterpret_cast<const float4 *>(rbase + e1.x);
+                    const float4 q2 = *reinterpret_cast<const float4 *>(rbase + e2.x);
+                    const float4 q3 = *reinterpret_cast<const float4 *>(rbase + e3.x);
+                    const uint2 n0 = ent[s + 4], n1 = ent[s + 5], n2 = ent[s + 6], n3 = ent[s + 7];
+                    acc = fma4(acc, __uint_as_float(e0.y), q0);
+                    acc = fma4(acc, __uint_as_float(e1.y), q1);
+                    acc = fma4(acc, __uint_as_float(e2.y), q2);
+                    acc = fma4(acc, __uint_as_float(e3.y), q3);
+                    e0 = n0; e1 = n1; e2 = n2; e3 = n3;
+                }
                 const float4 q0 = *reinterpret_cast<const float4 *>(rbase + e0.x);
                 const float4 q1 = *reinterpret_cast<const float4 *>(rbase + e1.x);
                 const float4 q2 = *reinterpret_cast<const float4 *>(rbase + e2.x);
@@ -359,6 +374,7 @@ __global__ __launch_bounds__(TPB_S) void k_splat_tiled(const float *__restrict__
                 acc = fma4(acc, __uint_as_float(e1.y), q1);
                 acc = fma4(acc, __uint_as_float(e2.y), q2);
                 acc = fma4(acc, __uint_as_float(e3.y), q3);
+                s += 4;
             }
             for (; s < s1; s++) {
                 const uint2 e0 = ent[s];
