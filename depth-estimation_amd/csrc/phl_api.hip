@@ -399,6 +399,8 @@ int phl_get_splat_lists(phl_lattice *lat, int32_t *ptr, int32_t *pixel, float *w
     if (!lat || !ptr || !pixel || !w) { phl_set_error("phl_get_splat_lists: bad arguments"); return PHL_ERR_INVALID; }
     if (lat->N == 0) { ptr[0] = 0; return PHL_OK; }
     device_guard g(lat->device);
+    const int rc = phl_ensure_csr(lat, nullptr);
+    if (rc) return rc;
     std::vector<phl_contrib_t> h((size_t)lat->N);
     PHL_HIP(hipDeviceSynchronize());
     PHL_HIP(hipMemcpy(ptr, lat->csr_ptr, sizeof(int32_t) * ((size_t)lat->M + 1), hipMemcpyDeviceToHost));

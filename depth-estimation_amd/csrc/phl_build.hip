@@ -8,13 +8,14 @@
 //   elevate    per pixel: elevate to H_d, nearest remainder-0 point, rank, barycentric
 //              weights -> d+1 candidate keys (int16[d]) + weights            (:380-447)
 //   insert     lock-free open addressing: slot <- atomicCAS(EMPTY, e), equal keys fold to the
-//              MINIMUM candidate index with atomicMin  => deterministic representative
+//              MINIMUM candidate index with atomicMin  => deterministic representative;
+//              runs of equal keys along a wavefront (neighbouring pixels) probe once
 //   flag+scan  representative candidates, exclusive scan => vertex id = first-touch rank,
 //              i.e. exactly the reference's insertion order                   (:70-77)
 //   assign     vertex keys [M][d]; table now maps key -> vertex id
-//   count/scan/fill/sort   transpose of the replay matrix: per vertex the (pixel, weight)
-//              list in ascending pixel order, so that splat is a deterministic segmented
-//              sum with the reference's own accumulation order (no float atomics)
+//   (on demand) count/scan/fill/sort   transpose of the replay matrix: per vertex the (pixel,
+//              weight) list in ascending pixel order for the reference-exact gather splat
+//              (phl_ensure_csr); the default chunk kernels do not need it
 //   neighbors  [d+1][M][2] blur neighbour ids, -1 where the vertex does not exist (:516-522)
 //
 // The whole translation unit is compiled with -ffp-contract=off: elevate must round exactly
@@ -137,30 +138,58 @@ __device__ __forceinline__ uint32_t mix_end(uint32_t h)
 
 // One thread per candidate (pixel, remainder).  table[slot] ends up holding the SMALLEST
 // candidate index among all candidates with that key.  ckeys was written by the previous
-// launch, and the index read back from the atomic is always a candidate with an equal-or-
-// different key that is fully written, so no in-kernel hand-off of plain data is needed.
-__global__ __launch_bounds__(256) void k_insert(const int16_t *__restrict__ ckeys, int d, int N, int *table,
+// launch, and the index read back from the atomic is always a candidate whose key is fully
+// written, so no in-kernel hand-off of plain data is needed.
+__global__ __launch_bounds__(256) void k_insert(const int16_t *__restrict__ ckeys, int d, int n, int *table,
                                                 uint32_t mask, int *__restrict__ slot_of)
 {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= N) return;
+    // A wavefront takes 64 CONSECUTIVE pixels of ONE remainder: neighbouring pixels mostly lie
+    // in the same simplex, so the same key repeats along the lanes and only the first lane of
+    // each run probes the table (its candidate index is the smallest of the run, which is what
+    // the atomicMin wants anyway).
+    const int dp1 = d + 1;
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int r = (int)(wave % dp1);
+    const int64_t p = (wave / dp1) * 64 + lane;
+    const bool active = p < n;
+    const int e = (int)((active ? p : (int64_t)n - 1) * dp1 + r);
     const int16_t *key = ckeys + (int64_t)e * d;
     uint32_t h = mix_begin();
     for (int i = 0; i < d; i++) h = mix_step(h, key[i]);
-    h = mix_end(h) & mask;
-    for (;;) {
-        int prev = atomicCAS(&table[h], PHL_EMPTY, e);
-        if (prev == PHL_EMPTY) break;
-        const int16_t *other = ckeys + (int64_t)prev * d;
-        bool same = true;
-        for (int i = 0; i < d; i++) same &= (other[i] == key[i]);
-        if (same) {
-            if (e < prev) atomicMin(&table[h], e);
-            break;
+    h = mix_end(h);
+    // same key as the previous lane?  (hash first, then the key itself)
+    bool same_prev = false;
+    {
+        const uint32_t hp = (uint32_t)__shfl_up((int)h, 1);
+        if (active && lane > 0 && hp == h) {
+            const int16_t *pk = ckeys + (int64_t)(e - dp1) * d;
+            same_prev = true;
+            for (int i = 0; i < d; i++) same_prev &= (pk[i] == key[i]);
         }
-        h = (h + 1) & mask;
     }
-    slot_of[e] = (int)h;
+    const unsigned long long heads = __ballot(active && !same_prev);
+    const unsigned long long below = heads & ((lane == 63) ? ~0ull : ((2ull << lane) - 1ull));
+    const int head_lane = 63 - __clzll(below ? below : 1ull);
+    int slot = 0;
+    if (active && lane == head_lane) {
+        h &= mask;
+        for (;;) {
+            int prev = atomicCAS(&table[h], PHL_EMPTY, e);
+            if (prev == PHL_EMPTY) break;
+            const int16_t *other = ckeys + (int64_t)prev * d;
+            bool same = true;
+            for (int i = 0; i < d; i++) same &= (other[i] == key[i]);
+            if (same) {
+                if (e < prev) atomicMin(&table[h], e);
+                break;
+            }
+            h = (h + 1) & mask;
+        }
+        slot = (int)h;
+    }
+    slot = __shfl(slot, head_lane);
+    if (active) slot_of[e] = slot;
 }
 
 __global__ __launch_bounds__(256) void k_flag(const int *__restrict__ table, const int *__restrict__ slot_of, int N,
@@ -182,14 +211,18 @@ __global__ __launch_bounds__(256) void k_assign(const int *__restrict__ flag, co
     table[slot_of[e]] = -(vid + 1);
 }
 
-__global__ __launch_bounds__(256) void k_count(const int *__restrict__ table, const int *__restrict__ slot_of, int N,
-                                               phl_replay_t *__restrict__ replay, int *cnt)
+__global__ __launch_bounds__(256) void k_set_vid(const int *__restrict__ table, const int *__restrict__ slot_of, int N,
+                                                 phl_replay_t *__restrict__ replay)
 {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= N) return;
-    const int vid = -(table[slot_of[e]] + 1);
-    replay[e].vid = vid;
-    atomicAdd(&cnt[vid], 1);
+    replay[e].vid = -(table[slot_of[e]] + 1);
+}
+
+__global__ __launch_bounds__(256) void k_count_vid(const phl_replay_t *__restrict__ replay, int N, int *cnt)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < N) atomicAdd(&cnt[replay[e].vid], 1);
 }
 
 __global__ __launch_bounds__(256) void k_fill(const phl_replay_t *__restrict__ replay, const int *__restrict__ ptr,
@@ -356,8 +389,7 @@ int phl_build_device(phl_lattice *lat, const float *ref, int64_t rs, int64_t cs,
 
     temp_pool tmp;
     int16_t *ckeys;
-    int *table, *slot_of, *flag, *rankv, *tile_sums, *err, *cursor;
-    phl_contrib_t *csr_tmp;
+    int *table, *slot_of, *flag, *rankv, *tile_sums, *err;
     PHL_HIP(tmp.get(&ckeys, (size_t)N * d));
     PHL_HIP(tmp.get(&table, cap));
     PHL_HIP(tmp.get(&slot_of, (size_t)N));
@@ -377,7 +409,10 @@ int phl_build_device(phl_lattice *lat, const float *ref, int64_t rs, int64_t cs,
     }
     const unsigned gN = (unsigned)((N + 255) / 256);
     hipLaunchKernelGGL(k_fill_i32, dim3(2048), dim3(256), 0, st, table, (int64_t)cap, PHL_EMPTY);
-    hipLaunchKernelGGL(k_insert, dim3(gN), dim3(256), 0, st, ckeys, d, N, table, mask, slot_of);
+    {
+        const int64_t waves = ((n + 63) / 64) * (d + 1);
+        hipLaunchKernelGGL(k_insert, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, ckeys, d, (int)n, table, mask, slot_of);
+    }
     hipLaunchKernelGGL(k_flag, dim3(gN), dim3(256), 0, st, table, slot_of, N, flag);
     PHL_HIP(hipGetLastError());
     int rc = exclusive_scan(flag, rankv, N, tile_sums, st);
@@ -396,33 +431,56 @@ int phl_build_device(phl_lattice *lat, const float *ref, int64_t rs, int64_t cs,
     lat->M = M;
 
     PHL_HIP(hipMalloc((void **)&lat->vkeys, sizeof(int16_t) * (size_t)M * d));
-    PHL_HIP(hipMalloc((void **)&lat->csr_ptr, sizeof(int32_t) * ((size_t)M + 1)));
-    PHL_HIP(hipMalloc((void **)&lat->csr, sizeof(phl_contrib_t) * (size_t)N));
-    PHL_HIP(tmp.get(&cursor, (size_t)M * 2));  // cnt | cursor
-    PHL_HIP(tmp.get(&csr_tmp, (size_t)N));
-    int *cnt = cursor + M;
-    PHL_HIP(hipMemsetAsync(cursor, 0, sizeof(int) * (size_t)M * 2, st));
-
     hipLaunchKernelGGL(k_assign, dim3(gN), dim3(256), 0, st, flag, rankv, slot_of, ckeys, d, N, table, lat->vkeys);
-    hipLaunchKernelGGL(k_count, dim3(gN), dim3(256), 0, st, table, slot_of, N, lat->replay, cnt);
+    hipLaunchKernelGGL(k_set_vid, dim3(gN), dim3(256), 0, st, table, slot_of, N, lat->replay);
     PHL_HIP(hipGetLastError());
-    rc = exclusive_scan(cnt, lat->csr_ptr, M, tile_sums, st);
-    if (rc) return rc;
-    hipLaunchKernelGGL(k_fill, dim3(gN), dim3(256), 0, st, lat->replay, lat->csr_ptr, cursor, N, d + 1, csr_tmp);
-    {
-        const int waves_needed = M;
-        int blocks = (waves_needed + 3) / 4;
-        if (blocks > 256 * 16) blocks = 256 * 16;
-        hipLaunchKernelGGL(k_sort_lists, dim3(blocks), dim3(256), 0, st, csr_tmp, lat->csr_ptr, M, lat->csr);
-    }
     lat->M_local = M;
     rc = phl_rebuild_table_and_neighbors(lat, st);
     if (rc) return rc;
     PHL_HIP(hipGetLastError());
     PHL_HIP(hipStreamSynchronize(st));  // temporaries are freed on return
-    lat->table_bytes = (int64_t)(sizeof(int16_t) * (size_t)M * d + sizeof(int32_t) * ((size_t)M + 1) +
-                                 sizeof(phl_contrib_t) * (size_t)N + sizeof(phl_replay_t) * (size_t)N +
+    lat->table_bytes = (int64_t)(sizeof(int16_t) * (size_t)M * d + sizeof(phl_replay_t) * (size_t)N +
                                  sizeof(int32_t) * (size_t)M * (d + 1) * 2 + sizeof(int) * ((size_t)lat->table_mask + 1));
+    return PHL_OK;
+}
+
+// Pixel-sorted contribution lists per vertex (the transpose of `replay`).  Only the
+// reference-exact gather splat (PHL_FILTER_EXACT / fallback shapes) and the introspection calls
+// need them, so they are built on first use, from `replay` alone.
+int phl_ensure_csr(phl_lattice *lat, hipStream_t st)
+{
+    if (lat->csr_ptr && lat->csr) return PHL_OK;
+    const int M = (int)lat->M, N = (int)lat->N, dp1 = lat->d + 1;
+    if (lat->csr_ptr) PHL_HIP(hipFree(lat->csr_ptr));
+    if (lat->csr) PHL_HIP(hipFree(lat->csr));
+    lat->csr_ptr = nullptr;
+    lat->csr = nullptr;
+    PHL_HIP(hipMalloc((void **)&lat->csr_ptr, sizeof(int32_t) * ((size_t)M + 1)));
+    PHL_HIP(hipMalloc((void **)&lat->csr, sizeof(phl_contrib_t) * (size_t)(N ? N : 1)));
+    if (N == 0 || M == 0) {
+        PHL_HIP(hipMemsetAsync(lat->csr_ptr, 0, sizeof(int32_t) * ((size_t)M + 1), st));
+        PHL_HIP(hipStreamSynchronize(st));
+        return PHL_OK;
+    }
+    temp_pool tmp;
+    int *cursor, *tile_sums;
+    phl_contrib_t *csr_tmp;
+    PHL_HIP(tmp.get(&cursor, (size_t)M * 2));  // cursor | cnt
+    PHL_HIP(tmp.get(&csr_tmp, (size_t)N));
+    PHL_HIP(tmp.get(&tile_sums, (size_t)M / SCAN_TILE + 2));
+    int *cnt = cursor + M;
+    PHL_HIP(hipMemsetAsync(cursor, 0, sizeof(int) * (size_t)M * 2, st));
+    const unsigned gN = (unsigned)((N + 255) / 256);
+    hipLaunchKernelGGL(k_count_vid, dim3(gN), dim3(256), 0, st, lat->replay, N, cnt);
+    PHL_HIP(hipGetLastError());
+    int rc = exclusive_scan(cnt, lat->csr_ptr, M, tile_sums, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_fill, dim3(gN), dim3(256), 0, st, lat->replay, lat->csr_ptr, cursor, N, dp1, csr_tmp);
+    int blocks = (M + 3) / 4;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(k_sort_lists, dim3(blocks), dim3(256), 0, st, csr_tmp, lat->csr_ptr, M, lat->csr);
+    PHL_HIP(hipGetLastError());
+    PHL_HIP(hipStreamSynchronize(st));  // temporaries go back to the scratch cache
     return PHL_OK;
 }
 
@@ -455,23 +513,21 @@ int phl_add_vertices_device(phl_lattice *lat, const int16_t *keys_host, int64_t 
     if (n_new > 0) {
         const int M_new = M_old + n_new;
         int16_t *vkeys_new;
-        int32_t *ptr_new;
         PHL_HIP(hipMalloc((void **)&vkeys_new, sizeof(int16_t) * (size_t)M_new * d));
-        PHL_HIP(hipMalloc((void **)&ptr_new, sizeof(int32_t) * ((size_t)M_new + 1)));
         if (M_old > 0)
             PHL_HIP(hipMemcpyAsync(vkeys_new, lat->vkeys, sizeof(int16_t) * (size_t)M_old * d, hipMemcpyDeviceToDevice, st));
-        if (lat->csr_ptr)
-            PHL_HIP(hipMemcpyAsync(ptr_new, lat->csr_ptr, sizeof(int32_t) * ((size_t)M_old + 1), hipMemcpyDeviceToDevice, st));
-        // ghosts have empty contribution lists: ptr[v] = N for all new v
-        hipLaunchKernelGGL(k_fill_i32, dim3(64), dim3(256), 0, st, ptr_new + M_old, (int64_t)n_new + 1, (int)lat->N);
         hipLaunchKernelGGL(k_append_missing, dim3((K + 255) / 256), dim3(256), 0, st, qkeys, d, K, mrank, M_old, vkeys_new,
                            vid);
         PHL_HIP(hipGetLastError());
         PHL_HIP(hipStreamSynchronize(st));
         if (lat->vkeys) PHL_HIP(hipFree(lat->vkeys));
+        // the per-vertex contribution lists are indexed by M: drop them, they are rebuilt on demand
+        // (ghosts get empty lists)
         if (lat->csr_ptr) PHL_HIP(hipFree(lat->csr_ptr));
+        if (lat->csr) PHL_HIP(hipFree(lat->csr));
+        lat->csr_ptr = nullptr;
+        lat->csr = nullptr;
         lat->vkeys = vkeys_new;
-        lat->csr_ptr = ptr_new;
         lat->M = M_new;
         rc = phl_rebuild_table_and_neighbors(lat, st);
         if (rc) return rc;

@@ -34,6 +34,38 @@ __global__ __launch_bounds__(256) void k_sort_lists(const phl_contrib_t *__restr
     }
 }
 
+// Run aggregation for atomics whose keys repeat in CONSECUTIVE lanes (neighbouring pixels hit the
+// same lattice vertex / grid cell): only the first lane of a run touches memory.
+// head_of_run: lane index of the first lane of my run; run_len (valid on head lanes): its length.
+__device__ __forceinline__ void wave_runs(int key, bool active, int *head_lane, int *run_len)
+{
+    const int lane = threadIdx.x & 63;
+    const int prev = __shfl_up(key, 1);
+    const bool prev_active = __shfl_up((int)active, 1) != 0;
+    const bool head = active && (lane == 0 || !prev_active || prev != key);
+    const unsigned long long heads = __ballot(head);
+    const unsigned long long act = __ballot(active);
+    const unsigned long long below = heads & ((lane == 63) ? ~0ull : ((2ull << lane) - 1ull));
+    *head_lane = 63 - __clzll(below ? below : 1ull);
+    // end of run = next head above me, or the end of the active lanes
+    const unsigned long long above = (lane == 63) ? 0ull : (heads >> (lane + 1));
+    const int next_head = above ? lane + 1 + __ffsll((long long)above) - 1 : 64;
+    const int last_active = act ? 64 - __clzll(act) : 0;   // one past the highest active lane
+    *run_len = min(next_head, last_active) - lane;
+}
+
+// counters[key] += (run length); returns the value before the add plus my rank inside the run
+__device__ __forceinline__ int run_atomic_add(int *counters, int key, bool active)
+{
+    int head_lane, run_len;
+    wave_runs(key, active, &head_lane, &run_len);
+    const int lane = threadIdx.x & 63;
+    int base = 0;
+    if (active && lane == head_lane) base = atomicAdd(&counters[key], run_len);
+    base = __shfl(base, head_lane);
+    return base + (lane - head_lane);
+}
+
 __attribute__((unused)) __global__ void k_fill_i32(int *p, int64_t n, int value)
 {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;

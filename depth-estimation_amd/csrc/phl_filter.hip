@@ -301,10 +301,12 @@ inline void dispatch_lpr(int lpr, F &&f)
 
 }  // namespace
 
-int phl_launch_splat(const phl_lattice *lat, const float *src, int64_t src_rs, int vd, float *vert, hipStream_t st)
+int phl_launch_splat(phl_lattice *lat, const float *src, int64_t src_rs, int vd, float *vert, hipStream_t st)
 {
     const int M = (int)lat->M;
     if (M == 0 || vd == 0) return PHL_OK;
+    const int rc_csr = phl_ensure_csr(lat, st);
+    if (rc_csr) return rc_csr;
     const bool v4 = (vd % 4 == 0) && (src_rs % 4 == 0) && aligned16(src) && aligned16(vert);
     const int lpr = pick_lpr(vd, v4 ? 4 : 1);
     const unsigned grid = grid_for(M, 64 / lpr);

@@ -81,6 +81,7 @@ void phl_scratch_release(size_t wanted_bytes);
 
 // ---- launchers implemented in phl_build.hip ----
 int phl_build_device(phl_lattice *lat, const float *ref, int64_t rs, int64_t cs, hipStream_t st);
+int phl_ensure_csr(phl_lattice *lat, hipStream_t st);  // pixel-sorted lists, built on first use
 int phl_add_vertices_device(phl_lattice *lat, const int16_t *keys_host, int64_t count, int32_t *vid_host, hipStream_t st);
 
 // ---- implemented in phl_tiles.hip ----
@@ -94,7 +95,7 @@ int phl_launch_slice_tiled(const phl_lattice *lat, const float *vert, int vd, fl
                            int64_t sub_rs, unsigned flags, hipStream_t st);
 
 // ---- launchers implemented in phl_filter.hip ----
-int phl_launch_splat(const phl_lattice *lat, const float *src, int64_t src_rs, int vd, float *vert, hipStream_t st);
+int phl_launch_splat(phl_lattice *lat, const float *src, int64_t src_rs, int vd, float *vert, hipStream_t st);
 int phl_launch_blur(const phl_lattice *lat, int axis, const float *vin, float *vout, int vd, hipStream_t st);
 int phl_launch_slice(const phl_lattice *lat, const float *vert, int vd, float *out, int64_t out_rs,
                      const float *sub, int64_t sub_rs, unsigned flags, hipStream_t st);

@@ -67,29 +67,32 @@ __global__ __launch_bounds__(256) void k_cell_ids(const float *__restrict__ ref,
                                                   int *__restrict__ cell, int *cnt)
 {
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= n) return;
-    int ca = (int)((ref[p * rs + da * cs] - lo_a) * inv_t);
+    const bool active = p < n;
+    const int64_t pc = active ? p : n - 1;
+    int ca = (int)((ref[pc * rs + da * cs] - lo_a) * inv_t);
     ca = min(max(ca, 0), nca - 1);
     int cb = 0;
     if (db >= 0) {
-        cb = (int)((ref[p * rs + db * cs] - lo_b) * inv_t);
+        cb = (int)((ref[pc * rs + db * cs] - lo_b) * inv_t);
         cb = min(max(cb, 0), ncb - 1);
     }
     const int c = cb * nca + ca;   // the wider dimension runs fastest inside a row of cells
-    cell[p] = c;
-    atomicAdd(&cnt[c], 1);
+    if (active) cell[p] = c;
+    (void)run_atomic_add(cnt, c, active);   // consecutive pixels mostly share a cell: one atomic per run
 }
 
 __global__ __launch_bounds__(256) void k_group_fill(const int *__restrict__ key, const int *__restrict__ ptr, int *cursor,
                                                     int n, phl_contrib_t *__restrict__ tmp)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const int k = key[i];
+    const bool active = i < n;
+    const int k = key[active ? i : n - 1] & 0x7FFFFFFF;
+    const int off = run_atomic_add(cursor, k, active);
+    if (!active) return;
     phl_contrib_t c;
     c.pixel = i;
     c.w = 0.f;
-    tmp[ptr[k] + atomicAdd(&cursor[k], 1)] = c;
+    tmp[ptr[k] + off] = c;
 }
 
 __global__ __launch_bounds__(256) void k_extract_index(const phl_contrib_t *__restrict__ in, int n, int *__restrict__ out)
