@@ -248,7 +248,7 @@ int phl_reserve(phl_lattice *lat, int vd)
     const int64_t need = lat->M * (int64_t)vd;
     if (need <= lat->buf_elems) {
         if (phl_tiles_lprs(lat, vd, 0) >= 0 && lat->S_multi <= lat->n) return phl_tiles_reserve(lat, vd);
-        return PHL_OK;
+        return phl_ensure_csr(lat, nullptr);   // gather splat will run: its lists must exist before a capture
     }
     int64_t cap0 = lat->buf_elems, cap1 = lat->buf_elems;
     int rc = grow(&lat->buf[0], &cap0, need);

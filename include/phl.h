@@ -108,8 +108,10 @@ int phl_add_vertices(phl_lattice *lat, const int16_t *keys_host, int64_t count, 
                      phl_stream stream);
 int64_t phl_num_local_vertices(const phl_lattice *lat); /* vertices created by this lattice's own pixels */
 
-/* Pre-size the [M][vd] ping-pong value buffers so that phl_filter allocates nothing
- * (needed before hipGraph capture). */
+/* Pre-size everything phl_filter(vd) needs (the [M][vd] ping-pong buffers, the partial-row buffer
+ * of the chunk splat or the contribution lists of the gather splat) so that the call itself
+ * allocates nothing and never synchronises: required before hipGraph capture.  For
+ * PHL_FILTER_EXACT call phl_filter once un-captured first (it builds its lists on first use). */
 int phl_reserve(phl_lattice *lat, int vd);
 
 /* ---- the hot path -----------------------------------------------------------------------
