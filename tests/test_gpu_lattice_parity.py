@@ -298,3 +298,43 @@ def test_full_size_properties(phl):
     want = po.Oracle(crop).filter(xs)
     got = phl.Lattice(torch.from_numpy(crop).to(dev)).filter(torch.from_numpy(xs).to(dev)).cpu().numpy()
     assert rel_err(got, want) <= 1e-5
+
+
+def test_randomised_shapes_against_oracle(phl):
+    """40 random (n, d, vd, feature scale, layout) draws: exact mode bit-identical to the oracle,
+    default mode within fp32 rounding; covers tiny n, every LPR / slab width, smooth and iid
+    features, padded and offset rows."""
+    from oracle import phl_oracle as po
+
+    rng = np.random.default_rng(20261004)
+    for trial in range(40):
+        n = int(rng.choice([1, 2, 7, 63, 64, 65, 255, 257, 1000, 4097, 20011]))
+        d = int(rng.integers(1, 9))
+        vd = int(rng.choice([1, 2, 3, 4, 5, 8, 12, 16, 20, 32, 60, 64, 68, 128, 132, 256, 300]))
+        if n * vd > 3_000_000:
+            vd = 8
+        scale = float(rng.choice([0.0, 0.3, 2.0, 8.0, 40.0]))
+        smooth = bool(rng.integers(0, 2))
+        ref = rng.random((n, d), dtype=np.float32) * np.float32(scale)
+        if smooth:
+            ref = np.cumsum(ref * np.float32(0.02), axis=0).astype(np.float32)
+        src = rng.random((n, vd), dtype=np.float32) - np.float32(0.25)
+        O = po.Oracle(ref)
+        if O.status == 1:        # a lattice coordinate left int16: both sides must say so
+            with pytest.raises(phl.PhlError) as err:
+                phl.Lattice(torch.from_numpy(ref).cuda())
+            assert err.value.status == 5
+            continue
+        want = O.filter(src)
+        L = phl.Lattice(torch.from_numpy(ref).cuda())
+        assert L.M == O.M, (trial, n, d, vd)
+        pad = int(rng.choice([0, 4, 3]))
+        buf = torch.zeros((n, vd + pad), device="cuda")
+        buf[:, :vd] = torch.from_numpy(src).cuda()
+        s = buf[:, :vd]
+        exact = L.filter(s, exact=True).cpu().numpy()
+        assert np.array_equal(exact.view(np.uint32), want.view(np.uint32)), (trial, n, d, vd, scale, smooth, pad)
+        fast = L.filter(s).cpu().numpy()
+        assert scaled_err(fast, want) <= 1e-5, (trial, n, d, vd, scale, smooth, pad)
+        sub = L.filter(s, subtract_input=True).cpu().numpy()
+        assert scaled_err(sub + src, want) <= 1e-5, (trial, n, d, vd)
