@@ -236,7 +236,13 @@ def main():
     # ---- per-kernel timing with HIP events on the launch stream (rank-local lattice) ---------
     roofline = None
     stage_ms = {}
-    if not rowtiled:
+    if rowtiled:
+        # rank 0's own band (own pixels + ghost vertices): the same kernels, timed locally
+        lat = job.band.eng
+        out = torch.empty_like(src)
+        kw = dict(exact=False, no_tiles=False)
+        extra["tiles"] = lat.tile_stats(L)
+    if rank == 0 or not rowtiled:
         ev = lambda: torch.cuda.Event(enable_timing=True)
         reps = max(3, min(args.steps, 10))
         acc = {"splat": 0.0, "blur_axis": 0.0, "slice": 0.0}
@@ -266,7 +272,7 @@ def main():
         staged_sl = extra["tiles"]["staged_slice"] and not args.no_tiles
         kname = {"splat": "k_splat_tiled+k_splat_reduce" if staged else "k_splat", "blur_axis": "k_blur",
                  "slice": "k_slice_tiled" if staged_sl else "k_slice"}
-        traffic, traffic_src = pmc_traffic(kname[dom], args.workload)
+        traffic, traffic_src = pmc_traffic(kname[dom], args.workload) if not rowtiled else (None, None)
         # measured streaming ceiling on this box: device copy of the value volume, R+W bytes
         e0, e1 = ev(), ev()
         phl.stream_copy(out, src)
@@ -286,6 +292,8 @@ def main():
                     # north-star wording: blur-pass READ bytes (d+1)*4*M*L against the HBM-read roofline
                     "measured_copy_GBps": round(copy_gbs, 1), "frac_of_measured_copy": round(achieved / copy_gbs, 4),
                     "blur_read_frac_of_peak": round(4 * M * L / (stage_ms["blur_axis"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+        if rowtiled:
+            roofline["scope"] = f"rank 0's band only ({n_local} pixels, {M} vertices incl. ghosts); kernels as in the 1-GPU run"
 
     cpu = None
     if rank == 0 and world == 1 and not rowtiled and not args.no_cpu_baseline:
