@@ -297,6 +297,17 @@ __global__ __launch_bounds__(TPB_S) void k_splat_tiled(const float *__restrict__
     int4 *meta = reinterpret_cast<int4 *>(ent + P * dp1);          // [nv_cap] {seg begin, seg end, slot_vert, slot_pidx}
     int *pixl = reinterpret_cast<int *>(meta + nv_cap);           // [P]
     int *ctr = pixl + P;                                           // one work counter per slab
+    // Loads are issued UNCONDITIONALLY from clamped (always valid) addresses and only the LDS
+    // stores are predicated: a load under a divergent `if` makes hipcc wait vmcnt(0) per load.
+    const int kclamp = cnt - 1;
+    const char *rbase = reinterpret_cast<const char *>(rows) + l * 16;
+    float4 pf[PF];
+    // Prologue, arranged so that the chunk pays ONE dependent HBM round trip, not two: every
+    // thread fetches the pixel ids of its own first PF rows itself and launches slab 0's row loads
+    // on them, while the index data (entries, pixel ids, per-vertex records) streams into LDS.
+    int prow[PF];
+#pragma unroll
+    for (int u = 0; u < PF; u++) prow[u] = pix_order[base + min(g + u * G, kclamp)];
     for (int e = threadIdx.x; e < E; e += TPB_S) {
         const phl_contrib_t s = seg[ebase + e];
         ent[e] = make_uint2((unsigned)(s.pixel * SL * 4), __float_as_uint(s.w));
@@ -306,22 +317,23 @@ __global__ __launch_bounds__(TPB_S) void k_splat_tiled(const float *__restrict__
         meta[i] = make_int4((int)(seg_rng[vbase + i].x - ebase), (int)(seg_rng[vbase + i].y - ebase), slot_vert[vbase + i],
                             slot_pidx[vbase + i]);
     if (threadIdx.x < 64) ctr[threadIdx.x] = NW;
-    __syncthreads();
-    const char *rbase = reinterpret_cast<const char *>(rows) + l * 16;
-    float4 pf[PF];
-    // Loads are issued UNCONDITIONALLY from clamped (always valid) addresses and only the LDS
-    // stores are predicated: a load under a divergent `if` makes hipcc wait vmcnt(0) per load.
-    const int kclamp = cnt - 1;
-    // slab 0 is staged synchronously
     {
         const bool chok = l * 4 < vd;
         const int chc = chok ? l * 4 : 0;
-        for (int k0 = g; k0 < cnt; k0 += PF * G) {
 #pragma unroll
-            for (int u = 0; u < PF; u++) pf[u] = ld4(src + (int64_t)pixl[min(k0 + u * G, kclamp)] * src_rs + chc);
+        for (int u = 0; u < PF; u++) pf[u] = ld4(src + (int64_t)prow[u] * src_rs + chc);
 #pragma unroll
-            for (int u = 0; u < PF; u++)
-                if (chok && k0 + u * G < cnt) st4(rows + (k0 + u * G) * SL + l * 4, pf[u]);
+        for (int u = 0; u < PF; u++)
+            if (chok && g + u * G < cnt) st4(rows + (g + u * G) * SL + l * 4, pf[u]);
+        if (PF * G < 256) {                // wide slabs: more rows per thread than the prefetch depth
+            __syncthreads();               // pixl is needed for the remaining rows
+            for (int k0 = g + PF * G; k0 < cnt; k0 += PF * G) {
+#pragma unroll
+                for (int u = 0; u < PF; u++) pf[u] = ld4(src + (int64_t)pixl[min(k0 + u * G, kclamp)] * src_rs + chc);
+#pragma unroll
+                for (int u = 0; u < PF; u++)
+                    if (chok && k0 + u * G < cnt) st4(rows + (k0 + u * G) * SL + l * 4, pf[u]);
+            }
         }
     }
     for (int c0 = 0; c0 < vd; c0 += SL) {
