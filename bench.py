@@ -148,6 +148,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-tiles", action="store_true", help="plain gather kernels (A/B against the LDS-staged chunk path)")
     ap.add_argument("--exact", action="store_true", help="reference-exact arithmetic (bit-identical to the CPU path)")
+    ap.add_argument("--graph", action="store_true", help="replay the step from a captured HIP graph (launch-bound sizes)")
     ap.add_argument("--force-rowtile", action="store_true", help="debug: run the row-band driver even with one rank")
     args = ap.parse_args()
 
@@ -220,6 +221,13 @@ def main():
     for _ in range(args.warmup):
         step()
     sync_all()
+    if args.graph and not rowtiled:
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            step()
+        step = graph.replay
+        step()
+        sync_all()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -310,6 +318,7 @@ def main():
                        "parallelism": ("single GPU" if world == 1 and not rowtiled else
                                        f"row bands x{world} + RCCL boundary-vertex exchange" if rowtiled else
                                        f"{world} independent volumes, one per GPU, no collective"),
+                       "launch": "hip graph replay" if (args.graph and not rowtiled) else "eager",
                        "arithmetic": "reference-exact (bit-identical to the CPU path)" if args.exact else "default (fp32-rounding-equivalent, ~1e-7 rel)"},
             "lattice_build_ms": round(build_ms, 2),
             "value_rebuild_each_iter": round(volumes * n_total * L / ((ms_per_step + build_ms) * 1e-3) / 1e6, 1),

@@ -338,3 +338,26 @@ def test_randomised_shapes_against_oracle(phl):
         assert scaled_err(fast, want) <= 1e-5, (trial, n, d, vd, scale, smooth, pad)
         sub = L.filter(s, subtract_input=True).cpu().numpy()
         assert scaled_err(sub + src, want) <= 1e-5, (trial, n, d, vd)
+
+
+def test_filter_is_graph_capturable(phl):
+    """After phl_reserve the filter launch sequence allocates nothing and never synchronises, so
+    it can be captured into a HIP graph (torch.cuda.CUDAGraph) and replayed on new input values."""
+    rng = np.random.default_rng(9)
+    n, d, L = 20000, 5, 32
+    ref = np.cumsum(rng.random((n, d), dtype=np.float32) * 0.02, axis=0).astype(np.float32)
+    Lat = phl.Lattice(torch.from_numpy(ref).cuda())
+    Lat.reserve(L)
+    x = torch.rand((n, L), device="cuda")
+    out = torch.empty_like(x)
+    Lat.filter(x, out=out)                       # warm-up outside the capture
+    want1 = out.clone()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        Lat.filter(x, out=out)
+    x.copy_(torch.rand((n, L), device="cuda"))   # new values in the captured input buffer
+    g.replay()
+    torch.cuda.synchronize()
+    want2 = Lat.filter(x)
+    assert torch.equal(out, want2) and not torch.equal(out, want1)
