@@ -104,17 +104,23 @@ __device__ __forceinline__ int waves_in_grid() { return (int)gridDim.x * (int)(b
 template <int VEC, int LPR>
 __global__ __launch_bounds__(256) void k_splat(const float *__restrict__ src, int64_t src_rs, int vd,
                                                const int *__restrict__ ptr, const phl_contrib_t *__restrict__ csr,
-                                               int M, float *__restrict__ vert)
+                                               int M, float *__restrict__ vert, const int *__restrict__ vorder,
+                                               int xcd_chunk)
 {
     using V = typename vec_of<VEC>::type;
     constexpr int G = 64 / LPR;
     const int lane = threadIdx.x & 63;
     const int sub = lane / LPR;
     const int l = lane % LPR;
-    const int64_t stride = (int64_t)waves_in_grid() * G;
-    for (int64_t v0 = (int64_t)wave_in_grid() * G; v0 < M; v0 += stride) {
-        const int64_t v = v0 + sub;
-        const bool act = v < M;
+    // vertices are visited in chunk-major order (vorder) and every XCD gets a contiguous part of
+    // that order (see k_blur): vertices summed together then share pixel rows through one L2
+    const int lb = xcd_chunk > 0 ? (int)(blockIdx.x & 7) * xcd_chunk + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    const int wv = lb * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    {
+        const int64_t idx = (int64_t)wv * G + sub;
+        if ((int64_t)wv * G >= M) return;
+        const bool act = idx < M;
+        const int64_t v = act ? (vorder ? vorder[idx] : idx) : 0;
         int beg = 0, end = 0;
         if (act) { beg = ptr[v]; end = ptr[v + 1]; }
         for (int c = l * VEC; c < vd; c += LPR * VEC) {
@@ -309,11 +315,19 @@ int phl_launch_splat(phl_lattice *lat, const float *src, int64_t src_rs, int vd,
     if (rc_csr) return rc_csr;
     const bool v4 = (vd % 4 == 0) && (src_rs % 4 == 0) && aligned16(src) && aligned16(vert);
     const int lpr = pick_lpr(vd, v4 ? 4 : 1);
-    const unsigned grid = grid_for(M, 64 / lpr);
+    const int rows_per_block = (64 / lpr) * 4;
+    int64_t blocks = ((int64_t)M + rows_per_block - 1) / rows_per_block;
+    static const bool xcd = !(getenv("PHL_XCD") && atoi(getenv("PHL_XCD")) == 0);
+    int xcd_chunk = 0;
+    if (xcd && blocks >= 64) {
+        blocks = (blocks + 7) / 8 * 8;
+        xcd_chunk = (int)(blocks / 8);
+    }
+    const unsigned grid = (unsigned)blocks;
     dispatch_lpr(lpr, [&](auto L) {
         constexpr int LPR = decltype(L)::value;
-        if (v4) k_splat<4, LPR><<<dim3(grid), dim3(256), 0, st>>>(src, src_rs, vd, lat->csr_ptr, lat->csr, M, vert);
-        else k_splat<1, LPR><<<dim3(grid), dim3(256), 0, st>>>(src, src_rs, vd, lat->csr_ptr, lat->csr, M, vert);
+        if (v4) k_splat<4, LPR><<<dim3(grid), dim3(256), 0, st>>>(src, src_rs, vd, lat->csr_ptr, lat->csr, M, vert, lat->vorder, xcd_chunk);
+        else k_splat<1, LPR><<<dim3(grid), dim3(256), 0, st>>>(src, src_rs, vd, lat->csr_ptr, lat->csr, M, vert, lat->vorder, xcd_chunk);
     });
     PHL_HIP(hipGetLastError());
     return PHL_OK;

@@ -52,6 +52,7 @@ struct phl_lattice {
     unsigned short *lidx;   // [N] local vertex index per (chunk pixel, remainder)
     int32_t *vs_ptr;        // [M+1] slots of each vertex ...
     phl_contrib_t *vs;      // [S]   ... ascending (slot index in .pixel)
+    int32_t *vorder;        // [M] vertices in chunk-major order (gather splat locality); may be null
     float *partial;         // [S_multi][vd] partial splat sums
     int64_t partial_elems;
     int64_t tile_bytes;

@@ -542,6 +542,27 @@ __global__ __launch_bounds__(TPB) void k_slice_tiled(const float *__restrict__ v
     }
 }
 
+// vertex processing order for the gather splat: vertices sorted by the first chunk that touches
+// them, so that vertices summed at the same time read the same few chunks' pixel rows (L2 hits
+// instead of Infinity-Cache traffic).  first[s] = 1 iff slot s is the first slot of its vertex.
+__global__ __launch_bounds__(256) void k_first_slot(const int *__restrict__ slot_vert, int S, const int *__restrict__ vs_ptr,
+                                                    const phl_contrib_t *__restrict__ vs, int *__restrict__ first)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= S) return;
+    const int v = slot_vert[s] & 0x7FFFFFFF;
+    first[s] = (vs[vs_ptr[v]].pixel == s) ? 1 : 0;
+}
+
+__global__ __launch_bounds__(256) void k_fill_vorder(const int *__restrict__ slot_vert, int S, const int *__restrict__ first,
+                                                     const int *__restrict__ rank, int M_local, int M,
+                                                     int *__restrict__ vorder)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < S && first[i]) vorder[rank[i]] = slot_vert[i] & 0x7FFFFFFF;
+    if (i >= M_local && i < M) vorder[i] = i;      // ghost vertices (no local contributions) go last
+}
+
 __global__ __launch_bounds__(256) void k_strip_marks(int *slot_vert, int S)
 {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
@@ -624,11 +645,12 @@ inline int pick_lpr_row(int vd)
 int phl_tiles_free(phl_lattice *lat)
 {
     void *ptrs[] = {lat->pix_order, lat->chunk_vptr, lat->slot_vert, lat->slot_pidx, lat->seg_rng, lat->seg,
-                    lat->lidx, lat->vs_ptr, lat->vs, lat->partial};
+                    lat->lidx, lat->vs_ptr, lat->vs, lat->partial, lat->vorder};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     lat->pix_order = lat->chunk_vptr = lat->slot_vert = lat->slot_pidx = lat->vs_ptr = nullptr;
     lat->seg_rng = nullptr;
+    lat->vorder = nullptr;
     lat->seg = lat->vs = nullptr;
     lat->lidx = nullptr;
     lat->partial = nullptr;
@@ -687,6 +709,23 @@ int phl_tiles_link_vertices(phl_lattice *lat, hipStream_t st)
     if (rc) return rc;
     int s_multi = 0;
     PHL_HIP(hipMemcpyAsync(&s_multi, lat->slot_pidx + S, sizeof(int), hipMemcpyDeviceToHost, st));
+    // chunk-major vertex order for the gather splat
+    if (lat->vorder) PHL_HIP(hipFree(lat->vorder));
+    lat->vorder = nullptr;
+    PHL_HIP(hipMalloc((void **)&lat->vorder, sizeof(int) * ((size_t)M + 1)));
+    {
+        int *first, *frank;
+        PHL_HIP(tmp.get(&first, (size_t)S + 1));
+        PHL_HIP(tmp.get(&frank, (size_t)S + 2));
+        hipLaunchKernelGGL(k_first_slot, dim3(gS), dim3(256), 0, st, lat->slot_vert, S, lat->vs_ptr, lat->vs, first);
+        PHL_HIP(hipGetLastError());
+        rc = exclusive_scan(first, frank, S, tile_sums, st);
+        if (rc) return rc;
+        const int span = S > M ? S : M;
+        hipLaunchKernelGGL(k_fill_vorder, dim3((span + 255) / 256), dim3(256), 0, st, lat->slot_vert, S, first, frank,
+                           (int)lat->M_local, M, lat->vorder);
+        PHL_HIP(hipGetLastError());
+    }
     PHL_HIP(hipStreamSynchronize(st));
     lat->S_multi = s_multi;
     return PHL_OK;
