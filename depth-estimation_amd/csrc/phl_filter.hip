@@ -126,6 +126,16 @@ __global__ __launch_bounds__(256) void k_splat(const float *__restrict__ src, in
         for (int c = l * VEC; c < vd; c += LPR * VEC) {
             V acc = vzero<VEC>();
             int e = beg;
+            for (; e + 8 <= end; e += 8) {      // 8 independent row loads in flight, summed in list order
+                phl_contrib_t cc[8];
+                V qq[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) cc[u] = csr[e + u];
+#pragma unroll
+                for (int u = 0; u < 8; u++) qq[u] = vload(src + (int64_t)cc[u].pixel * src_rs + c, V());
+#pragma unroll
+                for (int u = 0; u < 8; u++) acc = mac(acc, cc[u].w, qq[u]);
+            }
             for (; e + 4 <= end; e += 4) {
                 const phl_contrib_t c0 = csr[e], c1 = csr[e + 1], c2 = csr[e + 2], c3 = csr[e + 3];
                 const V q0 = vload(src + (int64_t)c0.pixel * src_rs + c, V());
