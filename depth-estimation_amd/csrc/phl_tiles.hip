@@ -263,9 +263,8 @@ __device__ __forceinline__ float4 fma4(float4 acc, float w, float4 v)
 // Each of a wavefront's 64/LPRS lane groups owns one local vertex and sums its pixel-sorted
 // segment sequentially out of LDS: a segmented reduction with one segment per lane group,
 // deterministic, no atomics (details at the loop).
-constexpr int TPB = 512;
-
-constexpr int TPB_S = 512;   // splat: more waves hide the LDS latency of the segmented sums
+constexpr int TPB = 512;     // slice workgroup
+constexpr int TPB_S = 512;   // splat workgroup (1024 threads and 1 workgroup per CU measured no better)
 
 template <int LPRS>
 __global__ __launch_bounds__(TPB_S) void k_splat_tiled(const float *__restrict__ src, int64_t src_rs, int vd, int n, int P,
@@ -296,7 +295,7 @@ __global__ __launch_bounds__(TPB_S) void k_splat_tiled(const float *__restrict__
     uint2 *ent = reinterpret_cast<uint2 *>(lds + (size_t)P * SL);
     int4 *meta = reinterpret_cast<int4 *>(ent + P * dp1);          // [nv_cap] {seg begin, seg end, slot_vert, slot_pidx}
     int *pixl = reinterpret_cast<int *>(meta + nv_cap);           // [P]
-    int *ctr = pixl + P;                                           // one work counter per slab
+    int *ctr = pixl + P;                                           // two work counters, used by alternate slabs
     // Loads are issued UNCONDITIONALLY from clamped (always valid) addresses and only the LDS
     // stores are predicated: a load under a divergent `if` makes hipcc wait vmcnt(0) per load.
     const int kclamp = cnt - 1;
@@ -316,7 +315,7 @@ __global__ __launch_bounds__(TPB_S) void k_splat_tiled(const float *__restrict__
     for (int i = threadIdx.x; i < nv; i += TPB_S)
         meta[i] = make_int4((int)(seg_rng[vbase + i].x - ebase), (int)(seg_rng[vbase + i].y - ebase), slot_vert[vbase + i],
                             slot_pidx[vbase + i]);
-    if (threadIdx.x < 64) ctr[threadIdx.x] = NW;
+    if (threadIdx.x < 2) ctr[threadIdx.x] = NW;
     {
         const bool chok = l * 4 < vd;
         const int chc = chok ? l * 4 : 0;
@@ -340,6 +339,8 @@ __global__ __launch_bounds__(TPB_S) void k_splat_tiled(const float *__restrict__
         const int ch = c0 + l * 4;
         const bool chok = ch < vd;
         __syncthreads();                   // rows of this slab are in LDS
+        const int slab = c0 / SL;
+        if (threadIdx.x == 0) ctr[(slab + 1) & 1] = NW;   // re-arm the other counter for the next slab
         const int chn = ch + SL;
         const bool more = c0 + SL < vd;    // wave-uniform
         const bool chnok = more && chn < vd;
@@ -353,7 +354,7 @@ __global__ __launch_bounds__(TPB_S) void k_splat_tiled(const float *__restrict__
         // (k_chunk_sort), so the Q vertices of a group have nearly equal loops, and the waves take
         // groups longest-first from a shared counter: no cross-lane combine, no padding, and the
         // per-vertex bookkeeping is paid once per Q vertices.
-        int *slab_ctr = ctr + (c0 / SL);
+        int *slab_ctr = ctr + (slab & 1);
         const int ngroups = (nv + Q - 1) / Q;
         for (int gi = wave; gi < ngroups;) {
             const int i = gi * Q + q;

@@ -361,3 +361,17 @@ def test_filter_is_graph_capturable(phl):
     torch.cuda.synchronize()
     want2 = Lat.filter(x)
     assert torch.equal(out, want2) and not torch.equal(out, want1)
+
+
+def test_very_wide_values_many_slabs(phl):
+    """vd = 3072 (the reference's ref-gradient filter for L=256, d=5 has 2L(1+d) channels): 48
+    slabs through the staged kernels."""
+    from oracle import phl_oracle as po
+
+    rng = np.random.default_rng(12)
+    n, d, vd = 600, 5, 3072
+    ref = np.cumsum(rng.random((n, d), dtype=np.float32) * 0.03, axis=0).astype(np.float32)
+    src = rng.random((n, vd), dtype=np.float32)
+    want = po.Oracle(ref).filter(src)
+    got = phl.Lattice(torch.from_numpy(ref).cuda()).filter(torch.from_numpy(src).cuda()).cpu().numpy()
+    assert rel_err(got, want) <= 1e-5
