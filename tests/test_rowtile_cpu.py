@@ -15,13 +15,16 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 RTOL = 1e-4
 
 
-def make_image(H, W, L, sigma_xy=2.0, seed=0):
+def make_image(H, W, L, sigma_xy=2.0, seed=0, iid_colour=False):
     rng = np.random.default_rng(seed)
     feat = np.empty((H, W, 5), np.float32)
     feat[..., 0] = (np.arange(W, dtype=np.float32) / sigma_xy)[None, :]
     feat[..., 1] = (np.arange(H, dtype=np.float32) / sigma_xy)[:, None]
-    col = rng.random((H // 4 + 1, W // 4 + 1, 3)).astype(np.float32)
-    feat[..., 2:] = np.kron(col, np.ones((4, 4, 1), np.float32))[:H, :W] * 6
+    if iid_colour:        # every pixel its own colour: many thin vertices, long blur chains across the cut
+        feat[..., 2:] = rng.random((H, W, 3)).astype(np.float32) * 3
+    else:
+        col = rng.random((H // 4 + 1, W // 4 + 1, 3)).astype(np.float32)
+        feat[..., 2:] = np.kron(col, np.ones((4, 4, 1), np.float32))[:H, :W] * 6
     src = rng.random((H * W, L), dtype=np.float32)
     return feat, src
 
@@ -54,6 +57,20 @@ def test_loopback_bands_match_single_lattice(world):
     top = po.oracle_filter(src[:bands[0].n_local], feat[:bands[0].own_rows].reshape(-1, 5))
     assert rel(top, want[:bands[0].n_local]) > 1e-2
     assert all(b.M > b.eng._o.M - 1 for b in bands) and bands[0].S == 13
+
+
+def test_loopback_bands_iid_colours():
+    """Stress the strip-depth bound: iid colours give M/n ~ 2 and blur chains that wander in the
+    colour dimensions while creeping across the cut."""
+    from oracle import phl_oracle as po
+    from phl import rowtile
+    from _engines import OracleEngine
+
+    H, W, L = 60, 24, 3
+    feat, src = make_image(H, W, L, iid_colour=True, seed=5)
+    want = po.oracle_filter(src, feat.reshape(-1, 5))
+    got, _ = rowtile.simulate(feat, torch.from_numpy(src), 2, OracleEngine, torch.device("cpu"))
+    assert rel(got.numpy(), want) <= RTOL
 
 
 def test_too_many_ranks_is_rejected():
