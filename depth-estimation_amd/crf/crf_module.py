@@ -66,6 +66,8 @@ def mean_field_infer(E_0, W, Mu, niters=10):
 
         Q = phl.softmax_neg_add(E_0)
         for _ in range(niters):
+            # (torch.addmm(E_0, X, Mu) would fold the add into the GEMM, but rocBLAS' beta=1 path
+            # measured 1.5 ms slower than mm at 3.1M x 256 x 256, more than the pass it saves)
             G = (W @ Q) @ Mu
             if not (G.is_cuda and G.dtype == torch.float32 and G.stride(1) == 1):
                 G = G.to(E_0.device, torch.float32).contiguous()

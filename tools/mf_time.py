@@ -20,6 +20,9 @@ print('softmax ms', t(lambda: torch.softmax(-E0, 1)))
 print('filter-U ms', t(lambda: Wop @ Q))
 X = Wop @ Q
 print('matmul fp32 ms', t(lambda: X @ Mu))
-torch.backends.cuda.matmul.allow_tf32 = True
 print('E0 + ... ms', t(lambda: E0 + X))
 print('mean_field_infer 5 iters ms', t(lambda: mean_field_infer(E0, Wop, Mu, 5), 2))
+
+E = torch.empty_like(E0)
+print('addmm ms', t(lambda: torch.addmm(E0, X, Mu, out=E)))
+print('mm ms', t(lambda: torch.mm(X, Mu)))
