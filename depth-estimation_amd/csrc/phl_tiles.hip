@@ -54,7 +54,7 @@ __global__ __launch_bounds__(256) void k_minmax(const float *__restrict__ ref, i
         if (lane == 0) { smin[w][i] = lo; smax[w][i] = hi; }
     }
     __syncthreads();
-    if (threadIdx.x < d) {
+    if ((int)threadIdx.x < d) {
         float lo = smin[0][threadIdx.x], hi = smax[0][threadIdx.x];
         for (int k = 1; k < 4; k++) { lo = fminf(lo, smin[k][threadIdx.x]); hi = fmaxf(hi, smax[k][threadIdx.x]); }
         out[((int64_t)blockIdx.x * d + threadIdx.x) * 2 + 0] = lo;

@@ -1,0 +1,77 @@
+"""Per-rank cost of the row-band path without a multi-GPU box: build all `world` bands of C3 in this
+process (loopback), then time ONE interior band's filter call (splat -> pack boundary rows -> add the
+neighbours' rows -> blur -> slice) with the exchange replaced by local copies.  Reports host time
+(python + launches) and GPU time per call for 1 and 2 channel groups.
+
+  python tools/band_time.py [world] [rank]
+"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "depth-estimation_amd"))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import torch
+
+import bench
+import phl
+from phl import rowtile
+
+world = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+rank = int(sys.argv[2]) if len(sys.argv) > 2 else world // 2
+H, W, L, _ = bench.WORKLOADS["c3"]
+dev = torch.device("cuda", 0)
+feat = bench.synthetic_features(H, W)
+want = [r for r in (rank - 1, rank, rank + 1) if 0 <= r < world]
+bands = {r: rowtile.RowBand(feat, r, world, phl.Lattice, dev) for r in want}
+out = {r: b.build_outbox() for r, b in bands.items()}
+b = bands[rank]
+b.build_inbox({p: out[p][rank] for p in b.sides})
+src = bench.synthetic_values(torch, b.own_rows, W, L, b.row0, dev)
+print(f"world {world} rank {rank}: rows {b.own_rows}, S {b.S}, n_local {b.n_local}, M(+ghosts) {b.M}, "
+      f"recv rows {[b.recv_rows(p) for p in b.sides]}, send rows {[int(s['send_idx'].numel()) for s in b.sides.values()]}")
+
+for groups in (1, 2, 4):
+    cuts = [(g * L // groups, (g + 1) * L // groups) for g in range(groups)]
+    b.eng.reserve(max(c1 - c0 for c0, c1 in cuts))
+    res = torch.empty((b.n_local, L), device=dev)
+    fake = [{p: torch.randn((b.recv_rows(p), c1 - c0), device=dev) for p in b.sides} for c0, c1 in cuts]
+
+    def call():
+        pend = []
+        for gi, (c0, c1) in enumerate(cuts):
+            vert, outbox = b.splat_outbox(src[:, c0:c1])
+            pend.append((vert, [v.contiguous() for v in outbox.values()]))
+        for gi, (c0, c1) in enumerate(cuts):
+            b.finish(pend[gi][0], fake[gi], out=res[:, c0:c1])
+
+    for _ in range(5):
+        call()
+    torch.cuda.synchronize()
+    reps = 50
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(reps):
+        call()
+    e1.record()
+    host = (time.perf_counter() - t0) / reps * 1e3
+    torch.cuda.synchronize()
+    wall = (time.perf_counter() - t0) / reps * 1e3
+    print(f"groups {groups}: host issue {host:.3f} ms/call, gpu {e0.elapsed_time(e1) / reps:.3f} ms/call, wall {wall:.3f} ms/call")
+
+# single-lattice reference point on the same box
+ref = torch.from_numpy(feat.reshape(-1, 5)).to(dev)
+full = bench.synthetic_values(torch, H, W, L, 0, dev)
+lat = phl.Lattice(ref)
+lat.reserve(L)
+o = torch.empty_like(full)
+for _ in range(3):
+    lat.filter(full, out=o)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(20):
+    lat.filter(full, out=o)
+torch.cuda.synchronize()
+t1 = (time.perf_counter() - t0) / 20 * 1e3
+print(f"single lattice full image: {t1:.3f} ms/call -> compute-only speedup bound at {world} ranks = {t1:.3f}/wall")
