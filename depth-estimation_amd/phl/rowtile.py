@@ -10,19 +10,28 @@ Decomposition (one process per GPU, rank r owns image rows [row0, row1)):
   build   every rank builds the lattice of ITS OWN pixels.  Splat is a sum over pixels, so a
           vertex near a cut gets contributions from two bands, and blur reaches vertices that
           only the neighbouring band creates.  Each rank therefore sends the KEYS of the
-          vertices touched by its pixels within S rows of a cut to the rank across that cut,
+          vertices the rank across a cut can need (selected by lattice coordinate, below) to that rank,
           which files them as ghost vertices (phl_add_vertices) and remembers the index map.
   filter  splat own pixels -> exchange the partial sums of those boundary vertices with the
           <= 2 neighbouring ranks (point-to-point, RCCL over xGMI) -> add -> blur -> slice own
           pixels.  One exchange per filter call; message = (#boundary vertices) x L floats.
 
-Strip depth S.  Let f be a feature that grows by at least g per image row (the "y" feature).
-A pixel's simplex vertices lie within the simplex diameter a = sqrt(d+1)*sqrt(6)/4 feature
-units of it; the d+1 blur steps displace by at most b = sqrt(6(d+1))/2 in total along any
-direction; so the vertices whose COMPLETE splat sums a band needs lie within a+b of its own
-pixels, and the foreign pixels contributing to them within 2a+b = sqrt(6(d+1)) (6.0 units for
-d=5).  S = ceil(sqrt(6(d+1)) / g) rows.  Vertices deeper in the strip arrive with incomplete
-sums; by the same bound they cannot influence the band's own pixels.  Results equal the
+Which vertices travel.  Feature k is elevated along the unit vector u_k = (1,..,1 [k+1 ones],
+-(k+1), 0,..)/sqrt((k+1)(k+2)) of the lattice hyperplane, scaled by alpha = (d+1)*sqrt(2/3)
+(permutohedral.h:354-384), so a vertex with integer key K sits at feature coordinate
+y(K) = K.u_k / alpha -- exact, no geometry assumed.  Along that coordinate
+  a_k  = how far a simplex vertex can lie from a pixel inside the simplex
+       = max over simplex edges w (entries m x(d+1-m), -(d+1-m) x m, any order) of |w.u_k| / alpha,
+  b_k  = the total displacement of the d+1 blur steps (step j moves by (1,..,1)-(d+1)e_j, whose
+         u_k component is -(d+1)u_k[j])  = sqrt(3/2) * |u_k|_1
+(d=5, k=1: a = 1.0, b = 2.0 feature units; the direction-free bounds are 1.5 and 3.0).
+A band whose pixels span [lo, hi] in feature k reads, at slice time, vertices within a_k of that
+interval, and their blurred values depend on splat sums within a further b_k.  So a rank sends
+to the rank across a cut exactly its vertices with y(K) in [lo' - a_k - b_k, hi' + a_k + b_k]
+(lo', hi' = the RECEIVER's span), which the receiver files as ghosts; nothing deeper is needed
+and nothing deeper is sent.  Bands two apart must not share such vertices: their spans have to
+be separated by more than 2a_k + b_k (checked at build; S = ceil((2a_k+b_k)/g)+1 rows is the
+same bound in image rows for a feature growing by g per row).  Results equal the
 single-lattice filter up to fp32 summation order (own partial + neighbour partial instead of
 one pixel-ordered sum): ~1e-7 relative, asserted at 1e-4 in tests.
 
@@ -39,21 +48,59 @@ import numpy as np
 import torch
 
 
-def strip_rows(feat, d=None):
-    """S for an [H, W, d] feature image: ceil(sqrt(6(d+1)) / g) + 1, g = the largest guaranteed
-    per-row increment of any feature."""
-    H, W, dd = feat.shape
-    d = dd if d is None else d
+def lattice_reach(d, k):
+    """(a_k, b_k) of the module header, in units of feature k."""
+    u = np.zeros(d + 1)
+    u[:k + 1] = 1.0
+    u[k + 1] = -(k + 1)
+    u /= math.sqrt((k + 1) * (k + 2))
+    alpha = (d + 1) * math.sqrt(2.0 / 3.0)
+    us = np.sort(u)
+    a = 0.0
+    for m in range(1, d + 1):
+        w = np.sort(np.array([m] * (d + 1 - m) + [-(d + 1 - m)] * m, dtype=np.float64))
+        a = max(a, abs(float(w @ us)), abs(float(w @ us[::-1])))      # rearrangement inequality: extremes over orders
+    return a / alpha, math.sqrt(1.5) * float(np.abs(u).sum())
+
+
+def vertex_coordinate(keys, d, k):
+    """Feature-k coordinate of lattice vertices given their int16 keys [M, d] (last coordinate implied)."""
+    K = keys.astype(np.float64)
+    # K_full . u_k with K_full = (K, -sum K); u_k is zero beyond index k+1
+    full_k1 = K[:, k + 1] if k + 1 < d else -K.sum(axis=1)
+    return (K[:, :k + 1].sum(axis=1) - (k + 1) * full_k1) / math.sqrt((k + 1) * (k + 2)) / ((d + 1) * math.sqrt(2.0 / 3.0))
+
+
+def band_axis(feat):
+    """Pick the feature the bands are ordered along: (k, sign, g, support) with sign*feat[..., k]
+    growing by at least g > 0 per image row and support = 2a_k + b_k; the k with the fewest
+    support rows wins."""
+    H, W, d = feat.shape
     if H < 2:
         raise ValueError("row bands need at least 2 image rows")
     inc = np.diff(feat.astype(np.float64), axis=0)            # [H-1, W, d]
-    lo = inc.min(axis=(0, 1))
-    hi = inc.max(axis=(0, 1))
-    g = float(np.max(np.where(lo > 0, lo, np.where(hi < 0, -hi, 0.0))))
-    if g <= 0:
+    lo, hi = inc.min(axis=(0, 1)), inc.max(axis=(0, 1))
+    best = None
+    for k in range(d):
+        g, sign = (lo[k], 1.0) if lo[k] > 0 else ((-hi[k], -1.0) if hi[k] < 0 else (0.0, 0.0))
+        if g > 0:
+            a, b = lattice_reach(d, k)
+            rows = (2 * a + b) / g
+            if best is None or rows < best[0]:
+                best = (rows, k, sign, float(g), a, b)
+    if best is None:
         raise ValueError("row-band sharding needs a feature that is strictly monotone in the row index "
                          "(e.g. y/sigma); these features have none")
-    return int(math.ceil(math.sqrt(6.0 * (d + 1)) / g)) + 1
+    return best[1:]
+
+
+def strip_rows(feat):
+    """Image rows the lattice support spans: ceil((2a_k + b_k) / g) + 1 (bands must be at least this tall)."""
+    k, sign, g, a, b = band_axis(np.asarray(feat))
+    return int(math.ceil((2 * a + b) / g - 1e-9)) + 1
+
+
+_REACH_SCALE = 1.0   # tests shrink this to show the bound is tight, never the product
 
 
 def band_rows(H, world):
@@ -71,29 +118,34 @@ class RowBand:
         self.row0, self.row1 = cuts[rank], cuts[rank + 1]
         self.own_rows = self.row1 - self.row0
         self.n_local = self.own_rows * W
-        self.S = strip_rows(feat)
-        if world > 1 and min(b - a for a, b in zip(cuts[:-1], cuts[1:])) < self.S:
-            raise ValueError(f"row bands ({min(b - a for a, b in zip(cuts[:-1], cuts[1:]))} rows) are shorter than the "
-                             f"lattice support ({self.S} rows): use fewer ranks")
+        k, sign, g, a_k, b_k = band_axis(feat)
+        self.S = int(math.ceil((2 * a_k + b_k) / g - 1e-9)) + 1
+        self.axis, self.reach = k, a_k + b_k
+        y = sign * feat[..., k]
+        span = [(float(y[r0:r1].min()), float(y[r0:r1].max())) for r0, r1 in zip(cuts[:-1], cuts[1:])]
+        for r in range(world - 2):
+            if span[r + 2][0] - span[r][1] <= 2 * a_k + b_k:
+                raise ValueError(f"row bands ({min(r1 - r0 for r0, r1 in zip(cuts[:-1], cuts[1:]))} rows) are shorter than the "
+                                 f"lattice support ({self.S} rows): use fewer ranks")
         self.device = device
         own = np.ascontiguousarray(feat[self.row0:self.row1].reshape(-1, d), dtype=np.float32)
         t0 = time.time()
         self.eng = engine_factory(torch.from_numpy(own).to(device))
         self.sides = {}   # peer -> dict(send_idx, map_idx)
-        vid, _ = self.eng.replay()
         keys = self.eng.keys()
-        vid = vid.reshape(self.own_rows, W, d + 1)
+        ypos = sign * vertex_coordinate(keys, d, k)
+        reach = (a_k + b_k) * _REACH_SCALE + 1e-3 * (1.0 + max(abs(span[0][0]), abs(span[-1][1])))   # + fp32 elevate slack
         self._send_keys = {}
-        for peer, rows in ((rank - 1, slice(0, self.S)), (rank + 1, slice(self.own_rows - self.S, self.own_rows))):
+        for peer in (rank - 1, rank + 1):
             if 0 <= peer < world:
-                v = np.unique(vid[rows].ravel())
+                v = np.nonzero((ypos >= span[peer][0] - reach) & (ypos <= span[peer][1] + reach))[0]
                 self.sides[peer] = dict(send_idx=torch.from_numpy(v.astype(np.int64)).to(device))
                 self._send_keys[peer] = torch.from_numpy(np.ascontiguousarray(keys[v]))
         self._t_build = time.time() - t0
 
     # -- build phases ---------------------------------------------------------------------------
     def build_outbox(self):
-        """{peer: int16 [K, d] keys of my vertices touched within S rows of the cut}"""
+        """{peer: int16 [K, d] keys of my vertices within a_k + b_k of the peer's band}"""
         return dict(self._send_keys)
 
     def build_inbox(self, inbox):

@@ -82,6 +82,7 @@ class Oracle:
         self.n, self.d = ref.shape
         lib = _oracle_lib()
         rs, cs = (s // 4 for s in ref.strides)
+        self._free = lib.phlo_free          # kept on the object: module globals may be gone at interpreter exit
         self._h = lib.phlo_build(_ptr(ref, _f32p), self.n, self.d, rs, cs, int(bool(faithful_table)))
         if not self._h:
             raise ValueError("phlo_build failed (d out of range?)")
@@ -90,7 +91,7 @@ class Oracle:
 
     def __del__(self):
         if getattr(self, "_h", None):
-            _oracle_lib().phlo_free(self._h)
+            self._free(self._h)
             self._h = None
 
     def keys(self):

@@ -37,7 +37,8 @@ def test_strip_rows_formula():
     from phl import rowtile
 
     feat, _ = make_image(40, 8, 1, sigma_xy=2.0)
-    assert rowtile.strip_rows(feat) == int(np.ceil(6.0 / 0.5)) + 1      # d=5: sqrt(6*6)=6 units, g=0.5/row
+    assert rowtile.lattice_reach(5, 1) == pytest.approx((1.0, 2.0))      # a_k, b_k of the module header, y = feature 1
+    assert rowtile.strip_rows(feat) == int(np.ceil(4.0 / 0.5)) + 1      # 2a+b = 4 feature units, g = 0.5 per row
     with pytest.raises(ValueError, match="monotone"):
         rowtile.strip_rows(np.zeros((10, 4, 3), np.float32))
 
@@ -56,7 +57,7 @@ def test_loopback_bands_match_single_lattice(world):
     # the exchange is really needed: without ghosts the cut rows are wrong
     top = po.oracle_filter(src[:bands[0].n_local], feat[:bands[0].own_rows].reshape(-1, 5))
     assert rel(top, want[:bands[0].n_local]) > 1e-2
-    assert all(b.M > b.eng._o.M - 1 for b in bands) and bands[0].S == 13
+    assert all(b.M > b.eng._o.M - 1 for b in bands) and bands[0].S == 9
 
 
 def test_loopback_bands_iid_colours():
@@ -71,6 +72,77 @@ def test_loopback_bands_iid_colours():
     want = po.oracle_filter(src, feat.reshape(-1, 5))
     got, _ = rowtile.simulate(feat, torch.from_numpy(src), 2, OracleEngine, torch.device("cpu"))
     assert rel(got.numpy(), want) <= RTOL
+
+
+def test_reach_bounds_hold_on_the_oracle_lattice():
+    """a_k: no simplex vertex lies farther than a_k (feature k) from its pixel; b_k: the d+1 blur steps move by
+    exactly b_k in total.  Checked on the CPU restatement's own keys / replay / neighbour tables."""
+    from oracle import phl_oracle as po
+    from phl import rowtile
+
+    rng = np.random.default_rng(3)
+    for d in (3, 5):
+        n = 4000
+        f = (rng.random((n, d)) * 6).astype(np.float32)
+        o = po.Oracle(f)
+        keys, (vid, _), nb = o.keys(), o.replay(), np.asarray(o.neighbors())
+        vid = vid.reshape(n, d + 1)
+        for k in range(d):
+            a, b = rowtile.lattice_reach(d, k)
+            y = rowtile.vertex_coordinate(keys, d, k)
+            off = np.abs(y[vid] - f[:, k:k + 1].astype(np.float64)).max()
+            assert 0.8 * a < off <= a + 1e-5
+            step = 0.0
+            for j in range(d + 1):
+                n1 = nb[j, :, 0]
+                m = n1 >= 0
+                step += float(np.abs(y[n1[m]] - y[m]).max())
+            assert step == pytest.approx(b, rel=1e-9)
+
+
+@pytest.mark.parametrize("order,flip", [((2, 3, 4, 1, 0), False), ((0, 1, 2, 3, 4), True), ((1, 0, 2, 3, 4), False)])
+def test_loopback_bands_any_feature_order(order, flip):
+    """The band axis is found, not assumed: y may sit at any feature index and may decrease with the row."""
+    from oracle import phl_oracle as po
+    from phl import rowtile
+    from _engines import OracleEngine
+
+    H, W, L = 72, 16, 3
+    feat, src = make_image(H, W, L, seed=7)
+    if flip:
+        feat[..., 1] = feat[..., 1].max() - feat[..., 1]
+    feat = np.ascontiguousarray(feat[..., list(order)])
+    want = po.oracle_filter(src, feat.reshape(-1, 5))
+    got, bands = rowtile.simulate(feat, torch.from_numpy(src), 3, OracleEngine, torch.device("cpu"))
+    assert bands[0].axis == list(order).index(1)
+    assert rel(got.numpy(), want) <= RTOL
+
+
+def test_loopback_bands_three_features():
+    from oracle import phl_oracle as po
+    from phl import rowtile
+    from _engines import OracleEngine
+
+    H, W, L = 60, 20, 2
+    feat, src = make_image(H, W, L, seed=9)
+    feat = np.ascontiguousarray(feat[..., :3])          # x, y, one colour: d = 3
+    want = po.oracle_filter(src, feat.reshape(-1, 3))
+    got, _ = rowtile.simulate(feat, torch.from_numpy(src), 3, OracleEngine, torch.device("cpu"))
+    assert rel(got.numpy(), want) <= RTOL
+
+
+def test_reach_is_not_generous(monkeypatch):
+    """Sending 25 % less than a_k + b_k breaks the iid-colour image: the bound that is shipped is the tight one."""
+    from oracle import phl_oracle as po
+    from phl import rowtile
+    from _engines import OracleEngine
+
+    H, W, L = 60, 24, 3
+    feat, src = make_image(H, W, L, iid_colour=True, seed=5)
+    want = po.oracle_filter(src, feat.reshape(-1, 5))
+    monkeypatch.setattr(rowtile, "_REACH_SCALE", 0.75)
+    got, _ = rowtile.simulate(feat, torch.from_numpy(src), 2, OracleEngine, torch.device("cpu"))
+    assert rel(got.numpy(), want) > RTOL
 
 
 def test_too_many_ranks_is_rejected():
@@ -124,4 +196,4 @@ def test_two_ranks_over_gloo():
     got = np.concatenate([r[2] for r in res], 0)
     assert rel(got, want) <= RTOL
     info = res[0][3]["rowtile"]
-    assert info["strip_rows"] == 13 and info["exchange_bytes_per_step_per_rank"] > 0 and info["channel_groups"] == 2
+    assert info["strip_rows"] == 9 and info["exchange_bytes_per_step_per_rank"] > 0 and info["channel_groups"] == 2

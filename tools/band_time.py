@@ -3,7 +3,7 @@ process (loopback), then time ONE interior band's filter call (splat -> pack bou
 neighbours' rows -> blur -> slice) with the exchange replaced by local copies.  Reports host time
 (python + launches) and GPU time per call for 1 and 2 channel groups.
 
-  python tools/band_time.py [world] [rank]
+  python tools/band_time.py [world] [rank] [groups,groups,...]
 """
 import os
 import sys
@@ -31,7 +31,7 @@ src = bench.synthetic_values(torch, b.own_rows, W, L, b.row0, dev)
 print(f"world {world} rank {rank}: rows {b.own_rows}, S {b.S}, n_local {b.n_local}, M(+ghosts) {b.M}, "
       f"recv rows {[b.recv_rows(p) for p in b.sides]}, send rows {[int(s['send_idx'].numel()) for s in b.sides.values()]}")
 
-for groups in (1, 2, 4):
+for groups in ([int(g) for g in sys.argv[3].split(',')] if len(sys.argv) > 3 else (1, 2, 4)):
     cuts = [(g * L // groups, (g + 1) * L // groups) for g in range(groups)]
     b.eng.reserve(max(c1 - c0 for c0, c1 in cuts))
     res = torch.empty((b.n_local, L), device=dev)
