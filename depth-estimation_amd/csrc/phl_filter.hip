@@ -289,6 +289,7 @@ inline int pick_lpr(int vd, int vec)
 {
     const int need = (vd + vec - 1) / vec;
     if (need >= 64) return 64;
+    if (need >= 32) return 32;      // vd = 128: one pass per row instead of two half-width ones
     if (need >= 16) return 16;
     if (need >= 4) return 4;
     return 1;
@@ -309,6 +310,7 @@ inline void dispatch_lpr(int lpr, F &&f)
 {
     switch (lpr) {
         case 64: f(std::integral_constant<int, 64>{}); break;
+        case 32: f(std::integral_constant<int, 32>{}); break;
         case 16: f(std::integral_constant<int, 16>{}); break;
         case 4: f(std::integral_constant<int, 4>{}); break;
         default: f(std::integral_constant<int, 1>{}); break;

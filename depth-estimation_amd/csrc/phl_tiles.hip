@@ -255,6 +255,25 @@ __device__ __forceinline__ float4 fma4(float4 acc, float w, float4 v)
                        __builtin_fmaf(w, v.w, acc.w));
 }
 
+// lane K of every 16-lane DPP row, to all lanes of that row (v_mov_b32_dpp row_newbcast:K -- VALU, no LDS traffic)
+#define PHL_ROW_BCAST(x, K) ((unsigned)__builtin_amdgcn_update_dpp(0, (int)(x), 0x150 + (K), 0xF, 0xF, false))
+
+// Eight consecutive entries of a segment, held one per lane in lanes K0..K0+7 of each DPP row (e.x = byte offset
+// of the pixel's LDS row, e.y = weight bits): broadcast each, issue the eight 16-byte row reads back to
+// back (one LDS round trip for all of them), then accumulate in entry order.
+template <int K0>
+__device__ __forceinline__ float4 sum8(float4 acc, const uint2 e, const char *rbase)
+{
+    float4 q[8];
+    unsigned w[8];
+#define PHL_E(k) w[k] = PHL_ROW_BCAST(e.y, K0 + k); q[k] = *reinterpret_cast<const float4 *>(rbase + PHL_ROW_BCAST(e.x, K0 + k));
+    PHL_E(0) PHL_E(1) PHL_E(2) PHL_E(3) PHL_E(4) PHL_E(5) PHL_E(6) PHL_E(7)
+#undef PHL_E
+#pragma unroll
+    for (int k = 0; k < 8; k++) acc = fma4(acc, __uint_as_float(w[k]), q[k]);
+    return acc;
+}
+
 // One workgroup (TPB threads) per chunk.  LPRS lanes own one row of a channel slab of
 // SL = 4*LPRS floats.  LDS: [rows x SL] staged rows | per-entry {LDS byte offset, weight} |
 // chunk pixel ids | local segment pointers | destination of each local vertex.  Index data
@@ -272,7 +291,8 @@ __global__ __launch_bounds__(TPB_S) void k_splat_tiled(const float *__restrict__
                                                      const int *__restrict__ vptr, const int *__restrict__ slot_vert,
                                                      const int *__restrict__ slot_pidx, const int2 *__restrict__ seg_rng,
                                                      const phl_contrib_t *__restrict__ seg, float *__restrict__ vert,
-                                                     float *__restrict__ partial, int nchunks, int xcd_chunk)
+                                                     float *__restrict__ partial, int nchunks, int xcd_chunk,
+                                                     unsigned long long *__restrict__ tl)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int SL = LPRS * 4;
@@ -286,13 +306,19 @@ __global__ __launch_bounds__(TPB_S) void k_splat_tiled(const float *__restrict__
     // XCD-aware chunk order (see k_blur): neighbouring chunks share boundary vertices
     const int c = xcd_chunk > 0 ? (int)(blockIdx.x & 7) * xcd_chunk + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
     if (c >= nchunks) return;
+    // debug timeline (PHL_TIMELINE=file): 100 MHz wall-clock stamps per workgroup, tl == nullptr in normal runs
+    unsigned long long *tlb = tl ? tl + (size_t)blockIdx.x * 8 : nullptr;
+    if (tlb && threadIdx.x == 0) {
+        tlb[0] = wall_clock64();
+        tlb[7] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | __builtin_amdgcn_s_getreg((31 << 11) | 4);
+    }
     const int base = c * P;
     const int cnt = min(P, n - base);
     const int E = cnt * dp1;
     const int64_t ebase = (int64_t)base * dp1;
     const int vbase = vptr[c], nv = vptr[c + 1] - vbase;
-    float *rows = lds;
-    uint2 *ent = reinterpret_cast<uint2 *>(lds + (size_t)P * SL);
+    float *rows = lds;                                             // [P][SL] staged pixel rows + one row of zeros
+    uint2 *ent = reinterpret_cast<uint2 *>(lds + (size_t)(P + 1) * SL);
     int4 *meta = reinterpret_cast<int4 *>(ent + P * dp1);          // [nv_cap] {seg begin, seg end, slot_vert, slot_pidx}
     int *pixl = reinterpret_cast<int *>(meta + nv_cap);           // [P]
     int *ctr = pixl + P;                                           // two work counters, used by alternate slabs
@@ -316,6 +342,7 @@ __global__ __launch_bounds__(TPB_S) void k_splat_tiled(const float *__restrict__
         meta[i] = make_int4((int)(seg_rng[vbase + i].x - ebase), (int)(seg_rng[vbase + i].y - ebase), slot_vert[vbase + i],
                             slot_pidx[vbase + i]);
     if (threadIdx.x < 2) ctr[threadIdx.x] = NW;
+    if (threadIdx.x < LPRS) st4(rows + (size_t)P * SL + threadIdx.x * 4, make_float4(0.f, 0.f, 0.f, 0.f));
     {
         const bool chok = l * 4 < vd;
         const int chc = chok ? l * 4 : 0;
@@ -340,6 +367,7 @@ __global__ __launch_bounds__(TPB_S) void k_splat_tiled(const float *__restrict__
         const bool chok = ch < vd;
         __syncthreads();                   // rows of this slab are in LDS
         const int slab = c0 / SL;
+        if (tlb && threadIdx.x == 0 && slab < 2) tlb[1 + 2 * slab] = wall_clock64();
         if (threadIdx.x == 0) ctr[(slab + 1) & 1] = NW;   // re-arm the other counter for the next slab
         const int chn = ch + SL;
         const bool more = c0 + SL < vd;    // wave-uniform
@@ -365,6 +393,30 @@ __global__ __launch_bounds__(TPB_S) void k_splat_tiled(const float *__restrict__
             const int s1 = m.y;
             float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
             int s = m.x;
+            if constexpr (LPRS >= 16) {
+                // A lane group is one or more whole 16-lane DPP rows.  Each row keeps SIXTEEN entries of its
+                // vertex's segment in registers, one per lane (a single 8-byte LDS read per lane), and hands
+                // them round with row broadcasts; the row reads of eight entries are in flight together.
+                // The trip count is the longest of the wave's segments, so the loop is wave-uniform; a
+                // shorter segment pads with weight 0 on the row of zeros.
+                const int len = s1 - s;
+                int lmax = __builtin_amdgcn_readlane(len, 0);
+                if (Q > 1) lmax = max(lmax, __builtin_amdgcn_readlane(len, 32));
+                if (Q > 2) lmax = max(max(lmax, __builtin_amdgcn_readlane(len, 16)), __builtin_amdgcn_readlane(len, 48));
+                const int r16 = lane & 15;
+                const unsigned zoff = (unsigned)P * SL * 4;
+                const int elast = E - 1;
+                uint2 e = ent[min(s + r16, elast)];
+                if (s + r16 >= s1) e = make_uint2(zoff, 0u);
+                for (int b = 0; b < lmax; b += 16) {
+                    const int nx = s + b + 16 + r16;
+                    uint2 en = ent[min(nx, elast)];              // next sixteen, under this batch's work
+                    if (nx >= s1) en = make_uint2(zoff, 0u);
+                    acc = sum8<0>(acc, e, rbase);
+                    if (b + 8 < lmax) acc = sum8<8>(acc, e, rbase);
+                    e = en;
+                }
+            } else {
             // software pipeline: the index reads of batch b+1 are issued before the row reads of
             // batch b are consumed, so a batch costs one LDS round trip instead of two (LDS returns
             // in order: waiting for the rows leaves the next indices in flight)
@@ -396,6 +448,7 @@ __global__ __launch_bounds__(TPB_S) void k_splat_tiled(const float *__restrict__
                 const uint2 e0 = ent[s];
                 acc = fma4(acc, __uint_as_float(e0.y), *reinterpret_cast<const float4 *>(rbase + e0.x));
             }
+            }
             if (i < nv && chok) {
                 float *dst = m.z < 0 ? vert + (int64_t)(m.z & 0x7FFFFFFF) * vd : partial + (int64_t)m.w * vd;
                 st4(dst + ch, acc);
@@ -403,6 +456,8 @@ __global__ __launch_bounds__(TPB_S) void k_splat_tiled(const float *__restrict__
             gi = __builtin_amdgcn_readfirstlane(nxt);
         }
         __syncthreads();                   // everyone is done reading this slab
+        if (tlb && threadIdx.x == 0 && slab < 2) tlb[2 + 2 * slab] = wall_clock64();
+        if (tlb && threadIdx.x == 0 && !more) tlb[5] = wall_clock64();
         if (more) {
 #pragma unroll
             for (int u = 0; u < PF; u++)
@@ -870,7 +925,7 @@ int phl_tiles_build(phl_lattice *lat, const float *ref, int64_t rs, int64_t cs, 
 int phl_tiles_lprs(const phl_lattice *lat, int vd, int for_slice)
 {
     if (lat->nchunks == 0 || vd % 4 != 0) return -1;
-    return pick_lprs(vd, for_slice ? lat->nv_max : lat->P, lds_extra(lat->P, lat->d + 1, lat->nv_max));
+    return pick_lprs(vd, for_slice ? lat->nv_max : lat->P + 1, lds_extra(lat->P, lat->d + 1, lat->nv_max));
 }
 
 int phl_tiles_reserve(phl_lattice *lat, int vd)
@@ -890,24 +945,41 @@ int phl_launch_splat_tiled(phl_lattice *lat, const float *src, int64_t src_rs, i
     const int M = (int)lat->M;
     if (M == 0 || vd == 0) return PHL_OK;
     const int64_t extra = lds_extra(lat->P, lat->d + 1, lat->nv_max);
-    const int lprs = pick_lprs(vd, lat->P, extra);
+    const int lprs = pick_lprs(vd, lat->P + 1, extra);      // + the row of zeros
     if (lprs < 0) {
         phl_set_error("tiled splat: chunk does not fit LDS");
         return PHL_ERR_UNSUPPORTED;
     }
     int rc = phl_tiles_reserve(lat, vd);
     if (rc) return rc;
-    const size_t lds = (size_t)lat->P * lprs * 16 + (size_t)extra;
+    const size_t lds = (size_t)(lat->P + 1) * lprs * 16 + (size_t)extra;
     unsigned cgrid;
     int xcd_chunk;
     chunk_grid(lat->nchunks, &cgrid, &xcd_chunk);
+    static const char *tl_path = getenv("PHL_TIMELINE");     // debug: dump per-workgroup time stamps of this launch
+    unsigned long long *tl = nullptr;
+    const size_t tl_n = (size_t)cgrid * 8;
+    if (tl_path) {
+        PHL_HIP(hipMalloc((void **)&tl, tl_n * 8));
+        PHL_HIP(hipMemsetAsync(tl, 0, tl_n * 8, st));
+    }
     dispatch_lprs(lprs, [&](auto L) {
         constexpr int LPRS = decltype(L)::value;
         if ((rc = allow_lds(k_splat_tiled<LPRS>, lds)) != PHL_OK) return;
         k_splat_tiled<LPRS><<<dim3(cgrid), dim3(TPB_S), lds, st>>>(
             src, src_rs, vd, (int)lat->n, lat->P, lat->d + 1, lat->nv_max, lat->pix_order, lat->chunk_vptr, lat->slot_vert,
-            lat->slot_pidx, lat->seg_rng, lat->seg, vert, lat->partial, lat->nchunks, xcd_chunk);
+            lat->slot_pidx, lat->seg_rng, lat->seg, vert, lat->partial, lat->nchunks, xcd_chunk, tl);
     });
+    if (tl) {
+        std::vector<unsigned long long> h(tl_n);
+        PHL_HIP(hipMemcpyAsync(h.data(), tl, tl_n * 8, hipMemcpyDeviceToHost, st));
+        PHL_HIP(hipStreamSynchronize(st));
+        (void)hipFree(tl);
+        if (FILE *f = fopen(tl_path, "wb")) {
+            fwrite(h.data(), 8, tl_n, f);
+            fclose(f);
+        }
+    }
     if (rc) return rc;
     const int lpr = pick_lpr_row(vd);
     int64_t waves = ((int64_t)M + (64 / lpr) - 1) / (64 / lpr);

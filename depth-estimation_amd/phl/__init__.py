@@ -104,6 +104,9 @@ def _as_device(t, device):
     return t if t.device == device else t.to(device)
 
 
+_parked = []    # lattice handles whose owner died during a stream capture; freed by the next close()
+
+
 class Lattice:
     """Permutohedral lattice of a feature tensor ``ref`` [n, d] (fp32, any strides).
 
@@ -132,7 +135,14 @@ class Lattice:
         h, self._h = getattr(self, "_h", None), None
         if h and _lib is not None:          # at interpreter shutdown the module globals may be gone
             try:
+                # phl_destroy hipFree()s; inside a stream capture that would invalidate the capture
+                # (a garbage-collected Lattice can land here at any time), so park the handle instead
+                if torch.cuda.is_current_stream_capturing():
+                    _parked.append(h)
+                    return
                 _lib.phl_destroy(h)
+                while _parked:
+                    _lib.phl_destroy(_parked.pop())
             except Exception:
                 pass
 

@@ -84,6 +84,8 @@ int phl_device_count(void);
  * numbering the reference's insertion-ordered hash table produces (permutohedral.h:70-77). */
 int phl_build(phl_lattice **out, const float *ref_dev, int64_t n, int d, int64_t ref_row_stride,
               int64_t ref_col_stride, int device, phl_stream stream);
+/* Frees device memory (hipFree): like any free it must not run while a stream capture is in
+ * progress on the device (the Python binding parks handles that die during a capture). */
 int phl_destroy(phl_lattice *lat);
 
 int64_t phl_num_pixels(const phl_lattice *lat);

@@ -353,9 +353,11 @@ def test_filter_is_graph_capturable(phl):
     Lat.filter(x, out=out)                       # warm-up outside the capture
     want1 = out.clone()
     torch.cuda.synchronize()
+    dead = phl.Lattice(torch.from_numpy(ref[:500]).cuda())
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g):
         Lat.filter(x, out=out)
+        del dead                                  # a lattice dying mid-capture (gc) must not invalidate it
     x.copy_(torch.rand((n, L), device="cuda"))   # new values in the captured input buffer
     g.replay()
     torch.cuda.synchronize()

@@ -31,6 +31,7 @@ src = bench.synthetic_values(torch, b.own_rows, W, L, b.row0, dev)
 print(f"world {world} rank {rank}: rows {b.own_rows}, S {b.S}, n_local {b.n_local}, M(+ghosts) {b.M}, "
       f"recv rows {[b.recv_rows(p) for p in b.sides]}, send rows {[int(s['send_idx'].numel()) for s in b.sides.values()]}")
 
+print("band tiles:", b.eng.tile_stats(L))
 for groups in ([int(g) for g in sys.argv[3].split(',')] if len(sys.argv) > 3 else (1, 2, 4)):
     cuts = [(g * L // groups, (g + 1) * L // groups) for g in range(groups)]
     b.eng.reserve(max(c1 - c0 for c0, c1 in cuts))
@@ -65,6 +66,7 @@ ref = torch.from_numpy(feat.reshape(-1, 5)).to(dev)
 full = bench.synthetic_values(torch, H, W, L, 0, dev)
 lat = phl.Lattice(ref)
 lat.reserve(L)
+print("full tiles:", lat.tile_stats(L))
 o = torch.empty_like(full)
 for _ in range(3):
     lat.filter(full, out=o)
