@@ -184,7 +184,7 @@ int phl_destroy(phl_lattice *lat)
     if (!lat) return PHL_OK;
     device_guard g(lat->device);
     phl_tiles_free(lat);
-    void *ptrs[] = {lat->vkeys, lat->replay, lat->csr_ptr, lat->csr, lat->nbr, lat->table, lat->buf[0], lat->buf[1], lat->stage_in, lat->stage_out};
+    void *ptrs[] = {lat->vkeys, lat->replay, lat->csr_ptr, lat->csr, lat->nbr, lat->nbr2, lat->table, lat->buf[0], lat->buf[1], lat->stage_in, lat->stage_out};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     delete lat;
@@ -274,6 +274,38 @@ int phl_blur_axis(phl_lattice *lat, int axis, const float *vin, float *vout, int
     return phl_launch_blur(lat, axis, vin, vout, vd, (hipStream_t)st);
 }
 
+// all blur axes, two per pass where a pair is left; returns the index (0/1) of the buffer holding the result
+static int blur_all(const phl_lattice *lat, float *const buf[2], int vd, hipStream_t st, int *cur_out)
+{
+    static const bool pairs = !(getenv("PHL_BLUR_PAIRS") && atoi(getenv("PHL_BLUR_PAIRS")) == 0);
+    int cur = 0;
+    for (int axis = 0; axis <= lat->d;) {  // axis order 0..d, Jacobi ping-pong (:498, :530-532)
+        int rc;
+        if (pairs && axis + 1 <= lat->d && lat->nbr2) {
+            rc = phl_launch_blur2(lat, axis / 2, buf[cur], buf[cur ^ 1], vd, st);
+            axis += 2;
+        } else {
+            rc = phl_launch_blur(lat, axis, buf[cur], buf[cur ^ 1], vd, st);
+            axis += 1;
+        }
+        if (rc) return rc;
+        cur ^= 1;
+    }
+    *cur_out = cur;
+    return PHL_OK;
+}
+
+int phl_blur(phl_lattice *lat, float *vert_a, float *vert_b, int vd, int *result_in_b, phl_stream st)
+{
+    if (!lat || vd < 0 || !result_in_b || vert_a == vert_b || (lat->M > 0 && vd > 0 && (!vert_a || !vert_b))) {
+        phl_set_error("phl_blur: bad arguments");
+        return PHL_ERR_INVALID;
+    }
+    device_guard g(lat->device);
+    float *const buf[2] = {vert_a, vert_b};
+    return blur_all(lat, buf, vd, (hipStream_t)st, result_in_b);
+}
+
 int phl_slice(phl_lattice *lat, const float *vert, int vd, float *out, int64_t out_rs, const float *sub, int64_t sub_rs,
               unsigned flags, phl_stream st)
 {
@@ -330,11 +362,8 @@ int phl_filter(phl_lattice *lat, const float *src, int vd, int64_t src_rs, int64
     else rc = phl_launch_splat(lat, src_eff, src_eff_rs, vd, lat->buf[0], st);
     if (rc) return rc;
     int cur = 0;
-    for (int axis = 0; axis <= lat->d; axis++) {  // axis order 0..d, Jacobi ping-pong (:498, :530-532)
-        rc = phl_launch_blur(lat, axis, lat->buf[cur], lat->buf[cur ^ 1], vd, st);
-        if (rc) return rc;
-        cur ^= 1;
-    }
+    rc = blur_all(lat, lat->buf, vd, st, &cur);
+    if (rc) return rc;
     const float *sub = (flags & PHL_FILTER_SUBTRACT_INPUT) ? src_eff : nullptr;
     if (use_tiled_slice(lat, vd, flags, lat->buf[cur], out_eff, sub, out_eff_rs, sub ? src_eff_rs : 0))
         rc = phl_launch_slice_tiled(lat, lat->buf[cur], vd, out_eff, out_eff_rs, sub, src_eff_rs, flags, st);

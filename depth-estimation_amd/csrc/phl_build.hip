@@ -279,6 +279,25 @@ __global__ __launch_bounds__(256) void k_neighbors(const int16_t *__restrict__ v
     nbr[idx * 2 + 1] = res[1];
 }
 
+// Neighbour ids for blurring along axes a = 2p and b = 2p+1 in ONE pass (k_blur2):
+//   out[v] = blur_b(blur_a(in))[v] needs in[] at  a-(u), u, a+(u)  for u in { b-(v), v, b+(v) }.
+// Stored per vertex: { a-(b-), b-, a+(b-), a-(v) | a+(v), a-(b+), b+, a+(b+) }, -1 = absent.
+__global__ __launch_bounds__(256) void k_compose_pairs(const int2 *__restrict__ nbr, int M, int npairs, int4 *__restrict__ nbr2)
+{
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)M * npairs) return;
+    const int p = (int)(idx / M);
+    const int v = (int)(idx - (int64_t)p * M);
+    const int2 *na = nbr + (int64_t)(2 * p) * M;
+    const int2 nb = nbr[(int64_t)(2 * p + 1) * M + v];
+    const int2 none = make_int2(-1, -1);
+    const int2 am = nb.x >= 0 ? na[nb.x] : none;
+    const int2 a0 = na[v];
+    const int2 ap = nb.y >= 0 ? na[nb.y] : none;
+    nbr2[idx * 2 + 0] = make_int4(am.x, nb.x, am.y, a0.x);
+    nbr2[idx * 2 + 1] = make_int4(a0.y, ap.x, nb.y, ap.y);
+}
+
 // (re)build the persistent key -> vertex table from the distinct vertex keys
 __global__ __launch_bounds__(256) void k_table_insert(const int16_t *__restrict__ vkeys, int d, int M, int *table,
                                                       uint32_t mask)
@@ -345,8 +364,10 @@ static int phl_rebuild_table_and_neighbors(phl_lattice *lat, hipStream_t st)
     const int M = (int)lat->M;
     if (lat->table) PHL_HIP(hipFree(lat->table));
     if (lat->nbr) PHL_HIP(hipFree(lat->nbr));
+    if (lat->nbr2) PHL_HIP(hipFree(lat->nbr2));
     lat->table = nullptr;
     lat->nbr = nullptr;
+    lat->nbr2 = nullptr;
     uint64_t cap = 1024;
     while (cap < (uint64_t)M * 2) cap <<= 1;
     lat->table_mask = (uint32_t)(cap - 1);
@@ -359,6 +380,11 @@ static int phl_rebuild_table_and_neighbors(phl_lattice *lat, hipStream_t st)
         const int64_t tot = (int64_t)M * (d + 1);
         hipLaunchKernelGGL(k_neighbors, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, lat->vkeys, d, M,
                            lat->table, lat->table_mask, lat->nbr);
+        const int npairs = (d + 1) / 2;
+        PHL_HIP(hipMalloc((void **)&lat->nbr2, sizeof(int32_t) * (size_t)M * npairs * 8));
+        const int64_t totp = (int64_t)M * npairs;
+        hipLaunchKernelGGL(k_compose_pairs, dim3((unsigned)((totp + 255) / 256)), dim3(256), 0, st,
+                           reinterpret_cast<const int2 *>(lat->nbr), M, npairs, reinterpret_cast<int4 *>(lat->nbr2));
     }
     PHL_HIP(hipGetLastError());
     return PHL_OK;

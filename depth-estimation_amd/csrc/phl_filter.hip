@@ -207,6 +207,58 @@ __global__ __launch_bounds__(256) void k_blur(const float *__restrict__ vin, flo
 }
 
 // ------------------------------------------------------------------------------------------
+// Two consecutive blur axes (a = 2p, then b = 2p+1) in one pass: every value the second blur reads
+// is recomputed from the input with the first blur's own expression, so the result is bit-identical
+// to two k_blur passes while the vertex array is read and written once instead of twice.
+// ids per vertex (k_compose_pairs): { a-(b-), b-, a+(b-), a-(v) | a+(v), a-(b+), b+, a+(b+) }.
+template <int VEC, int LPR>
+__global__ __launch_bounds__(256) void k_blur2(const float *__restrict__ vin, float *__restrict__ vout,
+                                               const int4 *__restrict__ nb2, int M, int vd, int xcd_chunk)
+{
+    using V = typename vec_of<VEC>::type;
+    constexpr int G = 64 / LPR;
+    constexpr int U = 2;  // row groups in flight per wave (9 row loads each)
+    const int lane = threadIdx.x & 63;
+    const int sub = lane / LPR;
+    const int l = lane % LPR;
+    const int lb = xcd_chunk > 0 ? (int)(blockIdx.x & 7) * xcd_chunk + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    const int wv = lb * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int64_t v0 = (int64_t)wv * G * U;
+    if (v0 >= M) return;
+    int64_t v[U];
+    int id[U][8];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        v[u] = v0 + u * G + sub;
+        const int64_t vc = v[u] < M ? v[u] : (int64_t)M - 1;
+        const int4 i0 = nb2[vc * 2], i1 = nb2[vc * 2 + 1];
+        id[u][0] = i0.x; id[u][1] = i0.y; id[u][2] = i0.z; id[u][3] = i0.w;
+        id[u][4] = i1.x; id[u][5] = i1.y; id[u][6] = i1.z; id[u][7] = i1.w;
+    }
+    for (int c = l * VEC; c < vd; c += LPR * VEC) {
+        V x[U][8], s[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {   // unconditional loads from clamped rows (see k_blur)
+            const int64_t vc = v[u] < M ? v[u] : (int64_t)M - 1;
+            s[u] = vload(vin + vc * vd + c, V());
+#pragma unroll
+            for (int k = 0; k < 8; k++) x[u][k] = vload(vin + (int64_t)max(id[u][k], 0) * vd + c, V());
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+#pragma unroll
+            for (int k = 0; k < 8; k++)
+                if (id[u][k] < 0) x[u][k] = vzero<VEC>();
+            // absent b-neighbour: the reference reads a row of zeros there (:516-522)
+            const V tm = id[u][1] >= 0 ? blur3(x[u][0], x[u][1], x[u][2]) : vzero<VEC>();
+            const V t0 = blur3(x[u][3], s[u], x[u][4]);
+            const V tp = id[u][6] >= 0 ? blur3(x[u][5], x[u][6], x[u][7]) : vzero<VEC>();
+            if (v[u] < M) vstore(vout + v[u] * vd + c, blur3(tm, t0, tp));
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // slice: out[p][:] = sum_{r<=d} w_r * vert[v_r][:] / (1 + 2^-d)   [ - sub[p][:] ]
 template <int VEC, int LPR, bool EXACT>
 __global__ __launch_bounds__(256) void k_slice(const float *__restrict__ vert, int vd,
@@ -365,6 +417,31 @@ int phl_launch_blur(const phl_lattice *lat, int axis, const float *vin, float *v
         constexpr int LPR = decltype(L)::value;
         if (v4) k_blur<4, LPR><<<dim3(grid), dim3(256), 0, st>>>(vin, vout, nbr, M, vd, xcd_chunk);
         else k_blur<1, LPR><<<dim3(grid), dim3(256), 0, st>>>(vin, vout, nbr, M, vd, xcd_chunk);
+    });
+    PHL_HIP(hipGetLastError());
+    return PHL_OK;
+}
+
+int phl_launch_blur2(const phl_lattice *lat, int pair, const float *vin, float *vout, int vd, hipStream_t st)
+{
+    const int M = (int)lat->M;
+    if (M == 0 || vd == 0) return PHL_OK;
+    const int4 *nb2 = reinterpret_cast<const int4 *>(lat->nbr2) + (int64_t)pair * M * 2;
+    const bool v4 = (vd % 4 == 0) && aligned16(vin) && aligned16(vout);
+    const int lpr = pick_lpr(vd, v4 ? 4 : 1);
+    const int rows_per_block = (64 / lpr) * 2 * 4;
+    int64_t blocks = ((int64_t)M + rows_per_block - 1) / rows_per_block;
+    static const bool xcd = !(getenv("PHL_XCD") && atoi(getenv("PHL_XCD")) == 0);
+    int xcd_chunk = 0;
+    if (xcd && blocks >= 64) {
+        blocks = (blocks + 7) / 8 * 8;
+        xcd_chunk = (int)(blocks / 8);
+    }
+    const unsigned grid = (unsigned)blocks;
+    dispatch_lpr(lpr, [&](auto L) {
+        constexpr int LPR = decltype(L)::value;
+        if (v4) k_blur2<4, LPR><<<dim3(grid), dim3(256), 0, st>>>(vin, vout, nb2, M, vd, xcd_chunk);
+        else k_blur2<1, LPR><<<dim3(grid), dim3(256), 0, st>>>(vin, vout, nb2, M, vd, xcd_chunk);
     });
     PHL_HIP(hipGetLastError());
     return PHL_OK;

@@ -33,6 +33,7 @@ struct phl_lattice {
     int32_t *csr_ptr;       // [M+1]
     phl_contrib_t *csr;     // [N] grouped by vertex, pixel-ascending inside a group
     int32_t *nbr;           // [d+1][M][2]
+    int32_t *nbr2;          // [(d+1)/2][M][8] composed neighbour ids of axis pairs (2p, 2p+1), see k_blur2
     int *table;             // open-addressing key -> -(vid+1), PHL_EMPTY = free; kept for phl_add_vertices
     uint32_t table_mask;
     int64_t M_local;        // vertices created by this lattice's own pixels (ghosts come after)
@@ -98,6 +99,7 @@ int phl_launch_slice_tiled(const phl_lattice *lat, const float *vert, int vd, fl
 // ---- launchers implemented in phl_filter.hip ----
 int phl_launch_splat(phl_lattice *lat, const float *src, int64_t src_rs, int vd, float *vert, hipStream_t st);
 int phl_launch_blur(const phl_lattice *lat, int axis, const float *vin, float *vout, int vd, hipStream_t st);
+int phl_launch_blur2(const phl_lattice *lat, int pair, const float *vin, float *vout, int vd, hipStream_t st);
 int phl_launch_slice(const phl_lattice *lat, const float *vert, int vd, float *out, int64_t out_rs,
                      const float *sub, int64_t sub_rs, unsigned flags, hipStream_t st);
 // generic strided 2-D copy dst[r*drs + c*dcs] = src[r*srs + c*scs], rows x cols

@@ -650,6 +650,8 @@ int lds_budget()
 
 // bytes of index data staged next to the rows (entries, pixel ids, local pointers)
 inline int64_t lds_extra(int P, int dp1, int nv_max) { return (int64_t)P * dp1 * 8 + (int64_t)P * 4 + ((int64_t)nv_max + 1) * 16 + 16 + 256; }
+// k_slice_tiled keeps less: entries, pixel ids, one vertex id per local vertex
+inline int64_t lds_extra_slice(int P, int dp1, int nv_max) { return (int64_t)P * dp1 * 8 + (int64_t)P * 4 + ((int64_t)nv_max + 4) * 4; }
 
 // lanes (of 4 floats) per slab row: as wide as vd, narrowed until `rows` rows + index data fit
 // in LDS; -1 if even the narrowest slab does not fit
@@ -925,7 +927,8 @@ int phl_tiles_build(phl_lattice *lat, const float *ref, int64_t rs, int64_t cs, 
 int phl_tiles_lprs(const phl_lattice *lat, int vd, int for_slice)
 {
     if (lat->nchunks == 0 || vd % 4 != 0) return -1;
-    return pick_lprs(vd, for_slice ? lat->nv_max : lat->P + 1, lds_extra(lat->P, lat->d + 1, lat->nv_max));
+    return for_slice ? pick_lprs(vd, lat->nv_max, lds_extra_slice(lat->P, lat->d + 1, lat->nv_max))
+                     : pick_lprs(vd, lat->P + 1, lds_extra(lat->P, lat->d + 1, lat->nv_max));
 }
 
 int phl_tiles_reserve(phl_lattice *lat, int vd)
@@ -1003,7 +1006,7 @@ int phl_launch_slice_tiled(const phl_lattice *lat, const float *vert, int vd, fl
                            int64_t sub_rs, unsigned flags, hipStream_t st)
 {
     if (lat->n == 0 || vd == 0) return PHL_OK;
-    const int64_t extra = lds_extra(lat->P, lat->d + 1, lat->nv_max);
+    const int64_t extra = lds_extra_slice(lat->P, lat->d + 1, lat->nv_max);
     const int lprs = pick_lprs(vd, lat->nv_max, extra);
     if (lprs < 0) {
         phl_set_error("tiled slice: chunk does not fit LDS");

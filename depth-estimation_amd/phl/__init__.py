@@ -71,6 +71,7 @@ def load_library():
         lib.phl_splat.argtypes = [vp, vp, i32, i64, vp, u32, vp]
         lib.phl_tile_stats.argtypes = [vp, i32, vp]
         lib.phl_blur_axis.argtypes = [vp, i32, vp, vp, i32, vp]
+        lib.phl_blur.argtypes = [vp, vp, vp, i32, C.POINTER(i32), vp]
         lib.phl_slice.argtypes = [vp, vp, i32, vp, i64, vp, i64, u32, vp]
         lib.phl_softmax_neg_add.argtypes = [vp, i64, vp, i64, vp, i64, i64, i32, vp]
         lib.phl_expected_value.argtypes = [vp, i64, vp, vp, i64, i32, vp]
@@ -201,12 +202,15 @@ class Lattice:
                                                 C.c_void_p(vout.data_ptr()), vd, _stream(self.device)))
         return vout
 
-    def blur(self, vert):
-        a, b = vert, torch.empty_like(vert)
-        for axis in range(self.d + 1):
-            self.blur_axis(axis, a, b)
-            a, b = b, a
-        return a
+    def blur(self, vert, scratch=None):
+        """All d+1 axes (two per pass).  ``vert`` is overwritten (it is one of the two ping-pong buffers)."""
+        other = torch.empty_like(vert) if scratch is None else scratch
+        assert vert.is_contiguous() and other.is_contiguous() and other.shape == vert.shape
+        which = C.c_int(0)
+        with torch.cuda.device(self.device):
+            _check(load_library().phl_blur(self._h, C.c_void_p(vert.data_ptr()), C.c_void_p(other.data_ptr()),
+                                           int(vert.shape[1]), C.byref(which), _stream(self.device)))
+        return other if which.value else vert
 
     def slice(self, vert, sub=None, exact=False, out=None, no_tiles=False):
         vd = int(vert.shape[1])

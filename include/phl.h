@@ -139,6 +139,11 @@ int phl_splat(phl_lattice *lat, const float *src_dev, int vd, int64_t src_row_st
 /* one blur axis, Jacobi: dst[v] = 2*(1/4 src[n1] + 1/2 src[v] + 1/4 src[n2])   (:498-533) */
 int phl_blur_axis(phl_lattice *lat, int axis, const float *vert_src_dev, float *vert_dst_dev, int vd,
                   phl_stream stream);
+/* blur(): all d+1 axes in order 0..d (:486-548), ping-ponging between the caller's two [M][vd]
+ * buffers (input in vert_a).  Consecutive axes are taken two per pass (same bits as two
+ * phl_blur_axis calls, half the traffic over the vertex array).  *result_in_b = 1 if the result
+ * ends up in vert_b, 0 if in vert_a. */
+int phl_blur(phl_lattice *lat, float *vert_a_dev, float *vert_b_dev, int vd, int *result_in_b, phl_stream stream);
 /* slice(): out[p] = sum_i w_i * vert[v_i] / (1 + 2^-d)                        (:473-483) */
 int phl_slice(phl_lattice *lat, const float *vert_dev, int vd, float *out_dev, int64_t out_row_stride,
               const float *sub_dev /* NULL or src to subtract */, int64_t sub_row_stride, unsigned flags,

@@ -340,6 +340,27 @@ def test_randomised_shapes_against_oracle(phl):
         assert scaled_err(sub + src, want) <= 1e-5, (trial, n, d, vd)
 
 
+@pytest.mark.parametrize("d", [1, 2, 3, 4, 5, 6])
+def test_fused_blur_equals_axis_by_axis(phl, d):
+    """phl_blur takes the axes two per pass (k_blur2) and a last single one when d+1 is odd: same bits as
+    d+1 phl_blur_axis calls, and as the CPU restatement."""
+    from oracle import phl_oracle as po
+
+    rng = np.random.default_rng(20 + d)
+    n, vd = 6000, 24
+    ref = np.cumsum(rng.random((n, d), dtype=np.float32) * 0.05, axis=0).astype(np.float32)
+    L = phl.Lattice(torch.from_numpy(ref).cuda())
+    v0 = torch.from_numpy(rng.standard_normal((L.M, vd)).astype(np.float32)).cuda()
+    a, b = v0.clone(), torch.empty_like(v0)
+    for axis in range(d + 1):
+        L.blur_axis(axis, a, b)
+        a, b = b, a
+    fused = L.blur(v0.clone())
+    assert torch.equal(fused, a)
+    want = po.Oracle(ref).blur(v0.cpu().numpy())
+    assert np.array_equal(fused.cpu().numpy().view(np.uint32), want.view(np.uint32))
+
+
 def test_filter_is_graph_capturable(phl):
     """After phl_reserve the filter launch sequence allocates nothing and never synchronises, so
     it can be captured into a HIP graph (torch.cuda.CUDAGraph) and replayed on new input values."""
