@@ -211,13 +211,12 @@ __global__ __launch_bounds__(256) void k_blur(const float *__restrict__ vin, flo
 // is recomputed from the input with the first blur's own expression, so the result is bit-identical
 // to two k_blur passes while the vertex array is read and written once instead of twice.
 // ids per vertex (k_compose_pairs): { a-(b-), b-, a+(b-), a-(v) | a+(v), a-(b+), b+, a+(b+) }.
-template <int VEC, int LPR>
+template <int VEC, int LPR, int U>
 __global__ __launch_bounds__(256) void k_blur2(const float *__restrict__ vin, float *__restrict__ vout,
                                                const int4 *__restrict__ nb2, int M, int vd, int xcd_chunk)
 {
     using V = typename vec_of<VEC>::type;
     constexpr int G = 64 / LPR;
-    constexpr int U = 2;  // row groups in flight per wave (9 row loads each)
     const int lane = threadIdx.x & 63;
     const int sub = lane / LPR;
     const int l = lane % LPR;
@@ -429,7 +428,8 @@ int phl_launch_blur2(const phl_lattice *lat, int pair, const float *vin, float *
     const int4 *nb2 = reinterpret_cast<const int4 *>(lat->nbr2) + (int64_t)pair * M * 2;
     const bool v4 = (vd % 4 == 0) && aligned16(vin) && aligned16(vout);
     const int lpr = pick_lpr(vd, v4 ? 4 : 1);
-    const int rows_per_block = (64 / lpr) * 2 * 4;
+    constexpr int U2 = 1;   // row groups in flight per wave: 9 row loads each; 1 measured best (2: +3 %, 4: +15 %)
+    const int rows_per_block = (64 / lpr) * U2 * 4;
     int64_t blocks = ((int64_t)M + rows_per_block - 1) / rows_per_block;
     static const bool xcd = !(getenv("PHL_XCD") && atoi(getenv("PHL_XCD")) == 0);
     int xcd_chunk = 0;
@@ -440,8 +440,8 @@ int phl_launch_blur2(const phl_lattice *lat, int pair, const float *vin, float *
     const unsigned grid = (unsigned)blocks;
     dispatch_lpr(lpr, [&](auto L) {
         constexpr int LPR = decltype(L)::value;
-        if (v4) k_blur2<4, LPR><<<dim3(grid), dim3(256), 0, st>>>(vin, vout, nb2, M, vd, xcd_chunk);
-        else k_blur2<1, LPR><<<dim3(grid), dim3(256), 0, st>>>(vin, vout, nb2, M, vd, xcd_chunk);
+        if (v4) k_blur2<4, LPR, U2><<<dim3(grid), dim3(256), 0, st>>>(vin, vout, nb2, M, vd, xcd_chunk);
+        else k_blur2<1, LPR, U2><<<dim3(grid), dim3(256), 0, st>>>(vin, vout, nb2, M, vd, xcd_chunk);
     });
     PHL_HIP(hipGetLastError());
     return PHL_OK;
