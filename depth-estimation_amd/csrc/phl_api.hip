@@ -306,6 +306,18 @@ int phl_blur(phl_lattice *lat, float *vert_a, float *vert_b, int vd, int *result
     return blur_all(lat, buf, vd, (hipStream_t)st, result_in_b);
 }
 
+int phl_gather_rows(const float *vert, int vd, const int64_t *idx_dev, int64_t k, float *out, int64_t out_rs, phl_stream st)
+{
+    if (vd < 0 || k < 0 || (k > 0 && vd > 0 && (!vert || !idx_dev || !out))) { phl_set_error("phl_gather_rows: bad arguments"); return PHL_ERR_INVALID; }
+    return phl_launch_rows(false, const_cast<float *>(vert), vd, idx_dev, k, out, out_rs, (hipStream_t)st);
+}
+
+int phl_scatter_add_rows(float *vert, int vd, const int64_t *idx_dev, int64_t k, const float *in, int64_t in_rs, phl_stream st)
+{
+    if (vd < 0 || k < 0 || (k > 0 && vd > 0 && (!vert || !idx_dev || !in))) { phl_set_error("phl_scatter_add_rows: bad arguments"); return PHL_ERR_INVALID; }
+    return phl_launch_rows(true, vert, vd, idx_dev, k, const_cast<float *>(in), in_rs, (hipStream_t)st);
+}
+
 int phl_slice(phl_lattice *lat, const float *vert, int vd, float *out, int64_t out_rs, const float *sub, int64_t sub_rs,
               unsigned flags, phl_stream st)
 {

@@ -334,6 +334,36 @@ __global__ __launch_bounds__(256) void k_copy2d(const float *__restrict__ src, i
 }
 
 // ------------------------------------------------------------------------------------------
+// ------------------------------------------------------------------------------------------
+// Row-band exchange helpers (phl/rowtile.py): pack the boundary vertices' rows into one send
+// buffer / add the rows received from the neighbouring bands.  One row per LPR lanes.
+template <int LPR>
+__global__ __launch_bounds__(256) void k_gather_rows(const float *__restrict__ vert, int vd, const int64_t *__restrict__ idx,
+                                                     int64_t k, float *__restrict__ out, int64_t out_rs)
+{
+    constexpr int G = 64 / LPR;
+    const int lane = threadIdx.x & 63;
+    const int64_t r = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * G + lane / LPR;
+    if (r >= k) return;
+    const float *src = vert + idx[r] * vd;
+    for (int c = (lane % LPR) * 4; c < vd; c += LPR * 4) vstore(out + r * out_rs + c, vload(src + c, float4()));
+}
+
+template <int LPR>
+__global__ __launch_bounds__(256) void k_scatter_add_rows(float *__restrict__ vert, int vd, const int64_t *__restrict__ idx,
+                                                          int64_t k, const float *__restrict__ in, int64_t in_rs)
+{
+    constexpr int G = 64 / LPR;
+    const int lane = threadIdx.x & 63;
+    const int64_t r = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * G + lane / LPR;
+    if (r >= k) return;
+    float *dst = vert + idx[r] * vd;
+    for (int c = (lane % LPR) * 4; c < vd; c += LPR * 4) {
+        const float4 a = vload(dst + c, float4()), b = vload(in + r * in_rs + c, float4());
+        vstore(dst + c, make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w));
+    }
+}
+
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 inline int pick_lpr(int vd, int vec)
@@ -416,6 +446,24 @@ int phl_launch_blur(const phl_lattice *lat, int axis, const float *vin, float *v
         constexpr int LPR = decltype(L)::value;
         if (v4) k_blur<4, LPR><<<dim3(grid), dim3(256), 0, st>>>(vin, vout, nbr, M, vd, xcd_chunk);
         else k_blur<1, LPR><<<dim3(grid), dim3(256), 0, st>>>(vin, vout, nbr, M, vd, xcd_chunk);
+    });
+    PHL_HIP(hipGetLastError());
+    return PHL_OK;
+}
+
+int phl_launch_rows(bool scatter, float *vert, int vd, const int64_t *idx, int64_t k, float *buf, int64_t buf_rs, hipStream_t st)
+{
+    if (k == 0 || vd == 0) return PHL_OK;
+    if (vd % 4 || buf_rs % 4 || !aligned16(vert) || !aligned16(buf)) {
+        phl_set_error("row gather/scatter: needs vd %% 4 == 0 and 16-byte aligned rows");
+        return PHL_ERR_UNSUPPORTED;
+    }
+    const int lpr = pick_lpr(vd, 4);
+    const unsigned grid = (unsigned)((k + (64 / lpr) * 4 - 1) / ((64 / lpr) * 4));
+    dispatch_lpr(lpr, [&](auto L) {
+        constexpr int LPR = decltype(L)::value;
+        if (scatter) k_scatter_add_rows<LPR><<<dim3(grid), dim3(256), 0, st>>>(vert, vd, idx, k, buf, buf_rs);
+        else k_gather_rows<LPR><<<dim3(grid), dim3(256), 0, st>>>(vert, vd, idx, k, buf, buf_rs);
     });
     PHL_HIP(hipGetLastError());
     return PHL_OK;

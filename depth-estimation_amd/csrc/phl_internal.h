@@ -100,6 +100,7 @@ int phl_launch_slice_tiled(const phl_lattice *lat, const float *vert, int vd, fl
 int phl_launch_splat(phl_lattice *lat, const float *src, int64_t src_rs, int vd, float *vert, hipStream_t st);
 int phl_launch_blur(const phl_lattice *lat, int axis, const float *vin, float *vout, int vd, hipStream_t st);
 int phl_launch_blur2(const phl_lattice *lat, int pair, const float *vin, float *vout, int vd, hipStream_t st);
+int phl_launch_rows(bool scatter, float *vert, int vd, const int64_t *idx, int64_t k, float *buf, int64_t buf_rs, hipStream_t st);
 int phl_launch_slice(const phl_lattice *lat, const float *vert, int vd, float *out, int64_t out_rs,
                      const float *sub, int64_t sub_rs, unsigned flags, hipStream_t st);
 // generic strided 2-D copy dst[r*drs + c*dcs] = src[r*srs + c*scs], rows x cols

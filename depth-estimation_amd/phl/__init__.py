@@ -72,6 +72,8 @@ def load_library():
         lib.phl_tile_stats.argtypes = [vp, i32, vp]
         lib.phl_blur_axis.argtypes = [vp, i32, vp, vp, i32, vp]
         lib.phl_blur.argtypes = [vp, vp, vp, i32, C.POINTER(i32), vp]
+        lib.phl_gather_rows.argtypes = [vp, i32, vp, i64, vp, i64, vp]
+        lib.phl_scatter_add_rows.argtypes = [vp, i32, vp, i64, vp, i64, vp]
         lib.phl_slice.argtypes = [vp, vp, i32, vp, i64, vp, i64, u32, vp]
         lib.phl_softmax_neg_add.argtypes = [vp, i64, vp, i64, vp, i64, i64, i32, vp]
         lib.phl_expected_value.argtypes = [vp, i64, vp, vp, i64, i32, vp]
@@ -211,6 +213,26 @@ class Lattice:
             _check(load_library().phl_blur(self._h, C.c_void_p(vert.data_ptr()), C.c_void_p(other.data_ptr()),
                                            int(vert.shape[1]), C.byref(which), _stream(self.device)))
         return other if which.value else vert
+
+    def gather_rows(self, vert, idx, out=None):
+        """out[r] = vert[idx[r]] (idx: int64 device tensor).  Row-band exchange helper."""
+        k, vd = int(idx.numel()), int(vert.shape[1])
+        out = torch.empty((k, vd), dtype=torch.float32, device=self.device) if out is None else out
+        assert vert.is_contiguous() and idx.dtype == torch.int64 and idx.is_contiguous() and out.stride(1) == 1
+        with torch.cuda.device(self.device):
+            _check(load_library().phl_gather_rows(C.c_void_p(vert.data_ptr()), vd, C.c_void_p(idx.data_ptr()), k,
+                                                  C.c_void_p(out.data_ptr()), out.stride(0) if k else vd, _stream(self.device)))
+        return out
+
+    def scatter_add_rows(self, vert, idx, rows):
+        """vert[idx[r]] += rows[r]; idx must hold distinct vertex ids."""
+        k, vd = int(idx.numel()), int(vert.shape[1])
+        assert vert.is_contiguous() and idx.dtype == torch.int64 and idx.is_contiguous() and (k == 0 or rows.stride(1) == 1)
+        with torch.cuda.device(self.device):
+            _check(load_library().phl_scatter_add_rows(C.c_void_p(vert.data_ptr()), vd, C.c_void_p(idx.data_ptr()), k,
+                                                       C.c_void_p(rows.data_ptr()), rows.stride(0) if k else vd,
+                                                       _stream(self.device)))
+        return vert
 
     def slice(self, vert, sub=None, exact=False, out=None, no_tiles=False):
         vd = int(vert.shape[1])

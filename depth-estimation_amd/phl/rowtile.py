@@ -153,6 +153,18 @@ class RowBand:
         for peer in sorted(inbox):
             ids = self.eng.add_vertices(inbox[peer].cpu().numpy())
             self.sides[peer]["map_idx"] = torch.from_numpy(ids.astype(np.int64)).to(self.device)
+        # packed forms for the engine's fused row kernels: one gather for all peers' send rows, one
+        # scatter-add for all received rows (only if no vertex receives from both sides: no atomics)
+        self.peers = sorted(self.sides)
+        if self.peers:
+            self._send_all = torch.cat([self.sides[p]["send_idx"] for p in self.peers])
+            self._map_all = torch.cat([self.sides[p]["map_idx"] for p in self.peers])
+            self._map_disjoint = int(torch.unique(self._map_all).numel()) == int(self._map_all.numel())
+            self._send_rng, self._recv_rng, so, ro = {}, {}, 0, 0
+            for p in self.peers:
+                ks, kr = int(self.sides[p]["send_idx"].numel()), int(self.sides[p]["map_idx"].numel())
+                self._send_rng[p], self._recv_rng[p] = (so, so + ks), (ro, ro + kr)
+                so, ro = so + ks, ro + kr
         self._t_build += time.time() - t0
         self._send_keys = None
 
@@ -160,11 +172,27 @@ class RowBand:
     def splat_outbox(self, src):
         """src [n_local, C] (any channel subset, unit column stride) -> (vertex sums, {peer: rows to send})"""
         vert = self.eng.splat(src)
+        if self.sides and hasattr(self.eng, "gather_rows"):
+            buf = self.eng.gather_rows(vert, self._send_all)        # one launch for both neighbours
+            return vert, {p: buf[a:b] for p, (a, b) in self._send_rng.items()}
         return vert, {peer: vert.index_select(0, s["send_idx"]) for peer, s in self.sides.items()}
 
-    def finish(self, vert, inbox, out=None):
-        for peer in sorted(inbox):
-            vert.index_add_(0, self.sides[peer]["map_idx"], inbox[peer])   # distinct rows: deterministic
+    def recv_range(self, peer):
+        """Row range of `peer`'s rows inside a packed receive buffer (peers in ascending order)."""
+        return self._recv_rng[peer]
+
+    def finish(self, vert, inbox, out=None, packed=None):
+        """inbox: {peer: rows}; packed: the same rows as ONE [sum of rows, C] tensor in ascending peer order
+        (lets the engine add them in a single launch)."""
+        fused = hasattr(self.eng, "scatter_add_rows")
+        if fused and packed is not None and self.sides and self._map_disjoint:
+            self.eng.scatter_add_rows(vert, self._map_all, packed)
+        else:
+            for peer in sorted(inbox):      # distinct rows per peer, peers in a fixed order: deterministic
+                if fused:
+                    self.eng.scatter_add_rows(vert, self.sides[peer]["map_idx"], inbox[peer])
+                else:
+                    vert.index_add_(0, self.sides[peer]["map_idx"], inbox[peer])
         vert = self.eng.blur(vert)
         return self.eng.slice(vert) if out is None else self.eng.slice(vert, out=out)
 
@@ -204,8 +232,9 @@ class RowTileFilter:
         if groups is None:
             groups = int(os.environ.get("PHL_ROWTILE_GROUPS", "0")) or (2 if (world > 1 and L % 8 == 0 and L >= 64) else 1)
         self.groups = [(g * L // groups, (g + 1) * L // groups) for g in range(groups)]
-        self._rbuf = [{p: torch.empty((self.band.recv_rows(p), c1 - c0), dtype=torch.float32, device=self.comm_device)
-                       for p in self.band.sides} for c0, c1 in self.groups]
+        total = sum(self.band.recv_rows(p) for p in self.band.sides)
+        self._rpack = [torch.empty((total, c1 - c0), dtype=torch.float32, device=self.comm_device) for c0, c1 in self.groups]
+        self._rbuf = [{p: pack[slice(*self.band.recv_range(p))] for p in self.band.sides} for pack in self._rpack]
         if hasattr(self.band.eng, "reserve"):
             self.band.eng.reserve(max(c1 - c0 for c0, c1 in self.groups))
 
@@ -251,8 +280,9 @@ class RowTileFilter:
             vert, reqs, _ = pending[gi]
             for req in reqs:
                 req.wait()
-            inbox = {p: (b if b.device == self.band.device else b.to(self.band.device)) for p, b in self._rbuf[gi].items()}
-            self.band.finish(vert, inbox, out=out[:, c0:c1])
+            pack = self._rpack[gi] if self._rpack[gi].device == self.band.device else self._rpack[gi].to(self.band.device)
+            inbox = {p: pack[slice(*self.band.recv_range(p))] for p in self.band.sides}
+            self.band.finish(vert, inbox, out=out[:, c0:c1], packed=pack)
         return out
 
     def describe(self):
@@ -273,5 +303,9 @@ def simulate(feat, src_full, world, engine_factory, device):
     for r, b in enumerate(bands):
         b.build_inbox({p: out[p][r] for p in b.sides})
     outs = [b.splat_outbox(src_full[b.row0 * W:b.row1 * W]) for b in bands]
-    res = [b.finish(outs[r][0], {p: outs[p][1][r] for p in b.sides}) for r, b in enumerate(bands)]
+    res = []
+    for r, b in enumerate(bands):
+        inbox = {p: outs[p][1][r] for p in b.sides}
+        packed = torch.cat([inbox[p] for p in sorted(inbox)]) if inbox else None
+        res.append(b.finish(outs[r][0], inbox, packed=packed))
     return torch.cat(res, 0), bands

@@ -144,6 +144,13 @@ int phl_blur_axis(phl_lattice *lat, int axis, const float *vert_src_dev, float *
  * phl_blur_axis calls, half the traffic over the vertex array).  *result_in_b = 1 if the result
  * ends up in vert_b, 0 if in vert_a. */
 int phl_blur(phl_lattice *lat, float *vert_a_dev, float *vert_b_dev, int vd, int *result_in_b, phl_stream stream);
+/* Row-band exchange helpers (no reference counterpart): out[r] = vert[idx[r]] and vert[idx[r]] += in[r]
+ * for k rows of vd channels (vd % 4 == 0, 16-byte aligned); idx_dev: int64 on the device, DISTINCT
+ * within one scatter call (no atomics: the sum order stays fixed).  Current device, given stream. */
+int phl_gather_rows(const float *vert_dev, int vd, const int64_t *idx_dev, int64_t k, float *out_dev,
+                    int64_t out_row_stride, phl_stream stream);
+int phl_scatter_add_rows(float *vert_dev, int vd, const int64_t *idx_dev, int64_t k, const float *in_dev,
+                         int64_t in_row_stride, phl_stream stream);
 /* slice(): out[p] = sum_i w_i * vert[v_i] / (1 + 2^-d)                        (:473-483) */
 int phl_slice(phl_lattice *lat, const float *vert_dev, int vd, float *out_dev, int64_t out_row_stride,
               const float *sub_dev /* NULL or src to subtract */, int64_t sub_row_stride, unsigned flags,

@@ -28,6 +28,25 @@ def test_bands_match_single_lattice_on_gpu(world, H, W, L):
         assert b.M >= b.eng.M_local and (b.M > b.eng.M_local or world == 1)
 
 
+@pytest.mark.parametrize("vd", [4, 8, 20, 64, 128, 256, 260])
+def test_row_gather_and_scatter_add(vd):
+    import phl
+
+    rng = np.random.default_rng(vd)
+    ref = (rng.random((500, 3), dtype=np.float32) * 3).astype(np.float32)
+    L = phl.Lattice(torch.from_numpy(ref).cuda())
+    vert = torch.from_numpy(rng.standard_normal((L.M, vd)).astype(np.float32)).cuda()
+    idx = torch.from_numpy(rng.permutation(L.M)[:L.M // 3].astype(np.int64)).cuda()
+    got = L.gather_rows(vert, idx)
+    assert torch.equal(got, vert.index_select(0, idx))
+    rows = torch.from_numpy(rng.standard_normal((idx.numel(), vd)).astype(np.float32)).cuda()
+    want = vert.clone().index_add_(0, idx, rows)
+    big = torch.cat([rows, rows], 1)[:, :vd]                    # a strided view as the receive buffer slice
+    assert torch.equal(L.scatter_add_rows(vert.clone(), idx, rows), want)
+    assert torch.equal(L.scatter_add_rows(vert.clone(), idx, big), want)
+    assert L.gather_rows(vert, idx[:0]).shape == (0, vd)
+
+
 def test_add_vertices_semantics():
     import phl
     from oracle import phl_oracle as po

@@ -36,7 +36,9 @@ for groups in ([int(g) for g in sys.argv[3].split(',')] if len(sys.argv) > 3 els
     cuts = [(g * L // groups, (g + 1) * L // groups) for g in range(groups)]
     b.eng.reserve(max(c1 - c0 for c0, c1 in cuts))
     res = torch.empty((b.n_local, L), device=dev)
-    fake = [{p: torch.randn((b.recv_rows(p), c1 - c0), device=dev) for p in b.sides} for c0, c1 in cuts]
+    total = sum(b.recv_rows(p) for p in b.sides)
+    pack = [torch.randn((total, c1 - c0), device=dev) for c0, c1 in cuts]
+    fake = [{p: pk[slice(*b.recv_range(p))] for p in b.sides} for pk in pack]
 
     def call():
         pend = []
@@ -44,7 +46,7 @@ for groups in ([int(g) for g in sys.argv[3].split(',')] if len(sys.argv) > 3 els
             vert, outbox = b.splat_outbox(src[:, c0:c1])
             pend.append((vert, [v.contiguous() for v in outbox.values()]))
         for gi, (c0, c1) in enumerate(cuts):
-            b.finish(pend[gi][0], fake[gi], out=res[:, c0:c1])
+            b.finish(pend[gi][0], fake[gi], out=res[:, c0:c1], packed=pack[gi])
 
     for _ in range(5):
         call()
