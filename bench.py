@@ -40,6 +40,27 @@ SIGMA_XY, SIGMA_C = 8.0, 0.1
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
+def ensure_built(local_rank):
+    """The HIP library normally travels with the tree (built by __graft_entry__.build()).  If it did not,
+    local rank 0 compiles it here (hipcc, ~1 min) and the other ranks wait; never a CPU fallback."""
+    lib = os.path.join(ROOT, "depth-estimation_amd", "lib", "libphl.so")
+    if os.path.exists(lib):
+        return
+    if local_rank == 0:
+        import subprocess
+
+        print("bench.py: libphl.so missing, building it with hipcc", file=sys.stderr)
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "depth-estimation_amd", "csrc"), "-j4", "ARCH=gfx950"],
+                              stdout=sys.stderr)
+    else:
+        t0 = time.time()
+        while not os.path.exists(lib):
+            if time.time() - t0 > 900:
+                sys.exit("bench.py: libphl.so did not appear (local rank 0 builds it)")
+            time.sleep(1.0)
+        time.sleep(2.0)     # let the linker finish writing
+
+
 def box_blur(a, r):
     """(2r+1)^2 box mean with edge replication, via cumulative sums."""
     for axis in (0, 1):
@@ -164,6 +185,7 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py: no HIP device; the lattice filter has no CPU path to benchmark")
+    ensure_built(local_rank)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
