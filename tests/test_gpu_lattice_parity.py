@@ -243,10 +243,12 @@ def test_poor_sharing_falls_back_to_gather(phl):
     assert rel_err(Lat.filter(torch.from_numpy(src).cuda()).cpu().numpy(), want) <= 1e-5
 
 
-@pytest.mark.parametrize("n,d,vd", [(5000, 5, 768), (777, 3, 36), (4099, 1, 8), (9000, 16, 12), (300, 5, 260)])
+@pytest.mark.parametrize("n,d,vd", [(5000, 5, 768), (777, 3, 36), (4099, 1, 8), (9000, 16, 12), (300, 5, 260),
+                                    (40, 5, 256), (60, 3, 128), (100, 5, 128), (150, 2, 64), (33, 5, 100)])
 def test_staged_path_shapes(phl, n, d, vd):
     """wide channel counts (several slabs), ragged last chunk, d = 1 and d = 16 through the
-    default (LDS-staged where eligible) path."""
+    default (LDS-staged where eligible) path; the tiny inputs take the 128- and 256-channel slabs
+    (lane groups of 2 and 4 DPP rows in the segmented sums)."""
     from oracle import phl_oracle as po
 
     rng = np.random.default_rng(n)
