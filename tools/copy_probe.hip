@@ -27,6 +27,33 @@ __global__ __launch_bounds__(256) void k_copy(const vf4 *__restrict__ src, vf4 *
     for (; i < n4; i += stride) dst[i] = src[i];
 }
 
+// read-only (sum into one float per thread) and write-only (fill) streams: how far is a one-directional
+// stream from the copy rate?
+template <int UNROLL>
+__global__ __launch_bounds__(256) void k_read(const vf4 *__restrict__ src, float *__restrict__ sink, long n4)
+{
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long stride = (long)gridDim.x * blockDim.x;
+    vf4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (; i + (UNROLL - 1) * stride < n4; i += UNROLL * stride) {
+        vf4 v[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; u++) v[u] = src[i + u * stride];
+#pragma unroll
+        for (int u = 0; u < UNROLL; u++) acc += v[u];
+    }
+    for (; i < n4; i += stride) acc += src[i];
+    if (acc.x + acc.y + acc.z + acc.w == 12345.678f) sink[0] = acc.x;   // never true: keeps the loads alive
+}
+
+__global__ __launch_bounds__(256) void k_fill(vf4 *__restrict__ dst, long n4)
+{
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long stride = (long)gridDim.x * blockDim.x;
+    const vf4 v = {1.f, 2.f, 3.f, 4.f};
+    for (; i < n4; i += stride) dst[i] = v;
+}
+
 template <int MODE, int UNROLL>
 void run(const char *name, const vf4 *s, vf4 *d, long n4, int blocks)
 {
@@ -55,6 +82,21 @@ int main()
         run<2, 8>("nt store", s, d, n4, blocks);
     }
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+    for (int blocks : {2048, 8192, 65536}) {
+        float ms;
+        k_read<8><<<blocks, 256>>>(s, (float *)d, n4);
+        hipDeviceSynchronize();
+        hipEventRecord(a);
+        for (int r = 0; r < 5; r++) k_read<8><<<blocks, 256>>>(s, (float *)d, n4);
+        hipEventRecord(b); hipEventSynchronize(b);
+        hipEventElapsedTime(&ms, a, b);
+        printf("read only   blocks=%6d : %7.1f GB/s\n", blocks, 1.0 * n4 * 16 * 5 / (ms * 1e-3) / 1e9);
+        hipEventRecord(a);
+        for (int r = 0; r < 5; r++) k_fill<<<blocks, 256>>>(d, n4);
+        hipEventRecord(b); hipEventSynchronize(b);
+        hipEventElapsedTime(&ms, a, b);
+        printf("write only  blocks=%6d : %7.1f GB/s\n", blocks, 1.0 * n4 * 16 * 5 / (ms * 1e-3) / 1e9);
+    }
     hipEventRecord(a);
     for (int r = 0; r < 5; r++) hipMemcpyAsync(d, s, n4 * 16, hipMemcpyDeviceToDevice, 0);
     hipEventRecord(b); hipEventSynchronize(b);
