@@ -33,3 +33,12 @@ def disparity_badness(img1, img2, window_size=9, criterion=AD):
 def disparity_estimate(img1, img2, window_size=9, criterion=AD):
     """Winner-takes-all disparity of the window sweep."""
     return np.argmin(disparity_badness(img1, img2, window_size, criterion), axis=-1)
+
+
+def disparity_energy_device(img1, img2, window_size=9, criterion=AD, max_disp=None):
+    """``disparity_badness`` computed on the GPU (csrc/phl_costvol.hip) and left there as the
+    E_0 [h*w, L] fp32 tensor ``mean_field_infer`` consumes (DenseCrf.ipynb cell 7 does
+    ``torch.from_numpy(disp_energy.reshape(-1, L)).float().to(device)`` after the CPU sweep)."""
+    import phl
+
+    return phl.cost_volume(img1, img2, max_disp=max_disp, window_size=window_size, criterion=criterion)

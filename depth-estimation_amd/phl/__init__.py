@@ -78,6 +78,7 @@ def load_library():
         lib.phl_softmax_neg_add.argtypes = [vp, i64, vp, i64, vp, i64, i64, i32, vp]
         lib.phl_expected_value.argtypes = [vp, i64, vp, vp, i64, i32, vp]
         lib.phl_stream_copy.argtypes = [vp, vp, i64, vp]
+        lib.phl_cost_volume.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, vp, i64, vp]
         lib.phl_get_keys.argtypes = [vp, vp]
         lib.phl_get_replay.argtypes = [vp, vp, vp]
         lib.phl_get_neighbors.argtypes = [vp, vp]
@@ -312,6 +313,34 @@ def softmax_neg_add(E0, G=None, out=None):
             C.c_void_p(E0.data_ptr()), E0.stride(0), C.c_void_p(G.data_ptr()) if G is not None else None,
             G.stride(0) if G is not None else 0, C.c_void_p(out.data_ptr()), out.stride(0), n, L, _stream(E0.device)))
     return out
+
+
+CRITERIA = {"AD": 0, "SD": 1, "nprod": 2}
+
+
+def cost_volume(img1, img2, max_disp=None, window_size=9, criterion="AD", out=None):
+    """Unary stereo cost volume on the device: the reference's ``disparity_badness(img1, img2, window_size,
+    criterion)`` (crf/depth.py:36-53), returned as E_0 [h*w, max_disp] fp32 pixel-major (what
+    ``mean_field_infer`` takes after the notebook's reshape, DenseCrf.ipynb cell 7).
+    img1/img2: [h, w, c] float tensors or numpy arrays; max_disp defaults to w // 6 (:40)."""
+    _require_gpu()
+    dev = img1.device if (torch.is_tensor(img1) and img1.is_cuda) else torch.device("cuda", torch.cuda.current_device())
+    a = torch.as_tensor(img1).to(device=dev, dtype=torch.float32).contiguous()
+    b = torch.as_tensor(img2).to(device=dev, dtype=torch.float32).contiguous()
+    if a.dim() == 2:
+        a, b = a[..., None], b[..., None]
+    if a.shape != b.shape or a.dim() != 3:
+        raise ValueError(f"cost_volume: images must both be [h, w, c], got {tuple(a.shape)} and {tuple(b.shape)}")
+    h, w, c = (int(v) for v in a.shape)
+    L = w // 6 if max_disp is None else int(max_disp)
+    crit = CRITERIA[getattr(criterion, "__name__", criterion)]
+    res = torch.empty((h * w, L), dtype=torch.float32, device=dev) if out is None else out
+    assert res.shape == (h * w, L) and res.stride(1) == 1 and res.dtype == torch.float32
+    with torch.cuda.device(dev):
+        _check(load_library().phl_cost_volume(C.c_void_p(a.data_ptr()), C.c_void_p(b.data_ptr()), h, w, c, L,
+                                              int(window_size), crit, C.c_void_p(res.data_ptr()), res.stride(0) if L else 0,
+                                              _stream(dev)))
+    return res
 
 
 def stream_copy(dst, src):

@@ -167,6 +167,18 @@ int phl_softmax_neg_add(const float *E0_dev, int64_t e0_row_stride, const float 
 int phl_expected_value(const float *Q_dev, int64_t q_row_stride, const float *labels_dev, float *out_dev,
                        int64_t n, int L, phl_stream stream);
 
+/* ---- caller side of the path: the unary cost volume E_0 ---------------------
+ * disparity_badness(img1, img2, window_size, criterion), crf/depth.py:36-53, on the device:
+ *   out[(y*w+x)*out_row_stride + k] = sum over the window x window neighbourhood (scipy 'reflect'
+ *   borders on the cost array, :51-52) of  sum_ch criterion(img1[y,x,ch], img2[y,x-k,ch])  with
+ *   img2 = 0 left of the image (:44-50), k = 0..max_disp-1.
+ * img1/img2: [h][w][channels] fp32 device arrays (1..4 channels), window odd <= 17,
+ * criterion 0 = AD (:26-27), 1 = SD (:24-25), 2 = nprod (:28-29).  The reference takes
+ * max_disp = w // 6 (:40); here it is the caller's argument.  Output is pixel-major fp32, the
+ * layout phl_filter reads. */
+int phl_cost_volume(const float *img1_dev, const float *img2_dev, int h, int w, int channels, int max_disp,
+                    int window, int criterion, float *out_dev, int64_t out_row_stride, phl_stream stream);
+
 /* Plain float4 streaming copy dst <- src (n_floats % 4 == 0, 16-byte aligned): measures the
  * HBM read+write ceiling of the box that the roofline fractions are compared with. */
 int phl_stream_copy(const float *src_dev, float *dst_dev, int64_t n_floats, phl_stream stream);

@@ -20,6 +20,12 @@ Two sources of truth are used, both the reference's own code:
        around the same engine built in (1) -- i.e. ``lattice.filter`` is still the reference's
        own splat/blur/slice.
 
+3. The unary cost volume  crf/depth.py:36-53 ``disparity_badness``  (SURVEY 8f-3), imported from
+   /root/reference by file path.  Its module header imports ``cv2`` / ``cv2.ximgproc.guidedFilter``
+   (absent from this image, never called by ``disparity_badness``): an empty placeholder module is
+   registered so that the import statement succeeds.  oracle/costvol_oracle.py is required to equal
+   the reference's output bit for bit (float64) on every stored case.
+
 While generating, the script also PINS oracle/phl_oracle.c: every lattice case is required to
 match the reference engine bit-for-bit (keys, replay offsets, weights, post-splat and
 post-blur vertex values, output), including cases that grow the reference's hash table, where
@@ -214,7 +220,55 @@ def python_layer_cases(report):
     report.append(dict(case="laplacians", n=n, d=d, k=k))
 
 
+def import_reference_depth():
+    import importlib.util
+
+    cv2 = types.ModuleType("cv2")
+    cv2.ximgproc = types.ModuleType("cv2.ximgproc")
+    cv2.ximgproc.guidedFilter = None          # placeholder; disparity_badness never touches it
+    sys.modules.setdefault("cv2", cv2)
+    sys.modules.setdefault("cv2.ximgproc", cv2.ximgproc)
+    spec = importlib.util.spec_from_file_location("reference_crf_depth", os.path.join(REFERENCE, "crf", "depth.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def cost_volume_cases(report):
+    """Reference outputs of disparity_badness (max_disp = w // 6 as it fixes it) + pin of the numpy oracle."""
+    from oracle import costvol_oracle as co
+
+    ref_depth = import_reference_depth()
+    imL = read_image(os.path.join(REFERENCE, "Experiments", "imL.png"))
+    imR = read_image(os.path.join(REFERENCE, "Experiments", "imR.png"))
+    rng = np.random.default_rng(77)
+    cases = [
+        ("tsukuba_crop_ad9", imL[100:140, 120:216], imR[100:140, 120:216], 9, "AD"),          # 40 x 96 x 3 -> L = 16
+        ("tsukuba_edge_sd5", imL[:21, :66], imR[:21, :66], 5, "SD"),                          # touches two borders, L = 11
+        ("random_nprod3_c1", rng.random((13, 31, 1)), rng.random((13, 31, 1)), 3, "nprod"),   # ragged tile, 1 channel
+        ("random_ad17_c4", rng.random((19, 50, 4)), rng.random((19, 50, 4)), 17, "AD"),       # widest window, 4 channels
+        ("tiny_ad9", rng.random((3, 12, 3)), rng.random((3, 12, 3)), 9, "AD"),               # window larger than the image
+    ]
+    for name, a, b, ws, crit in cases:
+        a, b = np.ascontiguousarray(a), np.ascontiguousarray(b)
+        want = ref_depth.disparity_badness(a, b, ws, getattr(ref_depth, crit))
+        got = co.disparity_badness(a, b, ws, crit)
+        pinned = bool(want.shape == got.shape and np.array_equal(want, got))
+        assert pinned, f"cost-volume oracle differs from the reference on {name}"
+        np.savez_compressed(os.path.join(HERE, f"costvol_{name}.npz"), img1=a, img2=b, window=np.int64(ws),
+                            criterion=np.array(crit), out=want)
+        report.append(dict(case=f"costvol_{name}", shape=list(want.shape), window=ws, criterion=crit, oracle_bit_exact=pinned))
+
+
 def main():
+    if sys.argv[1:] == ["costvol"]:          # add the cost-volume vectors without regenerating the rest
+        report = json.load(open(os.path.join(HERE, "PIN_REPORT.json")))
+        report = [r for r in report if not str(r.get("case", "")).startswith("costvol_")]
+        cost_volume_cases(report)
+        with open(os.path.join(HERE, "PIN_REPORT.json"), "w") as f:
+            json.dump(report, f, indent=1)
+        print("wrote", sorted(x for x in os.listdir(HERE) if x.startswith("costvol_")))
+        return
     po.build_oracle(force=True)
     assert po.build_reference(), "reference engine not built"
     report = []
@@ -230,6 +284,7 @@ def main():
                  ("grow_n200000_d3_vd2", 200000, 3, 2, 40.0, 23)]:
         lattice_case(*args, report=report, store=False)
     python_layer_cases(report)
+    cost_volume_cases(report)
     with open(os.path.join(HERE, "PIN_REPORT.json"), "w") as f:
         json.dump(report, f, indent=1)
     print("wrote", sorted(x for x in os.listdir(HERE) if x.endswith(".npz")))
