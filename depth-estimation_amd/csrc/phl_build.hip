@@ -466,7 +466,8 @@ int phl_build_device(phl_lattice *lat, const float *ref, int64_t rs, int64_t cs,
     PHL_HIP(hipGetLastError());
     PHL_HIP(hipStreamSynchronize(st));  // temporaries are freed on return
     lat->table_bytes = (int64_t)(sizeof(int16_t) * (size_t)M * d + sizeof(phl_replay_t) * (size_t)N +
-                                 sizeof(int32_t) * (size_t)M * (d + 1) * 2 + sizeof(int) * ((size_t)lat->table_mask + 1));
+                                 sizeof(int32_t) * (size_t)M * (d + 1) * 2 + sizeof(int32_t) * (size_t)M * ((d + 1) / 2) * 8 +
+                                 sizeof(int) * ((size_t)lat->table_mask + 1));
     return PHL_OK;
 }
 
