@@ -149,3 +149,17 @@ def test_torch_cpp_extension_binding():
     assert not c.is_cuda and torch.equal(c, b.cpu())
     with pytest.raises(RuntimeError, match="Incompatible shapes"):
         ext.filter(src[:10], ref)
+
+
+def test_notebook_flow_end_to_end_on_a_synthetic_pair():
+    """examples/stereo_crf.py: cost volume on the device -> lattice -> 5 mean-field iterations -> expected
+    disparity.  The CRF estimate must beat the window-sweep estimate it starts from."""
+    import importlib.util
+    import os
+
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "stereo_crf.py")
+    spec = importlib.util.spec_from_file_location("stereo_crf_example", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    err_wta, err_crf = mod.run(h=120, w=240, iters=5, quiet=True)
+    assert err_crf < err_wta and err_crf < 0.5, (err_wta, err_crf)
