@@ -192,6 +192,7 @@ def main():
     if world > 1 or args.force_rowtile:
         import torch.distributed as dist
 
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: what RCCL peer-to-peer needs on this pool
         if not (os.environ.get("MASTER_ADDR") and os.environ.get("MASTER_PORT")):
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29533")
