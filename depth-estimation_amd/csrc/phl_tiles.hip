@@ -108,10 +108,14 @@ __global__ __launch_bounds__(256) void k_extract_index(const phl_contrib_t *__re
 template <int SORTN, bool WRITE>
 __global__ __launch_bounds__(256) void k_chunk_sort(const int *__restrict__ pix_order, int n, int P, int dp1,
                                                     const phl_replay_t *__restrict__ replay, int *__restrict__ nv_out,
-                                                    const int *__restrict__ vptr, int *__restrict__ slot_vert,
+                                                    const int *__restrict__ vptr, int stride, int *__restrict__ slot_vert,
                                                     int2 *__restrict__ seg_rng, phl_contrib_t *__restrict__ seg,
                                                     unsigned short *__restrict__ lidx)
 {
+    // vptr != null: slots go to their final place vptr[c] + local index.  vptr == null (first and
+    // normally only pass): slots go to a scratch area with a fixed `stride` per chunk (local indices
+    // beyond it are dropped -- the host then repeats the pass with the real offsets), and the number of
+    // local vertices is reported in nv_out.
     __shared__ unsigned long long keys[SORTN];
     const int c = blockIdx.x;
     const int base = c * P;
@@ -150,17 +154,16 @@ __global__ __launch_bounds__(256) void k_chunk_sort(const int *__restrict__ pix_
     }
     int total;
     int li = block_exclusive_scan(heads, &total) - 1;
-    if (!WRITE) {
-        if (threadIdx.x == 0) nv_out[c] = total;
-        return;
-    }
+    if (nv_out && threadIdx.x == 0) nv_out[c] = total;
+    if (!WRITE) return;
     // Local vertices are renumbered by DESCENDING segment length (counting sort in LDS): the
     // splat kernel hands neighbouring local vertices to the lane groups of one wavefront, which
     // then run loops of nearly equal length, and takes groups longest-first.
     __shared__ int hpos[SORTN + 1];   // start position of the segment of vid-order vertex j
     __shared__ int newidx[SORTN];     // vid-order index -> length-order index
     __shared__ int lbin[258];         // histogram over segment lengths 1..P (P <= 256)
-    const int vbase = vptr[c];
+    const int64_t vbase = vptr ? (int64_t)vptr[c] : (int64_t)c * stride;
+    const int vcap = vptr ? SORTN : stride;
     const int64_t ebase = (int64_t)base * dp1;
     for (int j = threadIdx.x; j < 258; j += 256) lbin[j] = 0;
     {
@@ -203,9 +206,11 @@ __global__ __launch_bounds__(256) void k_chunk_sort(const int *__restrict__ pix_
         const bool head = (i == 0) || vid != (unsigned)(keys[i - 1] >> 32);
         if (head) {
             li++;
-            const int slot = vbase + newidx[li];
-            slot_vert[slot] = (int)vid;
-            seg_rng[slot] = make_int2((int)(ebase + i), (int)(ebase + hpos[li + 1]));
+            if (newidx[li] < vcap) {
+                const int64_t slot = vbase + newidx[li];
+                slot_vert[slot] = (int)vid;
+                seg_rng[slot] = make_int2((int)(ebase + i), (int)(ebase + hpos[li + 1]));
+            }
         }
         const int k = e / dp1, r = e - k * dp1;
         const int p = pix_order[base + k];
@@ -214,6 +219,19 @@ __global__ __launch_bounds__(256) void k_chunk_sort(const int *__restrict__ pix_
         s.w = replay[(int64_t)p * dp1 + r].w;
         seg[ebase + i] = s;
         lidx[ebase + e] = (unsigned short)newidx[li];
+    }
+}
+
+// scratch slot records [chunk][stride] -> compact [vptr[chunk] + i]
+__global__ __launch_bounds__(256) void k_compact_slots(const int *__restrict__ vptr, int nchunks, int stride,
+                                                       const int *__restrict__ t_vert, const int2 *__restrict__ t_rng,
+                                                       int *__restrict__ slot_vert, int2 *__restrict__ seg_rng)
+{
+    const int c = blockIdx.x;
+    const int b = vptr[c], nv = vptr[c + 1] - b;
+    for (int i = threadIdx.x; i < nv; i += 256) {
+        slot_vert[b + i] = t_vert[(int64_t)c * stride + i];
+        seg_rng[b + i] = t_rng[(int64_t)c * stride + i];
     }
 }
 
@@ -891,8 +909,18 @@ int phl_tiles_build(phl_lattice *lat, const float *ref, int64_t rs, int64_t cs, 
         case 1024: hipLaunchKernelGGL((k_chunk_sort<1024, WRITE_>), dim3(nchunks), dim3(256), 0, st, __VA_ARGS__); break; \
         default: hipLaunchKernelGGL((k_chunk_sort<2048, WRITE_>), dim3(nchunks), dim3(256), 0, st, __VA_ARGS__); break;   \
     }
-    PHL_CHUNK_SORT(false, lat->pix_order, n, P, dp1, lat->replay, nv, (const int *)nullptr, (int *)nullptr, (int2 *)nullptr,
-                   (phl_contrib_t *)nullptr, (unsigned short *)nullptr)
+    // One sort pass: segments and local indices go to their final arrays, the per-chunk slot records to a
+    // scratch area with a fixed stride; they are compacted once the chunk offsets are known.  Only when a
+    // chunk has more local vertices than the stride (pixels that share next to nothing) the pass is repeated.
+    constexpr int SLOT_STRIDE = 384;
+    int *t_vert;
+    int2 *t_rng;
+    PHL_HIP(tmp.get(&t_vert, (size_t)nchunks * SLOT_STRIDE));
+    PHL_HIP(tmp.get(&t_rng, (size_t)nchunks * SLOT_STRIDE));
+    PHL_HIP(hipMalloc((void **)&lat->seg, sizeof(phl_contrib_t) * (size_t)N));
+    PHL_HIP(hipMalloc((void **)&lat->lidx, sizeof(unsigned short) * (size_t)N));
+    PHL_CHUNK_SORT(true, lat->pix_order, n, P, dp1, lat->replay, nv, (const int *)nullptr, SLOT_STRIDE, t_vert, t_rng,
+                   lat->seg, lat->lidx)
     PHL_HIP(hipGetLastError());
     rc = exclusive_scan(nv, lat->chunk_vptr, nchunks, tile_sums, st);
     if (rc) return rc;
@@ -908,10 +936,13 @@ int phl_tiles_build(phl_lattice *lat, const float *ref, int64_t rs, int64_t cs, 
     lat->nv_max = nv_max;
     PHL_HIP(hipMalloc((void **)&lat->slot_vert, sizeof(int) * ((size_t)S + 1)));
     PHL_HIP(hipMalloc((void **)&lat->seg_rng, sizeof(int2) * ((size_t)S + 1)));
-    PHL_HIP(hipMalloc((void **)&lat->seg, sizeof(phl_contrib_t) * (size_t)N));
-    PHL_HIP(hipMalloc((void **)&lat->lidx, sizeof(unsigned short) * (size_t)N));
-    PHL_CHUNK_SORT(true, lat->pix_order, n, P, dp1, lat->replay, (int *)nullptr, lat->chunk_vptr, lat->slot_vert,
-                   lat->seg_rng, lat->seg, lat->lidx)
+    if (nv_max <= SLOT_STRIDE) {
+        hipLaunchKernelGGL(k_compact_slots, dim3(nchunks), dim3(256), 0, st, lat->chunk_vptr, nchunks, SLOT_STRIDE, t_vert,
+                           t_rng, lat->slot_vert, lat->seg_rng);
+    } else {
+        PHL_CHUNK_SORT(true, lat->pix_order, n, P, dp1, lat->replay, (int *)nullptr, lat->chunk_vptr, 0, lat->slot_vert,
+                       lat->seg_rng, lat->seg, lat->lidx)
+    }
 #undef PHL_CHUNK_SORT
     PHL_HIP(hipGetLastError());
     PHL_HIP(hipStreamSynchronize(st));
