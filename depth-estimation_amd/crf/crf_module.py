@@ -81,29 +81,48 @@ def mean_field_infer(E_0, W, Mu, niters=10):
 
 def potts(num_classes):
     """1x1 conv holding the Potts compatibility 1 - I (crf_module.py:55-64)."""
-    layer = nn.Conv2d(num_classes, num_classes, kernel_size=1, bias=False)
+    conv = nn.Conv2d(num_classes, num_classes, kernel_size=1, bias=False)
     with torch.no_grad():
-        layer.weight.copy_((1 - torch.eye(num_classes))[..., None, None])
-    return layer
+        conv.weight.copy_((1 - torch.eye(num_classes))[..., None, None])
+    return conv
+
+
+def _maybe_learnable(value, trainable):
+    """A scalar hyper-parameter: nn.Parameter when it is to be trained, the plain number otherwise
+    (the reference's ``nn.Parameter(torch.tensor(v)) if trainable else v`` idiom, crf_module.py:109-110)."""
+    return nn.Parameter(torch.tensor(value)) if trainable else value
 
 
 class charb(nn.Module):
     """Learnable Charbonnier compatibility applied as a 1x1 conv over label channels
-    (crf_module.py:66-79): Mu(Q) = conv(Q, charbonneir(l_a, l_b, gamma)) * exp(s)."""
+    (crf_module.py:66-79): Mu(Q) = conv(Q, charbonneir(l_a, l_b, gamma)) * exp(s).
+    Parameter names (``gamma``, ``s``) are the reference's, so its checkpoints load."""
 
     def __init__(self, gamma):
         super().__init__()
-        self.gamma = nn.Parameter(torch.tensor(gamma))
-        self.s = nn.Parameter(torch.tensor(0.))
+        self.register_parameter("gamma", nn.Parameter(torch.tensor(gamma)))
+        self.register_parameter("s", nn.Parameter(torch.tensor(0.)))
+
+    def _scale(self):
+        return torch.exp(self.s)
 
     def forward(self, x, labels=None):
-        if labels is None:
+        if labels is None:          # the reference builds them with .cuda(); here they follow the input
             labels = torch.arange(x.shape[1], dtype=torch.float32, device=x.device)
-        Mu = charbonneir(labels[None, :], labels[:, None], self.gamma)
-        return F.conv2d(x, Mu[..., None, None]) * torch.exp(self.s)
+        weight = compatibility_matrix(lambda p, q: charbonneir(q, p, self.gamma), labels)     # symmetric in (p, q)
+        return F.conv2d(x, weight[..., None, None]) * self._scale()
 
     def get_energies_from_scalar(self, x, labels):
-        return charbonneir(labels, x, self.gamma * labels.max()) * torch.exp(self.s)
+        return charbonneir(labels, x, self.gamma * labels.max()) * self._scale()
+
+
+def _mean_field_nchw(E0, message, niters):
+    """NCHW mean field: ``message(Q)`` returns the pairwise energy; gives the energy of the last iteration."""
+    E, Q = E0, F.softmax(-E0, dim=1)
+    for _ in range(niters):
+        E = E0 + message(Q)
+        Q = F.softmax(-E, dim=1)
+    return E
 
 
 class CRFasRNN(nn.Module):
@@ -114,46 +133,40 @@ class CRFasRNN(nn.Module):
 
     def __init__(self, mu_init, niters=5, r=20, eps=1e-5, notrain_mu=False, gaussian=False, gchannels=1, lattice=False):
         super().__init__()
-        self.Mu = mu_init
+        self.Mu, self.niters = mu_init, niters
         if notrain_mu:
-            for p in self.Mu.parameters():
-                p.requires_grad = False
-        self.niters = niters
+            self.Mu.requires_grad_(False)
         self.W = BatchedAdjacency() if lattice else BatchedGuidedAdjacency(gchannels, r, eps, gaussian=gaussian)
 
     def forward(self, refs, logits, confidence=None, labels=None):
-        E0 = -logits * (1 if confidence is None else confidence)
-        compat = (lambda q: self.Mu(q)) if labels is None else (lambda q: self.Mu(q, labels))
-        Q = F.softmax(-E0, dim=1)
-        E = E0
-        for _ in range(self.niters):
-            E = E0 + self.W(compat(Q), refs)
-            Q = F.softmax(-E, dim=1)
-        return -E
-
-
-def _ij_grid(x):
-    bs, _, h, w = x.shape
-    ij = torch.from_numpy(np.mgrid[:h, :w] / np.sqrt(h ** 2 + w ** 2)).float().to(x.device)
-    return ij[None].expand(bs, -1, -1, -1)
-
-
-class ijrgbGuide(nn.Module):
-    """Guide features (i, j)/s_ij ++ rgb/s_rgb (crf_module.py:106-114)."""
-
-    def __init__(self, s_ij=.1, s_rgb=.1, trainable=True):
-        super().__init__()
-        self.s_ij = nn.Parameter(torch.tensor(s_ij)) if trainable else s_ij
-        self.s_rgb = nn.Parameter(torch.tensor(s_rgb)) if trainable else s_rgb
-
-    def forward(self, x):
-        return torch.cat([_ij_grid(x) / self.s_ij, x / self.s_rgb], dim=1)
+        """refs [B, C, H, W], logits [B, L, H, W]."""
+        E0 = -logits if confidence is None else -logits * confidence
+        extra = () if labels is None else (labels,)
+        return -_mean_field_nchw(E0, lambda Q: self.W(self.Mu(Q, *extra), refs), self.niters)
 
 
 class ijGuide(nn.Module):
+    """Guide features (i, j) / sqrt(h^2 + w^2) / s_ij  (crf_module.py:116-123)."""
+
     def __init__(self, s_ij=.1, trainable=True):
         super().__init__()
-        self.s_ij = nn.Parameter(torch.tensor(s_ij)) if trainable else s_ij
+        self.s_ij = _maybe_learnable(s_ij, trainable)
+
+    def positions(self, x):
+        bs, _, h, w = x.shape
+        grid = np.mgrid[:h, :w] / np.sqrt(h ** 2 + w ** 2)
+        return torch.from_numpy(grid).float().to(x.device)[None].expand(bs, -1, -1, -1) / self.s_ij
 
     def forward(self, x):
-        return _ij_grid(x) / self.s_ij
+        return self.positions(x)
+
+
+class ijrgbGuide(ijGuide):
+    """Guide features (i, j)/s_ij ++ rgb/s_rgb (crf_module.py:106-114)."""
+
+    def __init__(self, s_ij=.1, s_rgb=.1, trainable=True):
+        super().__init__(s_ij, trainable)
+        self.s_rgb = _maybe_learnable(s_rgb, trainable)
+
+    def forward(self, x):
+        return torch.cat([self.positions(x), x / self.s_rgb], dim=1)
