@@ -145,6 +145,31 @@ def test_reach_is_not_generous(monkeypatch):
     assert rel(got.numpy(), want) > RTOL
 
 
+@pytest.mark.parametrize("seed", range(8))
+def test_loopback_bands_randomised(seed):
+    """Random image sizes, kernel widths, band counts, feature scalings and colour statistics: the band
+    decomposition must reproduce the single lattice whenever it accepts the configuration."""
+    from oracle import phl_oracle as po
+    from phl import rowtile
+    from _engines import OracleEngine
+
+    rng = np.random.default_rng(1000 + seed)
+    world = int(rng.integers(2, 5))
+    sigma_xy = float(rng.choice([1.5, 2.0, 3.0, 4.0]))
+    a, b = rowtile.lattice_reach(5, 1)
+    need = int(np.ceil((2 * a + b) * sigma_xy)) + 2            # rows per band so that bands two apart are separated
+    H = world * int(rng.integers(need, need + 12)) + int(rng.integers(0, world))   # ragged last bands
+    W, L = int(rng.integers(9, 28)), int(rng.integers(1, 5))
+    feat, src = make_image(H, W, L, sigma_xy=sigma_xy, seed=seed, iid_colour=bool(rng.integers(0, 2)))
+    feat[..., 2:] *= float(rng.choice([0.3, 1.0, 2.5]))         # colour bandwidth: few / many vertices per pixel
+    if rng.integers(0, 2):
+        feat[..., 0] += 0.05 * feat[..., 1]                     # x depends a little on the row as well
+    want = po.oracle_filter(src, feat.reshape(-1, 5))
+    got, bands = rowtile.simulate(feat, torch.from_numpy(src), world, OracleEngine, torch.device("cpu"))
+    assert rel(got.numpy(), want) <= RTOL, (world, sigma_xy, H, W)
+    assert all(b.axis == 1 for b in bands)
+
+
 def test_too_many_ranks_is_rejected():
     from phl import rowtile
     from _engines import OracleEngine
