@@ -105,7 +105,23 @@ __global__ __launch_bounds__(256) void k_extract_index(const phl_contrib_t *__re
 // entry e = k*(d+1)+r of the chunk (k-th pixel in chunk order, remainder r).  After the sort
 // the pairs are grouped by vertex with ascending e, i.e. ascending pixel: exactly the
 // per-vertex segment the splat needs.  WRITE=false only counts the distinct vertices.
-template <int SORTN, bool WRITE>
+// Sort keys: (vertex id, entry) packed into 32 bits when the lattice has fewer than 2^21 vertices (entry < 2048),
+// else 64 bits.
+template <typename KT> struct sort_key;
+template <> struct sort_key<unsigned> {
+    static __device__ __forceinline__ unsigned make(unsigned vid, unsigned e) { return (vid << 11) | e; }
+    static __device__ __forceinline__ unsigned vid(unsigned k) { return k >> 11; }
+    static __device__ __forceinline__ unsigned entry(unsigned k) { return k & 2047u; }
+    static __device__ __forceinline__ unsigned pad() { return ~0u; }
+};
+template <> struct sort_key<unsigned long long> {
+    static __device__ __forceinline__ unsigned long long make(unsigned vid, unsigned e) { return ((unsigned long long)vid << 32) | e; }
+    static __device__ __forceinline__ unsigned vid(unsigned long long k) { return (unsigned)(k >> 32); }
+    static __device__ __forceinline__ unsigned entry(unsigned long long k) { return (unsigned)k; }
+    static __device__ __forceinline__ unsigned long long pad() { return ~0ull; }
+};
+
+template <int SORTN, bool WRITE, typename KT>
 __global__ __launch_bounds__(256) void k_chunk_sort(const int *__restrict__ pix_order, int n, int P, int dp1,
                                                     const phl_replay_t *__restrict__ replay, int *__restrict__ nv_out,
                                                     const int *__restrict__ vptr, int stride, int *__restrict__ slot_vert,
@@ -116,41 +132,71 @@ __global__ __launch_bounds__(256) void k_chunk_sort(const int *__restrict__ pix_
     // normally only pass): slots go to a scratch area with a fixed `stride` per chunk (local indices
     // beyond it are dropped -- the host then repeats the pass with the real offsets), and the number of
     // local vertices is reported in nv_out.
-    __shared__ unsigned long long keys[SORTN];
+    using SK = sort_key<KT>;
+    __shared__ KT keys[SORTN];
+    constexpr int PER = SORTN / 256;       // consecutive elements owned by a thread in the register stages
     const int c = blockIdx.x;
     const int base = c * P;
     const int cnt = min(P, n - base);
     const int E = cnt * dp1;
-    for (int e = threadIdx.x; e < SORTN; e += 256) {
-        unsigned long long key = ~0ull;
+    const int i0 = threadIdx.x * PER;
+    // Bitonic sort.  Compare-exchange distances below PER stay inside one thread's PER consecutive elements:
+    // those sub-stages run in registers (no LDS traffic, no barrier); only distances >= PER go through LDS.
+    KT r[PER];
+#pragma unroll
+    for (int u = 0; u < PER; u++) {
+        const int e = i0 + u;
+        KT key = SK::pad();
         if (e < E) {
-            const int k = e / dp1, r = e - k * dp1;
+            const int k = e / dp1, rr = e - k * dp1;
             const int p = pix_order[base + k];
-            key = ((unsigned long long)(unsigned)replay[(int64_t)p * dp1 + r].vid << 32) | (unsigned)e;
+            key = SK::make((unsigned)replay[(int64_t)p * dp1 + rr].vid, (unsigned)e);
         }
-        keys[e] = key;
+        r[u] = key;
     }
+    auto cmpx = [](KT &a, KT &b, bool up) {
+        if ((a > b) == up) { const KT t = a; a = b; b = t; }
+    };
+#pragma unroll
+    for (int k = 2; k <= PER; k <<= 1)                 // levels entirely inside a thread
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1)
+#pragma unroll
+            for (int u = 0; u < PER; u++)
+                if ((u ^ j) > u) cmpx(r[u], r[u ^ j], ((i0 + u) & k) == 0);
+#pragma unroll
+    for (int u = 0; u < PER; u++) keys[i0 + u] = r[u];
     __syncthreads();
-    for (int k = 2; k <= SORTN; k <<= 1)
-        for (int j = k >> 1; j > 0; j >>= 1) {
+    for (int k = 2 * PER; k <= SORTN; k <<= 1) {
+        for (int j = k >> 1; j >= PER; j >>= 1) {      // distances that cross threads: through LDS
             for (int i = threadIdx.x; i < SORTN; i += 256) {
                 const int ixj = i ^ j;
                 if (ixj > i) {
-                    const unsigned long long a = keys[i], b = keys[ixj];
+                    const KT a = keys[i], b = keys[ixj];
                     const bool up = (i & k) == 0;
                     if ((a > b) == up) { keys[i] = b; keys[ixj] = a; }
                 }
             }
             __syncthreads();
         }
+        const bool up = (i0 & k) == 0;                 // the thread's whole run lies in one half of the k-block
+#pragma unroll
+        for (int u = 0; u < PER; u++) r[u] = keys[i0 + u];
+#pragma unroll
+        for (int j = PER >> 1; j > 0; j >>= 1)
+#pragma unroll
+            for (int u = 0; u < PER; u++)
+                if ((u ^ j) > u) cmpx(r[u], r[u ^ j], up);
+#pragma unroll
+        for (int u = 0; u < PER; u++) keys[i0 + u] = r[u];
+        __syncthreads();
+    }
     // heads = first entry of each distinct vertex; local vertex index = (#heads up to here) - 1
-    constexpr int PER = SORTN / 256;
-    const int i0 = threadIdx.x * PER;
     int heads = 0;
 #pragma unroll
     for (int u = 0; u < PER; u++) {
         const int i = i0 + u;
-        if (i < E && (i == 0 || (unsigned)(keys[i] >> 32) != (unsigned)(keys[i - 1] >> 32))) heads++;
+        if (i < E && (i == 0 || SK::vid(keys[i]) != SK::vid(keys[i - 1]))) heads++;
     }
     int total;
     int li = block_exclusive_scan(heads, &total) - 1;
@@ -171,7 +217,7 @@ __global__ __launch_bounds__(256) void k_chunk_sort(const int *__restrict__ pix_
 #pragma unroll
         for (int u = 0; u < PER; u++) {
             const int i = i0 + u;
-            if (i < E && (i == 0 || (unsigned)(keys[i] >> 32) != (unsigned)(keys[i - 1] >> 32))) hpos[++lj] = i;
+            if (i < E && (i == 0 || SK::vid(keys[i]) != SK::vid(keys[i - 1]))) hpos[++lj] = i;
         }
     }
     if (threadIdx.x == 0) hpos[total] = E;
@@ -201,9 +247,9 @@ __global__ __launch_bounds__(256) void k_chunk_sort(const int *__restrict__ pix_
     for (int u = 0; u < PER; u++) {
         const int i = i0 + u;
         if (i >= E) break;
-        const unsigned vid = (unsigned)(keys[i] >> 32);
-        const int e = (int)(unsigned)keys[i];
-        const bool head = (i == 0) || vid != (unsigned)(keys[i - 1] >> 32);
+        const unsigned vid = SK::vid(keys[i]);
+        const int e = (int)SK::entry(keys[i]);
+        const bool head = (i == 0) || vid != SK::vid(keys[i - 1]);
         if (head) {
             li++;
             if (newidx[li] < vcap) {
@@ -903,12 +949,17 @@ int phl_tiles_build(phl_lattice *lat, const float *ref, int64_t rs, int64_t cs, 
     int *nv;
     PHL_HIP(tmp.get(&nv, (size_t)nchunks + 1));
     PHL_HIP(hipMalloc((void **)&lat->chunk_vptr, sizeof(int) * ((size_t)nchunks + 1)));
-#define PHL_CHUNK_SORT(WRITE_, ...)                                                                                       \
-    switch (sortn) {                                                                                                      \
-        case 512: hipLaunchKernelGGL((k_chunk_sort<512, WRITE_>), dim3(nchunks), dim3(256), 0, st, __VA_ARGS__); break;   \
-        case 1024: hipLaunchKernelGGL((k_chunk_sort<1024, WRITE_>), dim3(nchunks), dim3(256), 0, st, __VA_ARGS__); break; \
-        default: hipLaunchKernelGGL((k_chunk_sort<2048, WRITE_>), dim3(nchunks), dim3(256), 0, st, __VA_ARGS__); break;   \
+    static const bool force64 = getenv("PHL_SORT_KEY64") != nullptr;       // tests: take the wide-key kernels on small inputs
+    const bool key32 = lat->M < (1 << 21) && !force64;                     // (vertex id, entry < 2048) fits 32 bits
+#define PHL_CHUNK_SORT_K(WRITE_, KT_, ...)                                                                                    \
+    switch (sortn) {                                                                                                          \
+        case 512: hipLaunchKernelGGL((k_chunk_sort<512, WRITE_, KT_>), dim3(nchunks), dim3(256), 0, st, __VA_ARGS__); break;   \
+        case 1024: hipLaunchKernelGGL((k_chunk_sort<1024, WRITE_, KT_>), dim3(nchunks), dim3(256), 0, st, __VA_ARGS__); break; \
+        default: hipLaunchKernelGGL((k_chunk_sort<2048, WRITE_, KT_>), dim3(nchunks), dim3(256), 0, st, __VA_ARGS__); break;   \
     }
+#define PHL_CHUNK_SORT(WRITE_, ...)                                            \
+    if (key32) { PHL_CHUNK_SORT_K(WRITE_, unsigned, __VA_ARGS__) }             \
+    else { PHL_CHUNK_SORT_K(WRITE_, unsigned long long, __VA_ARGS__) }
     // One sort pass: segments and local indices go to their final arrays, the per-chunk slot records to a
     // scratch area with a fixed stride; they are compacted once the chunk offsets are known.  Only when a
     // chunk has more local vertices than the stride (pixels that share next to nothing) the pass is repeated.
@@ -944,6 +995,7 @@ int phl_tiles_build(phl_lattice *lat, const float *ref, int64_t rs, int64_t cs, 
                        lat->seg_rng, lat->seg, lat->lidx)
     }
 #undef PHL_CHUNK_SORT
+#undef PHL_CHUNK_SORT_K
     PHL_HIP(hipGetLastError());
     PHL_HIP(hipStreamSynchronize(st));
     }

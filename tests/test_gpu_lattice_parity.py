@@ -363,6 +363,58 @@ def test_fused_blur_equals_axis_by_axis(phl, d):
     assert np.array_equal(fused.cpu().numpy().view(np.uint32), want.view(np.uint32))
 
 
+def test_more_than_two_million_vertices(phl):
+    """M >= 2^21 switches the chunk sort to 64-bit keys, and pixels that share nothing overflow the
+    fixed-stride slot scratch, so the chunk pass is repeated with exact offsets: both rare paths, checked
+    through the slice (which uses the chunk structures whenever they fit) against the CPU restatement."""
+    from oracle import phl_oracle as po
+
+    rng = np.random.default_rng(77)
+    n, d, vd = 380_000, 5, 4
+    ref = (rng.random((n, d), dtype=np.float32) * np.float32(400.0)).astype(np.float32)
+    src = rng.random((n, vd), dtype=np.float32)
+    L = phl.Lattice(torch.from_numpy(ref).cuda())
+    assert L.M >= (1 << 21)
+    st = L.tile_stats(vd)
+    assert st["slots"] == n * (d + 1) and st["max_local_vertices"] > 384
+    O = po.Oracle(ref)
+    assert O.M == L.M
+    want = O.filter(src)
+    assert rel_err(L.filter(torch.from_numpy(src).cuda()).cpu().numpy(), want) <= 1e-5
+    vb = L.blur(L.splat(torch.from_numpy(src).cuda(), exact=True))
+    for no_tiles in (False, True):
+        out = L.slice(vb.clone(), exact=True, no_tiles=no_tiles).cpu().numpy()
+        assert np.array_equal(out.view(np.uint32), want.view(np.uint32)), no_tiles
+
+
+def test_wide_sort_keys_give_the_same_chunks():
+    """The 64-bit-key chunk sort (lattices with >= 2^21 vertices) forced on a small shared lattice in a fresh
+    process: the LDS-staged filter must still match the CPU restatement."""
+    import subprocess
+    import sys
+
+    code = (
+        "import os, sys, numpy as np, torch\n"
+        "root = sys.argv[1]\n"
+        "sys.path[:0] = [os.path.join(root, 'depth-estimation_amd'), root]\n"
+        "import phl\n"
+        "from oracle import phl_oracle as po\n"
+        "rng = np.random.default_rng(3)\n"
+        "ref = np.cumsum(rng.random((9000, 5), dtype=np.float32) * 0.03, axis=0).astype(np.float32)\n"
+        "src = rng.random((9000, 64), dtype=np.float32)\n"
+        "L = phl.Lattice(torch.from_numpy(ref).cuda())\n"
+        "st = L.tile_stats(64)\n"
+        "assert st['staged_splat'] == 1 and st['staged_slice'] == 1, st\n"
+        "want = po.Oracle(ref).filter(src)\n"
+        "got = L.filter(torch.from_numpy(src).cuda()).cpu().numpy()\n"
+        "assert np.abs(got - want).max() <= 1e-5 * np.abs(want).max()\n"
+        "print('ok')\n")
+    env = dict(os.environ, PHL_SORT_KEY64="1")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code, root], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
+
+
 def test_filter_is_graph_capturable(phl):
     """After phl_reserve the filter launch sequence allocates nothing and never synchronises, so
     it can be captured into a HIP graph (torch.cuda.CUDAGraph) and replayed on new input values."""
