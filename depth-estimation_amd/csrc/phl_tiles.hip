@@ -27,7 +27,10 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include <map>
+#include <mutex>
 #include <type_traits>
+#include <utility>
 #include <vector>
 
 #include "phl_device_utils.h"
@@ -731,8 +734,20 @@ inline int pick_lprs(int vd, int rows, int64_t extra)
 template <typename K>
 inline int allow_lds(K kernel, size_t bytes, int threads = 512)
 {
-    if (bytes > 64 * 1024)
-        PHL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    if (bytes > 64 * 1024) {
+        // once per (device, kernel, size): the attribute call is not free and this runs on every launch
+        static std::mutex mu;
+        static std::map<std::pair<int, const void *>, size_t> allowed;
+        int dev = 0;
+        PHL_HIP(hipGetDevice(&dev));
+        const void *fn = reinterpret_cast<const void *>(kernel);
+        std::lock_guard<std::mutex> lk(mu);
+        size_t &have = allowed[std::make_pair(dev, fn)];
+        if (bytes > have) {
+            PHL_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+            have = bytes;
+        }
+    }
     static const bool dbg = getenv("PHL_DEBUG") != nullptr;
     if (dbg) {
         int nb = -1;
