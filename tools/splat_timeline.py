@@ -3,7 +3,8 @@
 import os
 import sys
 
-path = "/tmp/phl_timeline.bin"
+analyze_only = len(sys.argv) > 2 and sys.argv[1] == "--analyze"      # python tools/splat_timeline.py --analyze dump.bin
+path = sys.argv[2] if analyze_only else "/tmp/phl_timeline.bin"
 os.environ["PHL_TIMELINE"] = path
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "depth-estimation_amd"))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
@@ -13,16 +14,17 @@ import torch
 import bench
 import phl
 
-rows = int(sys.argv[1]) if len(sys.argv) > 1 else 192
+rows = 0 if analyze_only else (int(sys.argv[1]) if len(sys.argv) > 1 else 192)
 H, W, L, _ = bench.WORKLOADS["c3"]
-dev = torch.device("cuda", 0)
-feat = bench.synthetic_features(H, W)
-r0 = (H - rows) // 2
-lat = phl.Lattice(torch.from_numpy(np.ascontiguousarray(feat[r0:r0 + rows].reshape(-1, 5))).to(dev))
-src = bench.synthetic_values(torch, rows, W, L, r0, dev)
-for _ in range(6):
-    lat.splat(src)
-torch.cuda.synchronize()
+if not analyze_only:
+    dev = torch.device("cuda", 0)
+    feat = bench.synthetic_features(H, W)
+    r0 = (H - rows) // 2
+    lat = phl.Lattice(torch.from_numpy(np.ascontiguousarray(feat[r0:r0 + rows].reshape(-1, 5))).to(dev))
+    src = bench.synthetic_values(torch, rows, W, L, r0, dev)
+    for _ in range(6):
+        lat.splat(src)
+    torch.cuda.synchronize()
 t = np.fromfile(path, dtype=np.uint64).reshape(-1, 8)
 t = t[t[:, 0] > 0]
 st = t[:, 0].astype(np.int64)
