@@ -11,6 +11,7 @@ import warnings
 import numpy as np
 import torch
 import torch.nn as nn
+import torch.nn.functional as F  # noqa: F401   (re-exported like the reference module does)
 from scipy.ndimage import zoom
 
 _CFG = [64, 64, "M", 128, 128, "M", 256, 256, 256, "M", 512, 512, 512]      # vgg16.features[:23]

@@ -15,6 +15,11 @@ import torch
 import torch.nn as nn
 from torch.autograd import Function
 
+import time  # noqa: F401   (the notebooks pick np, F, time up through ``from crf.gaussian_matrix import *``)
+
+import numpy as np  # noqa: F401
+import torch.nn.functional as F  # noqa: F401
+
 import phl
 
 latticefilter = phl.filter  # same symbol the reference binds at import (:16)

@@ -5,6 +5,12 @@ import re
 
 import numpy as np
 
+try:                                    # the reference module leaks these to ``from crf.utils import *`` users
+    from PIL import Image  # noqa: F401
+    import matplotlib.pyplot as plt  # noqa: F401
+except Exception:                       # headless / missing backends: readers below still work
+    pass
+
 
 def read_image(imgname):
     """RGB image as float64 [h, w, 3] in [0, 1]."""

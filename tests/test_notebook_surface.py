@@ -16,6 +16,28 @@ def test_densecrf_notebook_imports():
         assert hasattr(depth, name)
 
 
+def test_star_imports_give_the_names_the_other_notebooks_use():
+    """trainableDenseCRF / Spectral_clustering / benchmarking.ipynb do ``from crf.<module> import *`` and then use
+    module-level names of the reference modules (np, F, time, sp, identity_op, ...)."""
+    import crf.crf as legacy
+    import crf.depth as depth
+    import crf.features as features
+    import crf.gaussian_matrix as gm
+
+    for name in ("np", "F", "time", "LatticeGaussian", "LatticeFilter", "RbfLaplacian", "RbfLaplacianC", "GuidedAdjacency",
+                 "BatchedAdjacency", "latticefilter"):
+        assert hasattr(gm, name), name
+    for name in ("sp", "scipy", "np", "identity_op", "diag_op", "laplacian_op", "convolve_op", "normalized", "centroids"):
+        assert hasattr(depth, name), name
+    assert hasattr(features, "F") and hasattr(legacy, "mean_field_infer")
+    op = depth.identity_op((4, 5)) + 2.0 * depth.laplacian_op((4, 5))       # composes like in Spectral_clustering.ipynb
+    v = np.arange(20, dtype=float)
+    assert np.allclose(op @ v, v + 2.0 * depth.laplacian(v.reshape(4, 5)).reshape(-1))
+    assert depth.sp.sparse.linalg.LinearOperator is not None
+    img = np.random.default_rng(0).random((6, 7, 3))
+    assert abs(depth.normalized(img).mean()) < 1e-6
+
+
 def test_readers_round_trip(tmp_path):
     from PIL import Image
 
