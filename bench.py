@@ -13,7 +13,17 @@ bilateral features (SURVEY.md section 8d synthetic recipe).
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
 N > 1 shards the image by row bands over the ranks (strong scaling, same total volume); see
-depth-estimation_amd/phl/rowtile.py for the halo exchange over RCCL.
+depth-estimation_amd/phl/rowtile.py for the halo exchange over RCCL.  `--workload c5` instead
+gives every rank its own volume (BASELINE configs[4]; the reference's one-image-per-worker
+batch mode, crf/gaussian_matrix.py:370-377), no data-path collective, weak scaling.
+
+Launch forms (both supported):
+  * `python bench.py --gpus N ...` with no torchrun environment: this process becomes a
+    LAUNCHER -- it never touches the GPU (no torch import), starts N fresh rank processes of
+    this same file with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, forwards rank 0's JSON
+    line and exits with the worst child's code;
+  * `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`: RANK etc.
+    come from the environment, this process is one rank.
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -21,6 +31,10 @@ import json
 import os
 import sys
 import time
+
+# ROCr reads this at hsa_init, i.e. before the first torch.cuda / HIP call of the process: RCCL's
+# peer-to-peer transport needs dmabuf IPC on this pool.  Must precede `import torch`.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import numpy as np
 
@@ -37,6 +51,7 @@ WORKLOADS = {
     "band8": (192, 2048, 256, "one eighth of c3 (192 rows): the per-rank share of an 8-GPU row-band run, for overhead studies"),
 }
 SIGMA_XY, SIGMA_C = 8.0, 0.1
+JSON_OUT = sys.stdout
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
@@ -117,9 +132,12 @@ def pmc_traffic(kernel_names, workload):
     """HBM bytes per launch of the named kernel(s) from the committed rocprofv3 --pmc summary
     (counters cannot be collected from inside the timed process; FETCH_SIZE is doubled there as
     MI355X_MICROARCH.md prescribes for gfx950).  Only valid for the workload it was taken on."""
-    path = os.path.join(ROOT, "profiles", "r01_final_pmc_traffic.json")
-    if workload != "c3" or not os.path.exists(path):
+    import glob
+
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))     # newest round last
+    if workload != "c3" or not found:
         return None, None
+    path = found[-1]
     k = json.load(open(path))["kernels"]
     total = 0
     for name in kernel_names.split("+"):
@@ -128,37 +146,183 @@ def pmc_traffic(kernel_names, workload):
         if not hit:
             return None, None
         total += int(count or 1) * hit[0]["hbm_bytes_per_launch"]
-    return int(total), "profiles/r01_final_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, same command)"
+    return int(total), f"profiles/{os.path.basename(path)} (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, same command)"
 
 
-def cpu_baseline(feat, H, W, L, d, torch):
-    """Reference engine (oracle/_ref, the reference's own C++) or our C port, one thread, on a
-    bounded crop of the same workload.  Reported beside the GPU number; not a target."""
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def _cpu_filter_once(src, ref):
+    """One reference-shaped call (lattice rebuilt inside, as the reference does) on the CPU checker:
+    the reference's own engine when oracle/_ref travelled with the tree, else our C port."""
     from oracle import phl_oracle as po
 
+    if po.reference_available():
+        t0 = time.time()
+        _, M, st = po.reference_filter_timed(src, ref)
+        return "reference", time.time() - t0, int(M), dict(init=st[0], splat=st[1], blur=st[2], slice=st[3])
+    po.build_oracle()
+    t0 = time.time()
+    O = po.Oracle(ref)
+    tb = time.time() - t0
+    _, st = O.filter(src, timing=True)
+    return "port", time.time() - t0, int(O.M), dict(build=tb, splat=st[0], blur=st[1], slice=st[2])
+
+
+def cpu_worker(path):
+    """Child of cpu_baseline()'s batch leg: a fresh process (numpy + the CPU checker only, no torch, no GPU)
+    that filters one stored item -- the reference's `mp.Pool(num_threads).starmap(latticefilter, ...)`
+    worker (crf/gaussian_matrix.py:370-377)."""
+    z = np.load(path)
+    kind, dt, M, _ = _cpu_filter_once(z["src"], z["ref"])
+    print(json.dumps({"kind": kind, "seconds": dt, "M": M}))
+
+
+def cpu_baseline(feat, H, W, L, d):
+    """SURVEY.md 8(d) CPU baseline, timed on this box's host cores, beside (never inside) the GPU timing:
+      (i)   1 thread on a bounded crop of the bench workload (the reference filters one image per thread);
+      (ii)  batch mode: 8 independent items on P = min(8, nproc) worker PROCESSES, as the reference's
+            `BatchedAdjacency(num_threads=8)` pool does (crf/gaussian_matrix.py:342,370-377);
+      (iii) C1 (Tsukuba 384x288x16, BASELINE configs[0]) at FULL size, 1 thread.
+    The lattice is rebuilt in every call (reference behaviour).  A reported baseline, not a target."""
+    import subprocess
+    import tempfile
+
+    nproc = os.cpu_count() or 1
     ch, cw = min(H, 1024), min(W, 1536)      # ~10 s of single-thread CPU work at L=256
     ref = np.ascontiguousarray(feat[:ch, :cw].reshape(-1, d))
     rng = np.random.default_rng(4321)
     src = rng.random((ch * cw, L), dtype=np.float32)
     src /= src.sum(1, keepdims=True)
-    sample = f"top-left {cw}x{ch} crop of the same features, L={L}, 1 thread, lattice rebuilt per call (reference behaviour)"
-    if po.reference_available():
+    kind, dt, M, stages = _cpu_filter_once(src, ref)
+    out = {"value": round(ch * cw * L / dt / 1e6, 3), "unit": "Mpixel-labels/s", "cores": 1, "kind": kind,
+           "sample": f"top-left {cw}x{ch} crop of the same features, L={L}, 1 thread, lattice rebuilt per call (reference behaviour)",
+           "seconds": round(dt, 3), "M_over_n": round(M / (ch * cw), 4),
+           "stage_seconds": {k: round(float(v), 4) for k, v in stages.items()},
+           "nproc": nproc, "cpu_model": _cpu_model(),
+           "compiler": "g++ -O2 (oracle/build_ref.sh)" if kind == "reference" else "gcc -O2 -ffp-contract=off (oracle/Makefile)"}
+
+    # (ii) the reference's batch mode: one worker process per item, P at a time
+    items, P = 8, min(8, nproc)
+    bh, bw = min(H, 512), min(W, 768)        # 8 items of ~2.5 s each
+    bref = np.ascontiguousarray(feat[:bh, :bw].reshape(-1, d))
+    bsrc = np.ascontiguousarray(src[:bh * bw])
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, "item.npz")
+        np.savez(path, ref=bref, src=bsrc)
+        env = dict(os.environ, OMP_NUM_THREADS="1")
         t0 = time.time()
-        _, M, st = po.reference_filter_timed(src, ref)
-        dt = time.time() - t0
-        kind, stages = "reference", dict(init=st[0], splat=st[1], blur=st[2], slice=st[3])
-    else:
-        po.build_oracle()
-        t0 = time.time()
-        O = po.Oracle(ref)
-        tb = time.time() - t0
-        _, st = O.filter(src, timing=True)
-        dt = time.time() - t0
-        M = O.M
-        kind, stages = "port", dict(build=tb, splat=st[0], blur=st[1], slice=st[2])
-    return {"value": round(ch * cw * L / dt / 1e6, 3), "unit": "Mpixel-labels/s", "cores": 1, "kind": kind,
-            "sample": sample, "seconds": round(dt, 3), "M_over_n": round(M / (ch * cw), 4),
-            "stage_seconds": {k: round(float(v), 4) for k, v in stages.items()}}
+        done, running, per_item = 0, [], []
+        while done < items:
+            while len(running) < P and done + len(running) < items:
+                running.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", path],
+                                                stdout=subprocess.PIPE, env=env))
+            proc = running.pop(0)
+            o, _ = proc.communicate()
+            if proc.returncode != 0:
+                for q in running:
+                    q.kill()
+                raise RuntimeError("cpu_baseline: worker failed")
+            per_item.append(json.loads(o.decode().strip().splitlines()[-1])["seconds"])
+            done += 1
+        wall = time.time() - t0
+    out["batch"] = {"value": round(items * bh * bw * L / wall / 1e6, 3), "unit": "Mpixel-labels/s", "cores": P,
+                    "processes": P, "items": items, "seconds": round(wall, 3),
+                    "seconds_per_item_in_worker": round(float(np.mean(per_item)), 3),
+                    "sample": f"{items} independent {bw}x{bh}x{L} items (crops of the same features), one fresh worker "
+                              f"process per item, {P} at a time (mp.Pool(num_threads=8) semantics); wall time includes process start"}
+
+    # (iii) C1 at full size
+    H1, W1, L1, _ = WORKLOADS["c1"]
+    f1 = synthetic_features(H1, W1).reshape(-1, d)
+    s1 = rng.random((H1 * W1, L1), dtype=np.float32)
+    s1 /= s1.sum(1, keepdims=True)
+    reps, t = 5, []
+    for _ in range(reps):
+        _, dt1, M1, _ = _cpu_filter_once(s1, f1)
+        t.append(dt1)
+    out["c1_full"] = {"value": round(H1 * W1 * L1 / min(t) / 1e6, 3), "unit": "Mpixel-labels/s", "cores": 1,
+                      "seconds": round(min(t), 4), "M_over_n": round(M1 / (H1 * W1), 4),
+                      "sample": f"C1 {W1}x{H1}x{L1} full size (synthetic features of the SURVEY 8d recipe), best of {reps} calls, lattice rebuilt per call"}
+    return out
+
+
+# ---- launcher ----------------------------------------------------------------------------------
+def _free_port():
+    import socket
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def launch(n, argv):
+    """`python bench.py --gpus N` without a torchrun environment: start N fresh rank processes.
+
+    This parent has not imported torch and never touches the GPU, so nothing that has initialised
+    HIP is ever forked or re-executed.  Children get RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR /
+    MASTER_PORT (127.0.0.1 rendezvous) and HSA_ENABLE_IPC_MODE_LEGACY=0 in their environment
+    before they start.  Rank 0's stdout (the ONE JSON line) is forwarded; the other ranks' stdout
+    goes to stderr.  If a rank dies the others are terminated (by PID) and its code is returned."""
+    import subprocess
+
+    env = dict(os.environ)
+    env.update(WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
+               HSA_ENABLE_IPC_MODE_LEGACY="0", PHL_BENCH_LAUNCHED="1")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    procs = []
+    for r in range(n):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=e,
+                                      stdout=None if r == 0 else sys.stderr))
+    rc, alive = 0, list(procs)
+    while alive:
+        time.sleep(0.2)
+        for p in list(alive):
+            code = p.poll()
+            if code is None:
+                continue
+            alive.remove(p)
+            if code != 0 and rc == 0:
+                rc = code
+                for q in alive:          # a failed rank leaves the others stuck in a collective
+                    q.terminate()
+    return rc
+
+
+def dry_rank(args, rank, world):
+    """--dry-launch: the launch / rendezvous / barrier / max-over-ranks / one-JSON-line plumbing over gloo on
+    the CPU, without the filter (tests/test_bench_launch.py; there is no CPU filter to benchmark)."""
+    import torch
+    import torch.distributed as dist
+
+    if os.environ.get("PHL_BENCH_TEST_FAIL_RANK") == str(rank):      # tests: a rank that dies before the rendezvous
+        sys.exit(3)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        pass
+    dist.barrier()
+    t = torch.tensor([time.perf_counter() - t0 + 1e-3 * rank], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    env = {k: os.environ.get(k) for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "HSA_ENABLE_IPC_MODE_LEGACY")}
+    seen = [None] * world
+    dist.all_gather_object(seen, env)
+    if rank == 0:
+        print(json.dumps({"metric": "Mpixel-labels/s per CRF mean-field iter (splat+blur+slice)", "value": None,
+                          "unit": "Mpixel-labels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "dry_launch": True, "backend": "gloo", "max_over_ranks_s": float(t.item()),
+                          "launched_by": "bench.py launcher" if os.environ.get("PHL_BENCH_LAUNCHED") else "external (torchrun)",
+                          "rank_env": seen}), file=JSON_OUT, flush=True)
+    dist.destroy_process_group()
 
 
 def main():
@@ -172,31 +336,54 @@ def main():
     ap.add_argument("--exact", action="store_true", help="reference-exact arithmetic (bit-identical to the CPU path)")
     ap.add_argument("--graph", action="store_true", help="replay the step from a captured HIP graph (launch-bound sizes)")
     ap.add_argument("--force-rowtile", action="store_true", help="debug: run the row-band driver even with one rank")
+    ap.add_argument("--mean-field", action="store_true", help="also time one full mean-field iteration (extra key)")
+    ap.add_argument("--dry-launch", action="store_true", help="launcher / rendezvous plumbing only, gloo on CPU, no filter")
+    ap.add_argument("--cpu-worker", default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
 
-    import torch
+    if args.cpu_worker:
+        return cpu_worker(args.cpu_worker)
+
+    if "RANK" not in os.environ and args.gpus > 1:
+        sys.exit(launch(args.gpus, sys.argv[1:]))       # launcher: no torch import, no GPU touched in this process
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py: --gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
-        args.gpus = world
+    args.gpus = world
+    # stdout carries the ONE JSON line and nothing else: native libraries (gloo, RCCL, rocBLAS) write their
+    # chatter to fd 1, so fd 1 is pointed at stderr and the JSON goes to a private copy of the real stdout
+    global JSON_OUT
+    sys.stdout.flush()
+    JSON_OUT = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+    if args.dry_launch:
+        return dry_rank(args, rank, world)
+
+    import torch
+
     if not torch.cuda.is_available():
         sys.exit("bench.py: no HIP device; the lattice filter has no CPU path to benchmark")
     ensure_built(local_rank)
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank % ndev      # ranks share a card only in rehearsals on a 1-GPU box (then: gloo, see below)
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     dist = None
+    backend = None
     if world > 1 or args.force_rowtile:
         import torch.distributed as dist
 
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: what RCCL peer-to-peer needs on this pool
         if not (os.environ.get("MASTER_ADDR") and os.environ.get("MASTER_PORT")):
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        # one rank per GPU -> RCCL.  Two ranks on one card cannot form an RCCL communicator: gloo then
+        # carries the (small) control traffic and the row-band payloads through host memory.
+        backend = "nccl" if world <= ndev else "gloo"
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     import phl
 
@@ -218,7 +405,7 @@ def main():
         extra = job.describe()
     else:
         ref = torch.from_numpy(feat.reshape(-1, d)).to(device)
-        src = synthetic_values(torch, H, W, L, 0, device)
+        src = synthetic_values(torch, H, W, L, 1000 * rank, device)      # every rank its own volume
         torch.cuda.synchronize()
         t0 = time.time()
         lat = phl.Lattice(ref)
@@ -258,7 +445,7 @@ def main():
     sync_all()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        t = torch.tensor([dt], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ms_per_step = dt / args.steps * 1e3
@@ -274,7 +461,7 @@ def main():
         out = torch.empty_like(src)
         kw = dict(exact=False, no_tiles=False)
         extra["tiles"] = lat.tile_stats(L)
-    if rank == 0 or not rowtiled:
+    if rank == 0:
         ev = lambda: torch.cuda.Event(enable_timing=True)
         reps = max(3, min(args.steps, 10))
         acc = {"splat": 0.0, "blur": 0.0, "slice": 0.0}
@@ -297,6 +484,10 @@ def main():
         blur_launches = (d + 2) // 2
         dom = max(stage_ms, key=stage_ms.get)
         ab = algorithmic_bytes(n_local, M, L, d)
+        # what the blur launches really move when two axes share a pass (vertex array read + written once per
+        # launch, composed neighbour ids 32 B per vertex per pair, 8 B for an odd last axis)
+        npair = (d + 1) // 2
+        blur_fused_bytes = blur_launches * 8 * M * L + npair * 32 * M + ((d + 1) % 2) * 8 * M
         achieved = ab[dom] / (stage_ms[dom] * 1e-3) / 1e9
         staged = extra["tiles"]["staged_splat"] and not (args.no_tiles or args.exact)
         staged_sl = extra["tiles"]["staged_slice"] and not args.no_tiles
@@ -314,21 +505,29 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         copy_gbs = 2 * src.numel() * 4 * 5 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        per_stage = {k: {"ms": round(stage_ms[k], 4), "launches_per_step": (blur_launches if k == "blur" else 1),
+                         "algorithmic_GBps": round(ab[k] / (stage_ms[k] * 1e-3) / 1e9, 1)} for k in stage_ms}
+        # blur: the 8(d) figure counts d+1 single-axis passes; the launches move less (two axes per pass)
+        per_stage["blur"]["fused_pass_bytes"] = int(blur_fused_bytes)
+        per_stage["blur"]["fused_pass_GBps"] = round(blur_fused_bytes / (stage_ms["blur"] * 1e-3) / 1e9, 1)
         roofline = {"bound": "hbm", "kernel": kname[dom],
                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                     "algorithmic_bytes_per_launch": int(ab[dom]), "avg_launch_ms": round(stage_ms[dom], 4),
-                    "per_stage": {k: {"ms": round(stage_ms[k], 4), "launches_per_step": (blur_launches if k == "blur" else 1),
-                                      "algorithmic_GBps": round(ab[k] / (stage_ms[k] * 1e-3) / 1e9, 1)} for k in stage_ms},
+                    "per_stage": per_stage,
                     # north-star wording: blur-pass READ bytes (d+1)*4*M*L against the HBM-read roofline
                     "measured_copy_GBps": round(copy_gbs, 1), "frac_of_measured_copy": round(achieved / copy_gbs, 4),
                     "blur_read_frac_of_peak": round((d + 1) * 4 * M * L / (stage_ms["blur"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
         if rowtiled:
             roofline["scope"] = f"rank 0's band only ({n_local} pixels, {M} vertices incl. ghosts); kernels as in the 1-GPU run"
 
+    mean_field = None
+    if args.mean_field and rank == 0 and not rowtiled:
+        mean_field = mean_field_iteration(torch, phl, lat, src, L, device)
+
     cpu = None
     if rank == 0 and world == 1 and not rowtiled and not args.no_cpu_baseline:
-        cpu = cpu_baseline(feat, H, W, L, d, torch)
+        cpu = cpu_baseline(feat, H, W, L, d)
 
     if rank == 0:
         line = {
@@ -343,16 +542,48 @@ def main():
                                        f"{world} independent volumes, one per GPU, no collective"),
                        "launch": "hip graph replay" if (args.graph and not rowtiled) else "eager",
                        "arithmetic": "reference-exact (bit-identical to the CPU path)" if args.exact else "default (fp32-rounding-equivalent, ~1e-7 rel)"},
+            "ranks": world, "backend": backend, "devices_visible": ndev,
+            "launched_by": "bench.py launcher" if os.environ.get("PHL_BENCH_LAUNCHED") else ("torchrun" if "TORCHELASTIC_RUN_ID" in os.environ else "direct"),
             "lattice_build_ms": round(build_ms, 2),
             # the reference rebuilds its lattice in every filter call: the same metric with a (steady-state, warm
             # scratch) build added to every step -- SURVEY 8d asks for both
             "value_rebuild_each_iter": round(volumes * n_total * L / ((ms_per_step + extra.get("lattice_build_warm_ms", build_ms)) * 1e-3) / 1e6, 1),
             "roofline": roofline, "cpu_baseline": cpu,
         }
+        if mean_field is not None:
+            line["mean_field_iteration"] = mean_field
         line.update(extra)
-        print(json.dumps(line))
+        print(json.dumps(line), file=JSON_OUT, flush=True)
     if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
+
+
+def mean_field_iteration(torch, phl, lat, Q, L, device):
+    """One full mean-field iteration of crf/crf_module.py:49-52 around the cached lattice:
+    G = (filter(Q) - Q) @ Mu ; Q' = softmax(-(E0 + G)).  Extra key, not the headline metric."""
+    from crf.crf_module import charbonneir, compatibility_matrix, mean_field_step
+
+    labels = torch.arange(L, dtype=torch.float32, device=device)
+    Mu = compatibility_matrix(lambda a, b: charbonneir(a, b, 3.0), labels)
+    g = torch.Generator(device=device)
+    g.manual_seed(99)
+    E0 = torch.rand(Q.shape, generator=g, device=device) * 10.0
+    Qn = torch.empty_like(Q)
+    W = lambda U: lat.filter(U, subtract_input=True)
+    for _ in range(2):
+        mean_field_step(E0, W, Mu, Q, out=Qn)
+    ev = lambda: torch.cuda.Event(enable_timing=True)
+    e0, e1 = ev(), ev()
+    reps = 5
+    e0.record()
+    for _ in range(reps):
+        mean_field_step(E0, W, Mu, Q, out=Qn)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    return {"ms": round(ms, 3), "Mpixel_labels_per_s": round(Q.shape[0] * L / (ms * 1e-3) / 1e6, 1),
+            "what": "filter - Q (fused), (.)@Mu + E0 + softmax(-.)"}
 
 
 if __name__ == "__main__":

@@ -55,23 +55,46 @@ def _fused_ok(E_0, Mu):
             and not (torch.is_grad_enabled() and (E_0.requires_grad or Mu.requires_grad)))
 
 
+def mean_field_step(E_0, W, Mu, Q, out=None):
+    """One iteration ``softmax(-(E_0 + (W @ Q) @ Mu))`` (crf_module.py:51-52) on the fused device path.
+
+    ``W`` is an operator (``@``) or a callable.  The raw-pointer kernels below know nothing of autograd, so
+    the caller must have established that no gradient flows (``mean_field_infer`` does)."""
+    import phl
+
+    X = W(Q) if callable(W) and not hasattr(W, "__matmul__") else W @ Q
+    if not (X.is_cuda and X.dtype == torch.float32 and X.stride(1) == 1):
+        X = X.to(E_0.device, torch.float32).contiguous()
+    return phl.compat_softmax(E_0, X, Mu, out=out)
+
+
 def mean_field_infer(E_0, W, Mu, niters=10):
     """[E_0] n x L unaries, [W] n x n operator, [Mu] L x L compatibility -> Q n x L (crf_module.py:41-53).
 
-    On the GPU inference path the elementwise half of an iteration (add, negate, softmax: ~7
-    sweeps over [n, L] in torch) is one fused HIP pass (phl.softmax_neg_add); the compatibility
-    product stays a library GEMM.  With autograd or CPU tensors the plain torch ops run."""
+    On the GPU inference path everything of an iteration outside the lattice filter -- the compatibility
+    product, the add, the negation and the softmax -- is ONE fused HIP kernel (phl.compat_softmax: fp32 MFMA
+    tiles of X @ Mu with the softmax as epilogue, so neither G nor E ever exists in HBM).  With autograd
+    (E_0, Mu, or anything W carries -- e.g. a LatticeGaussian whose ``ref`` requires grad) or CPU tensors
+    the plain, differentiable torch ops run."""
     if _fused_ok(E_0, Mu):
         import phl
 
         Q = phl.softmax_neg_add(E_0)
+        fused = True
         for _ in range(niters):
-            # (torch.addmm(E_0, X, Mu) would fold the add into the GEMM, but rocBLAS' beta=1 path
-            # measured 1.5 ms slower than mm at 3.1M x 256 x 256, more than the pass it saves)
-            G = (W @ Q) @ Mu
-            if not (G.is_cuda and G.dtype == torch.float32 and G.stride(1) == 1):
-                G = G.to(E_0.device, torch.float32).contiguous()
-            Q = phl.softmax_neg_add(E_0, G, out=Q)
+            if fused:
+                X = W @ Q
+                if torch.is_grad_enabled() and X.requires_grad:
+                    # W itself is being differentiated: the raw-pointer kernels would drop its graph (and
+                    # overwrite a tensor LatticeFilter saved for backward) -> differentiable path from here on
+                    fused = False
+                    Q = F.softmax(-(E_0 + X @ Mu), dim=1)
+                    continue
+                if not (X.is_cuda and X.dtype == torch.float32 and X.stride(1) == 1):
+                    X = X.to(E_0.device, torch.float32).contiguous()
+                Q = phl.compat_softmax(E_0, X, Mu, out=Q)
+            else:
+                Q = F.softmax(-(E_0 + (W @ Q) @ Mu), dim=1)
         return Q
     Q = F.softmax(-E_0, dim=1)
     for _ in range(niters):

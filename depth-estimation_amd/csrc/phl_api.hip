@@ -155,6 +155,12 @@ int phl_device_count(void)
 int phl_build(phl_lattice **out, const float *ref_dev, int64_t n, int d, int64_t rs, int64_t cs, int device,
               phl_stream stream)
 {
+    return phl_build_ex(out, ref_dev, n, d, rs, cs, device, stream, PHL_BUILD_DEFAULT);
+}
+
+int phl_build_ex(phl_lattice **out, const float *ref_dev, int64_t n, int d, int64_t rs, int64_t cs, int device,
+                 phl_stream stream, unsigned build_flags)
+{
     if (!out) { phl_set_error("phl_build: out is NULL"); return PHL_ERR_INVALID; }
     *out = nullptr;
     if (n < 0 || d < 1 || (n > 0 && !ref_dev)) { phl_set_error("phl_build: bad arguments (n=%lld d=%d)", (long long)n, d); return PHL_ERR_INVALID; }
@@ -169,6 +175,8 @@ int phl_build(phl_lattice **out, const float *ref_dev, int64_t n, int d, int64_t
     lat->device = device;
     lat->d = d;
     lat->n = n;
+    lat->build_flags = build_flags;
+    lat->nbr00_override = -2;
     int rc = phl_build_device(lat, ref_dev, rs, cs, (hipStream_t)stream);
     if (rc == PHL_OK) rc = phl_tiles_build(lat, ref_dev, rs, cs, (hipStream_t)stream);
     if (rc != PHL_OK) {

@@ -298,12 +298,20 @@ __global__ __launch_bounds__(256) void k_compose_pairs(const int2 *__restrict__ 
     nbr2[idx * 2 + 1] = make_int4(a0.y, ap.x, nb.y, ap.y);
 }
 
-// (re)build the persistent key -> vertex table from the distinct vertex keys
+struct hidden_t {
+    int n;
+    int32_t id[PHL_MAX_HIDDEN];
+};
+
+// (re)build the persistent key -> vertex table from the distinct vertex keys (reference-table mode: the
+// duplicates the reference's own table cannot reach stay out)
 __global__ __launch_bounds__(256) void k_table_insert(const int16_t *__restrict__ vkeys, int d, int M, int *table,
-                                                      uint32_t mask)
+                                                      uint32_t mask, hidden_t hidden)
 {
     const int v = blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= M) return;
+    for (int i = 0; i < hidden.n; i++)
+        if (hidden.id[i] == v) return;
     const int16_t *key = vkeys + (int64_t)v * d;
     uint32_t h = mix_begin();
     for (int i = 0; i < d; i++) h = mix_step(h, key[i]);
@@ -375,11 +383,16 @@ static int phl_rebuild_table_and_neighbors(phl_lattice *lat, hipStream_t st)
     PHL_HIP(hipMalloc((void **)&lat->nbr, sizeof(int32_t) * (size_t)(M ? M : 1) * (d + 1) * 2));
     hipLaunchKernelGGL(k_fill_i32, dim3(1024), dim3(256), 0, st, lat->table, (int64_t)cap, PHL_EMPTY);
     if (M > 0) {
+        hidden_t hidden;
+        hidden.n = lat->n_hidden;
+        for (int i = 0; i < lat->n_hidden; i++) hidden.id[i] = lat->hidden[i];
         hipLaunchKernelGGL(k_table_insert, dim3((M + 255) / 256), dim3(256), 0, st, lat->vkeys, d, M, lat->table,
-                           lat->table_mask);
+                           lat->table_mask, hidden);
         const int64_t tot = (int64_t)M * (d + 1);
         hipLaunchKernelGGL(k_neighbors, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, lat->vkeys, d, M,
                            lat->table, lat->table_mask, lat->nbr);
+        if (lat->nbr00_override != -2)    // a table doubling inside the reference's blur(): phl_reftable.hip
+            PHL_HIP(hipMemcpyAsync(lat->nbr, &lat->nbr00_override, sizeof(int32_t), hipMemcpyHostToDevice, st));
         const int npairs = (d + 1) / 2;
         PHL_HIP(hipMalloc((void **)&lat->nbr2, sizeof(int32_t) * (size_t)M * npairs * 8));
         const int64_t totp = (int64_t)M * npairs;
@@ -398,6 +411,8 @@ int phl_build_device(phl_lattice *lat, const float *ref, int64_t rs, int64_t cs,
     lat->N = N64;
     lat->M = 0;
     lat->M_local = 0;
+    lat->n_hidden = 0;
+    lat->nbr00_override = -2;
     if (n == 0) return phl_rebuild_table_and_neighbors(lat, st);
     const int N = (int)N64;
 
@@ -460,7 +475,11 @@ int phl_build_device(phl_lattice *lat, const float *ref, int64_t rs, int64_t cs,
     hipLaunchKernelGGL(k_assign, dim3(gN), dim3(256), 0, st, flag, rankv, slot_of, ckeys, d, N, table, lat->vkeys);
     hipLaunchKernelGGL(k_set_vid, dim3(gN), dim3(256), 0, st, table, slot_of, N, lat->replay);
     PHL_HIP(hipGetLastError());
-    lat->M_local = M;
+    if (lat->build_flags & PHL_BUILD_REFERENCE_TABLE) {
+        rc = phl_apply_reference_table(lat, flag, rankv, st);
+        if (rc) return rc;
+    }
+    lat->M_local = lat->M;
     rc = phl_rebuild_table_and_neighbors(lat, st);
     if (rc) return rc;
     PHL_HIP(hipGetLastError());

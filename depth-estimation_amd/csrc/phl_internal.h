@@ -5,7 +5,10 @@
 
 #include "phl.h"
 
+#include <vector>
+
 #define PHL_WAVE 64
+#define PHL_MAX_HIDDEN 64   // duplicate vertices of the reference-table mode (<= 2 per table doubling)
 #define PHL_EMPTY 0x7FFFFFFF  // empty hash slot (larger than any candidate index)
 
 // (vertex, weight) per (pixel, remainder): the sparse n x M splat matrix, d+1 entries per
@@ -66,7 +69,34 @@ struct phl_lattice {
     int64_t stage_elems;
 
     int64_t table_bytes;    // device bytes of the persistent tables
+
+    // PHL_BUILD_REFERENCE_TABLE (phl_reftable.hip): vertices the reference's final hash table cannot reach
+    // (duplicates of a key; never anybody's blur neighbour), and the one neighbour entry a doubling inside
+    // blur() decides (-2 = none)
+    unsigned build_flags;
+    int n_hidden;
+    int32_t hidden[PHL_MAX_HIDDEN];
+    int32_t nbr00_override;
 };
+
+// host replay of the reference's hash table (phl_reftable.hip)
+struct phl_reftable_query {
+    virtual int vid_at(int64_t candidate) = 0;                          // clean vertex id of a candidate
+    virtual int64_t next_occurrence(int clean_vid, int64_t after) = 0;  // next candidate with that key, or -1
+    virtual ~phl_reftable_query() {}
+};
+struct phl_reftable_result {
+    int64_t M_ref;
+    std::vector<int16_t> keys;      // [M_ref][d] in the reference's insertion order
+    std::vector<int32_t> remap;     // [M_clean] reference vertex, or -(k+1) for tracked key k
+    std::vector<int32_t> dup_clean, dup_ptr, seg_e, seg_id;
+    std::vector<int32_t> hidden;
+    bool blur_grow;
+    int32_t blur_first_nbr;
+};
+int phl_reference_table_sim(const int16_t *keys_clean, const int32_t *efirst, int64_t M, int d, int64_t N,
+                            phl_reftable_query &q, phl_reftable_result &out);
+int phl_apply_reference_table(phl_lattice *lat, const int *flag, const int *rankv, hipStream_t st);
 
 // thread-local error message
 void phl_set_error(const char *fmt, ...);

@@ -1,0 +1,419 @@
+// phl_reftable.hip -- PHL_BUILD_REFERENCE_TABLE: reproduce the OBSERVABLE behaviour of the reference's hash
+// table across its doublings (crf/lattice/lite/permutohedral.h:29-169).
+//
+// What is observable.  The reference numbers vertices in insertion order and finds them through an open-
+// addressing table that starts at 2^15 slots and doubles when `filled >= capacity/2 - 1` (:62).  lookup()
+// computes h = hash(k) % capacity BEFORE lookupOffset() may grow() the table (:101-103, :59-62), and then
+// keeps probing from that stale h in the doubled table.  The ONE key in flight at a doubling is therefore
+// probed from the wrong place whenever hash % (2 cap) != hash % cap: it is not found there, so splat()
+// (create = true) appends a SECOND vertex with the same key, filed where later lookups (which hash with the
+// new capacity) cannot see it until the next grow() re-files every entry.  Effects on the result: M is
+// larger by one per such doubling, the contributions of that key are split over two vertices, and blur()'s
+// neighbour lookups see only one of them.  0.3-4 % of output rows move by more than 1e-4
+// (tests/golden/PIN_REPORT.json).
+//
+// The default build of this library implements the algorithm without that defect (every key has one
+// vertex).  With PHL_BUILD_REFERENCE_TABLE the build additionally replays the reference's table on the host
+// and re-labels the device lattice so that vertex numbering, duplicate vertices, the per-pixel vertex each
+// lookup resolved to, and the vertices blur can see are EXACTLY the reference's -- the filter is then
+// bit-identical to the reference's CPU path at any size (tests: growth_*.npz, outputs of the reference
+// engine itself).
+//
+// How.  Everything outside the doublings is history-independent: a key that has one properly filed entry
+// always resolves to it.  So the replay is event driven over the CLEAN first-touch vertex list the device
+// build produced (M keys + the candidate index e = pixel*(d+1)+remainder of each first touch):
+//   * creations in first-touch order keep the simulated table (same hash, same linear probe, same
+//     slot-order re-filing in grow(), :122-155) in the reference's state at every moment;
+//   * when `filled` reaches capacity/2 - 1 the NEXT lookup -- candidate e+1, whose key is fetched from the
+//     device -- grows the table and probes from its stale slot;
+//   * a key with an unreachable or duplicated entry is tracked: which vertex its lookups resolve to can
+//     only change at a doubling or at its first lookup after one (then fixed: entries never move inside an
+//     epoch and a probe path never contains an empty slot), so each such key gets a short list of
+//     (from candidate index, vertex) segments.  At most two extra vertices per doubling.
+// The device then re-labels replay[].vid (one pass), uploads the new key list, and builds its own lookup
+// table from the vertices the reference's final table can reach.
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <queue>
+#include <unordered_map>
+#include <vector>
+
+#include "phl_device_utils.h"
+
+namespace {
+
+struct ref_sim {
+    int d = 0;
+    uint64_t cap = (uint64_t)1 << 15;   // :36
+    std::vector<int32_t> slots;
+    std::vector<int16_t> keys;          // [F][d], insertion order
+    int64_t F = 0;
+
+    explicit ref_sim(int d_) : d(d_), slots((size_t)1 << 15, -1) {}
+    uint64_t hash(const int16_t *k) const    // :109-116, size_t arithmetic
+    {
+        uint64_t h = 0;
+        for (int i = 0; i < d; i++) {
+            h += (uint64_t)(int64_t)k[i];
+            h *= 2531011;
+        }
+        return h;
+    }
+    bool need_grow() const { return (uint64_t)F >= cap / 2 - 1; }   // :62
+    void grow()                                                      // :122-155, entries re-filed in old slot order
+    {
+        std::vector<int32_t> old;
+        old.swap(slots);
+        const uint64_t oldcap = cap;
+        cap *= 2;
+        slots.assign((size_t)cap, -1);
+        for (uint64_t i = 0; i < oldcap; i++) {
+            if (old[i] < 0) continue;
+            uint64_t h = hash(keys.data() + (size_t)old[i] * d) % cap;
+            while (slots[h] >= 0) { h++; if (h == cap) h = 0; }
+            slots[h] = old[i];
+        }
+    }
+    // linear probe from slot h (:65-90); returns the vertex or -1
+    int32_t probe(const int16_t *key, uint64_t h, bool create, bool *created)
+    {
+        *created = false;
+        for (;;) {
+            const int32_t v = slots[h];
+            if (v < 0) {
+                if (!create) return -1;
+                keys.insert(keys.end(), key, key + d);
+                slots[h] = (int32_t)F;
+                *created = true;
+                return (int32_t)(F++);
+            }
+            if (memcmp(keys.data() + (size_t)v * d, key, sizeof(int16_t) * d) == 0) return v;
+            h++;
+            if (h == cap) h = 0;
+        }
+    }
+    int32_t lookup(const int16_t *key, bool create, bool *created) { return probe(key, hash(key) % cap, create, created); }
+};
+
+struct dup_key {
+    int clean;                                       // clean vertex id of the key
+    std::vector<std::pair<int32_t, int32_t>> seg;    // (from candidate index, reference vertex), ascending
+    int64_t pending_e = -1;                          // scheduled "first lookup since it became unreachable"
+};
+
+}  // namespace
+
+// Host replay.  keys_clean [M][d] and efirst [M] (candidate index of each clean vertex's first touch,
+// ascending) come from the device build; `q` answers the two questions the replay has about individual
+// candidates.  See the file header.
+int phl_reference_table_sim(const int16_t *keys_clean, const int32_t *efirst, int64_t M, int d, int64_t N,
+                            phl_reftable_query &q, phl_reftable_result &out)
+{
+    ref_sim sim(d);
+    sim.keys.reserve((size_t)(M + 64) * d);
+    std::vector<int32_t> primary((size_t)M, -1);
+    std::vector<dup_key> dups;
+    std::unordered_map<int, int> dup_index;
+    using ev = std::pair<int64_t, int>;              // (candidate index, index into dups)
+    std::priority_queue<ev, std::vector<ev>, std::greater<ev>> pending;
+    const int64_t INF = (int64_t)1 << 62;
+
+    auto key_of = [&](int clean) { return keys_clean + (size_t)clean * d; };
+    auto dup_for = [&](int clean) -> int {
+        auto it = dup_index.find(clean);
+        if (it != dup_index.end()) return it->second;
+        dup_key D;
+        D.clean = clean;
+        if (primary[clean] >= 0) D.seg.push_back({efirst[clean], primary[clean]});
+        dups.push_back(D);
+        dup_index[clean] = (int)dups.size() - 1;
+        return (int)dups.size() - 1;
+    };
+
+    int64_t vi = 0, t_last = -1;
+    for (;;) {
+        if (sim.need_grow()) {
+            // `filled` reached capacity/2 - 1 at the creation at t_last: the very next lookup grows the table
+            const int64_t eg = t_last + 1;
+            if (eg >= N) break;                       // that lookup is blur's first one: below
+            const bool first_touch = vi < M && efirst[vi] == eg;
+            int K = first_touch ? (int)vi : q.vid_at(eg);
+            if (K < 0 || K >= M) return PHL_ERR_INVALID;
+            const int16_t *key = key_of(K);
+            const uint64_t h_old = sim.hash(key) % sim.cap;     // :102, computed before grow()
+            sim.grow();
+            const uint64_t h_new = sim.hash(key) % sim.cap;
+            bool created = false;
+            const int32_t r = sim.probe(key, h_old, true, &created);
+            if (first_touch) {
+                primary[K] = r;
+                vi++;
+            }
+            if ((created && h_new != h_old) || dup_index.count(K)) {
+                const int di = dup_for(K);                       // base segment: (first touch, primary)
+                if (!(first_touch && dups[di].seg.size() == 1 && dups[di].seg[0].second == r))
+                    dups[di].seg.push_back({(int32_t)eg, r});     // this one candidate resolved to r
+                if (dups[di].pending_e == eg) dups[di].pending_e = -1;
+            }
+            while (!pending.empty() && pending.top().first == eg) pending.pop();   // it was this lookup
+            // every tracked key: what do lookups resolve to in the re-filed table?
+            for (size_t i = 0; i < dups.size(); i++) {
+                bool c;
+                const int32_t rr = sim.lookup(key_of(dups[i].clean), false, &c);
+                if (rr >= 0) {
+                    dups[i].seg.push_back({(int32_t)(eg + 1), rr});
+                } else if (dups[i].pending_e <= eg) {
+                    // only an unreachable copy exists: the key's next lookup will append another vertex
+                    const int64_t en = q.next_occurrence(dups[i].clean, eg);
+                    dups[i].pending_e = en;
+                    if (en >= 0) pending.push({en, (int)i});
+                }
+            }
+            t_last = eg;
+            continue;
+        }
+        const int64_t e_c = vi < M ? (int64_t)efirst[vi] : INF;
+        while (!pending.empty() && dups[pending.top().second].pending_e != pending.top().first) pending.pop();   // stale
+        const int64_t e_p = pending.empty() ? INF : pending.top().first;
+        if (e_c == INF && e_p == INF) break;
+        bool created = false;
+        if (e_c <= e_p) {
+            const int32_t r = sim.lookup(key_of((int)vi), true, &created);
+            if (!created) return PHL_ERR_INVALID;     // a clean first touch must be new to the table
+            primary[vi] = r;
+            vi++;
+            t_last = e_c;
+        } else {
+            const int di = pending.top().second;
+            pending.pop();
+            const int32_t r = sim.lookup(key_of(dups[di].clean), true, &created);
+            dups[di].seg.push_back({(int32_t)e_p, r});
+            dups[di].pending_e = -1;
+            t_last = e_p;
+        }
+    }
+
+    // blur()'s lookups (create = false) grow the table too when splat left it at the threshold (:62 has no
+    // `create` test); the first neighbour lookup -- axis 0, vertex 0, key+1 with coordinate 0 at key-d
+    // (:504-509) -- is then the one probed from a stale slot.
+    out.blur_grow = false;
+    out.blur_first_nbr = -1;
+    if (sim.F > 0 && sim.need_grow()) {
+        std::vector<int16_t> n1(d);
+        for (int i = 0; i < d; i++) n1[i] = (int16_t)(sim.keys[i] + 1);
+        n1[0] = (int16_t)(sim.keys[0] - d);
+        const uint64_t h_old = sim.hash(n1.data()) % sim.cap;
+        sim.grow();
+        bool c;
+        out.blur_first_nbr = sim.probe(n1.data(), h_old, false, &c);
+        out.blur_grow = true;
+    }
+
+    out.M_ref = sim.F;
+    out.keys.swap(sim.keys);
+    sim.keys = out.keys;                    // the final lookups below still need them
+    out.remap.assign(primary.begin(), primary.end());
+    out.dup_clean.clear();
+    out.dup_ptr.assign(1, 0);
+    out.seg_e.clear();
+    out.seg_id.clear();
+    out.hidden.clear();
+    for (size_t i = 0; i < dups.size(); i++) {
+        const dup_key &D = dups[i];
+        bool c;
+        const int32_t visible = sim.lookup(key_of(D.clean), false, &c);
+        std::vector<int32_t> ids;
+        for (auto &s : D.seg) ids.push_back(s.second);
+        std::sort(ids.begin(), ids.end());
+        ids.erase(std::unique(ids.begin(), ids.end()), ids.end());
+        for (int32_t id : ids)
+            if (id != visible) out.hidden.push_back(id);
+        out.remap[D.clean] = -(int32_t)(i + 1);
+        out.dup_clean.push_back(D.clean);
+        for (auto &s : D.seg) {
+            out.seg_e.push_back(s.first);
+            out.seg_id.push_back(s.second);
+        }
+        out.dup_ptr.push_back((int32_t)out.seg_e.size());
+    }
+    std::sort(out.hidden.begin(), out.hidden.end());
+    return PHL_OK;
+}
+
+namespace {
+
+// ---- device side ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_efirst(const int *__restrict__ flag, const int *__restrict__ rankv, int N,
+                                                int *__restrict__ efirst)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < N && flag[e]) efirst[rankv[e]] = e;
+}
+
+__global__ __launch_bounds__(256) void k_next_occurrence(const phl_replay_t *__restrict__ replay, int N, int vid, int after,
+                                                         int *__restrict__ out)
+{
+    int best = 0x7FFFFFFF;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < N; e += gridDim.x * blockDim.x)
+        if (e > after && replay[e].vid == vid && e < best) best = e;
+    for (int o = 32; o > 0; o >>= 1) best = min(best, __shfl_xor(best, o));
+    if ((threadIdx.x & 63) == 0 && best != 0x7FFFFFFF) atomicMin(out, best);
+}
+
+__global__ __launch_bounds__(256) void k_relabel(phl_replay_t *__restrict__ replay, int N, const int *__restrict__ remap,
+                                                 const int *__restrict__ dup_ptr, const int *__restrict__ seg_e,
+                                                 const int *__restrict__ seg_id)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= N) return;
+    int r = remap[replay[e].vid];
+    if (r < 0) {                       // a key with several vertices: the last segment that starts at or before e
+        const int k = -r - 1;
+        int id = seg_id[dup_ptr[k]];
+        for (int s = dup_ptr[k]; s < dup_ptr[k + 1] && seg_e[s] <= e; s++) id = seg_id[s];
+        r = id;
+    }
+    replay[e].vid = r;
+}
+
+struct device_query : phl_reftable_query {
+    const phl_replay_t *replay;
+    int N;
+    int *scratch;            // one device int
+    hipStream_t st;
+    hipError_t err = hipSuccess;
+    int vid_at(int64_t e) override
+    {
+        int v = -1;
+        hipError_t r = hipMemcpyAsync(&v, &replay[e].vid, sizeof(int), hipMemcpyDeviceToHost, st);
+        if (r == hipSuccess) r = hipStreamSynchronize(st);
+        if (r != hipSuccess) { err = r; return -1; }
+        return v;
+    }
+    int64_t next_occurrence(int vid, int64_t after) override
+    {
+        int v = 0x7FFFFFFF;
+        hipError_t r = hipMemcpyAsync(scratch, &v, sizeof(int), hipMemcpyHostToDevice, st);
+        if (r == hipSuccess) {
+            hipLaunchKernelGGL(k_next_occurrence, dim3(1024), dim3(256), 0, st, replay, N, vid, (int)after, scratch);
+            r = hipMemcpyAsync(&v, scratch, sizeof(int), hipMemcpyDeviceToHost, st);
+        }
+        if (r == hipSuccess) r = hipStreamSynchronize(st);
+        if (r != hipSuccess) { err = r; return -1; }
+        return v == 0x7FFFFFFF ? -1 : v;
+    }
+};
+
+}  // namespace
+
+// Called by phl_build_device between the clean numbering and the neighbour tables.  flag / rankv are the
+// first-touch flags and their exclusive scan over the N candidates; replay[].vid holds clean ids.
+int phl_apply_reference_table(phl_lattice *lat, const int *flag, const int *rankv, hipStream_t st)
+{
+    const int d = lat->d;
+    const int64_t M = lat->M;
+    const int N = (int)lat->N;
+    lat->n_hidden = 0;
+    lat->nbr00_override = -2;
+    if (M < (1 << 14) - 1) return PHL_OK;            // the reference's table never doubles: nothing to reproduce
+    temp_pool tmp;
+    int *efirst_dev, *scratch;
+    PHL_HIP(tmp.get(&efirst_dev, (size_t)M));
+    PHL_HIP(tmp.get(&scratch, 1));
+    hipLaunchKernelGGL(k_efirst, dim3((N + 255) / 256), dim3(256), 0, st, flag, rankv, N, efirst_dev);
+    PHL_HIP(hipGetLastError());
+    std::vector<int16_t> keys((size_t)M * d);
+    std::vector<int32_t> efirst((size_t)M);
+    PHL_HIP(hipMemcpyAsync(keys.data(), lat->vkeys, sizeof(int16_t) * keys.size(), hipMemcpyDeviceToHost, st));
+    PHL_HIP(hipMemcpyAsync(efirst.data(), efirst_dev, sizeof(int32_t) * efirst.size(), hipMemcpyDeviceToHost, st));
+    PHL_HIP(hipStreamSynchronize(st));
+
+    device_query q;
+    q.replay = lat->replay;
+    q.N = N;
+    q.scratch = scratch;
+    q.st = st;
+    phl_reftable_result R;
+    int rc = phl_reference_table_sim(keys.data(), efirst.data(), M, d, N, q, R);
+    if (q.err != hipSuccess) return phl_hip_fail(q.err, "reference-table device query", __FILE__, __LINE__);
+    if (rc) { phl_set_error("reference-table replay failed (inconsistent first-touch list)"); return rc; }
+    if ((int)R.hidden.size() > PHL_MAX_HIDDEN) { phl_set_error("reference-table replay: too many duplicate vertices"); return PHL_ERR_UNSUPPORTED; }
+
+    if (R.M_ref != M || !R.dup_clean.empty()) {
+        int *remap_dev, *dup_ptr_dev, *seg_e_dev, *seg_id_dev;
+        PHL_HIP(tmp.get(&remap_dev, (size_t)M));
+        PHL_HIP(tmp.get(&dup_ptr_dev, R.dup_ptr.size()));
+        PHL_HIP(tmp.get(&seg_e_dev, R.seg_e.size() + 1));
+        PHL_HIP(tmp.get(&seg_id_dev, R.seg_id.size() + 1));
+        PHL_HIP(hipMemcpyAsync(remap_dev, R.remap.data(), sizeof(int) * (size_t)M, hipMemcpyHostToDevice, st));
+        PHL_HIP(hipMemcpyAsync(dup_ptr_dev, R.dup_ptr.data(), sizeof(int) * R.dup_ptr.size(), hipMemcpyHostToDevice, st));
+        if (!R.seg_e.empty()) {
+            PHL_HIP(hipMemcpyAsync(seg_e_dev, R.seg_e.data(), sizeof(int) * R.seg_e.size(), hipMemcpyHostToDevice, st));
+            PHL_HIP(hipMemcpyAsync(seg_id_dev, R.seg_id.data(), sizeof(int) * R.seg_id.size(), hipMemcpyHostToDevice, st));
+        }
+        hipLaunchKernelGGL(k_relabel, dim3((N + 255) / 256), dim3(256), 0, st, lat->replay, N, remap_dev, dup_ptr_dev,
+                           seg_e_dev, seg_id_dev);
+        PHL_HIP(hipGetLastError());
+        int16_t *vkeys_new;
+        PHL_HIP(hipMalloc((void **)&vkeys_new, sizeof(int16_t) * (size_t)R.M_ref * d));
+        PHL_HIP(hipMemcpyAsync(vkeys_new, R.keys.data(), sizeof(int16_t) * (size_t)R.M_ref * d, hipMemcpyHostToDevice, st));
+        PHL_HIP(hipStreamSynchronize(st));            // host vectors and pool temporaries die on return
+        PHL_HIP(hipFree(lat->vkeys));
+        lat->vkeys = vkeys_new;
+        lat->M = R.M_ref;
+    }
+    lat->n_hidden = (int)R.hidden.size();
+    for (int i = 0; i < lat->n_hidden; i++) lat->hidden[i] = R.hidden[i];
+    if (R.blur_grow) lat->nbr00_override = R.blur_first_nbr;
+    return PHL_OK;
+}
+
+// CPU-only entry for tests: the same replay with the candidates' clean vertex ids in a host array.
+namespace {
+struct host_query : phl_reftable_query {
+    const int32_t *cand;
+    int64_t N;
+    int vid_at(int64_t e) override { return cand[e]; }
+    int64_t next_occurrence(int vid, int64_t after) override
+    {
+        for (int64_t e = after + 1; e < N; e++)
+            if (cand[e] == vid) return e;
+        return -1;
+    }
+};
+}  // namespace
+
+extern "C" int phl_debug_reference_table(const int16_t *keys_clean, const int32_t *cand_vid, int64_t M, int d, int64_t N,
+                                         int16_t *keys_ref_out, int64_t keys_ref_cap, int64_t *M_ref_out,
+                                         int32_t *cand_ref_vid_out, int32_t *hidden_out, int hidden_cap, int *n_hidden_out,
+                                         int *blur_first_nbr_out)
+{
+    if (!keys_clean || !cand_vid || M < 0 || d < 1 || N < 0 || !M_ref_out) { phl_set_error("phl_debug_reference_table: bad arguments"); return PHL_ERR_INVALID; }
+    std::vector<int32_t> efirst((size_t)M, -1);
+    for (int64_t e = N - 1; e >= 0; e--) efirst[cand_vid[e]] = (int32_t)e;
+    host_query q;
+    q.cand = cand_vid;
+    q.N = N;
+    phl_reftable_result R;
+    const int rc = phl_reference_table_sim(keys_clean, efirst.data(), M, d, N, q, R);
+    if (rc) return rc;
+    *M_ref_out = R.M_ref;
+    if (R.M_ref > keys_ref_cap || (int)R.hidden.size() > hidden_cap) { phl_set_error("phl_debug_reference_table: output too small"); return PHL_ERR_INVALID; }
+    memcpy(keys_ref_out, R.keys.data(), sizeof(int16_t) * (size_t)R.M_ref * d);
+    for (int64_t e = 0; e < N; e++) {
+        int r = R.remap[cand_vid[e]];
+        if (r < 0) {
+            const int k = -r - 1;
+            int id = R.seg_id[R.dup_ptr[k]];
+            for (int s = R.dup_ptr[k]; s < R.dup_ptr[k + 1] && R.seg_e[s] <= e; s++) id = R.seg_id[s];
+            r = id;
+        }
+        cand_ref_vid_out[e] = r;
+    }
+    *n_hidden_out = (int)R.hidden.size();
+    for (size_t i = 0; i < R.hidden.size(); i++) hidden_out[i] = R.hidden[i];
+    *blur_first_nbr_out = R.blur_grow ? R.blur_first_nbr : -2;
+    return PHL_OK;
+}

@@ -26,6 +26,7 @@ LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libphl.so")
 SUBTRACT_INPUT = 1
 EXACT = 4
 NO_TILES = 8
+BUILD_REFERENCE_TABLE = 1
 
 _f32p = C.c_void_p
 _lib = None
@@ -56,6 +57,9 @@ def load_library():
         lib.phl_status_string.argtypes = [i32]
         lib.phl_device_count.restype = i32
         lib.phl_build.argtypes = [C.POINTER(vp), vp, i64, i32, i64, i64, i32, vp]
+        lib.phl_build_ex.argtypes = [C.POINTER(vp), vp, i64, i32, i64, i64, i32, vp, u32]
+        lib.phl_debug_reference_table.argtypes = [vp, vp, i64, i32, i64, vp, i64, C.POINTER(i64), vp, vp, i32,
+                                                  C.POINTER(i32), C.POINTER(i32)]
         lib.phl_destroy.argtypes = [vp]
         for name in ("phl_num_pixels", "phl_num_vertices", "phl_device_bytes"):
             getattr(lib, name).restype = i64
@@ -118,7 +122,10 @@ class Lattice:
     Not re-entrant: use one Lattice per concurrent stream.
     """
 
-    def __init__(self, ref, device=None):
+    def __init__(self, ref, device=None, reference_table=False):
+        """reference_table=True: reproduce the reference's hash-table behaviour across its doublings (duplicate
+        vertices above M = 16383, see PHL_BUILD_REFERENCE_TABLE in include/phl.h) -- with ``exact=True`` the
+        filter is then bit-identical to the reference's CPU path at any size."""
         _require_gpu()
         lib = load_library()
         if ref.dim() != 2:
@@ -130,8 +137,10 @@ class Lattice:
         self.n, self.d = int(ref_d.shape[0]), int(ref_d.shape[1])
         handle = C.c_void_p()
         with torch.cuda.device(self.device):
-            _check(lib.phl_build(C.byref(handle), C.c_void_p(ref_d.data_ptr()), self.n, self.d, ref_d.stride(0),
-                                 ref_d.stride(1), self.device.index or 0, _stream(self.device)))
+            _check(lib.phl_build_ex(C.byref(handle), C.c_void_p(ref_d.data_ptr()), self.n, self.d, ref_d.stride(0),
+                                    ref_d.stride(1), self.device.index or 0, _stream(self.device),
+                                    BUILD_REFERENCE_TABLE if reference_table else 0))
+        self.reference_table = bool(reference_table)
         self._h = handle
         self.M = int(lib.phl_num_vertices(handle))
 
@@ -315,6 +324,15 @@ def softmax_neg_add(E0, G=None, out=None):
     return out
 
 
+def compat_softmax(E0, X, Mu, out=None):
+    """softmax(-(E0 + X @ Mu), dim=1): the whole non-lattice half of a mean-field iteration
+    (crf/crf_module.py:51-52) for fp32 CUDA E0, X [n, L] and Mu [L, L]."""
+    if not (_rowmajor(E0) and _rowmajor(X) and X.shape == E0.shape and Mu.shape == (E0.shape[1], E0.shape[1])):
+        raise TypeError("compat_softmax: expects fp32 CUDA E0, X [n, L] with unit channel stride and Mu [L, L]")
+    G = X @ Mu.to(E0.device, torch.float32)
+    return softmax_neg_add(E0, G, out=out)
+
+
 CRITERIA = {"AD": 0, "SD": 1, "nprod": 2}
 
 
@@ -371,6 +389,11 @@ _cache = OrderedDict()
 _cache_lock = threading.Lock()
 
 
+# PHL_REFERENCE_TABLE=1: the drop-in ``filter(src, ref)`` builds its lattices with the reference's table
+# behaviour (Lattice(reference_table=True)) -- for users who want the reference's exact vertices above M = 16383
+_REFERENCE_TABLE = os.environ.get("PHL_REFERENCE_TABLE", "0") not in ("", "0")
+
+
 def _cache_key(ref):
     return (ref.device.type, ref.device.index, ref.data_ptr(), tuple(ref.shape), tuple(ref.stride()), ref._version)
 
@@ -379,14 +402,14 @@ def lattice_for(ref):
     """Cached Lattice for ``ref``.  The entry keeps ``ref`` alive, so its storage address cannot be
     recycled while cached; an in-place update bumps ``ref._version`` and misses."""
     if _CACHE_SIZE <= 0:
-        return Lattice(ref)
+        return Lattice(ref, reference_table=_REFERENCE_TABLE)
     key = _cache_key(ref)
     with _cache_lock:
         hit = _cache.get(key)
         if hit is not None:
             _cache.move_to_end(key)
             return hit[0]
-    lat = Lattice(ref)
+    lat = Lattice(ref, reference_table=_REFERENCE_TABLE)
     with _cache_lock:
         _cache[key] = (lat, ref)
         while len(_cache) > _CACHE_SIZE:

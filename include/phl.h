@@ -67,6 +67,19 @@ enum phl_filter_flags {
     PHL_FILTER_NO_TILES = 8
 };
 
+enum phl_build_flags {
+    PHL_BUILD_DEFAULT = 0,
+    /* Reproduce the observable behaviour of the reference's hash table across its doublings
+     * (permutohedral.h:59-62, :101-103: lookup() hashes with the capacity it had BEFORE lookupOffset() grows
+     * the table, so the one key in flight at each doubling -- first at M = 16383 -- is probed from a stale
+     * slot and usually gets a SECOND vertex; blur then sees only one of the two).  Default: every key has one
+     * vertex (the algorithm without that defect; identical to the reference below M = 16383 and on all but
+     * 0.3-4 % of rows above).  With this flag vertex numbering, duplicate vertices and their visibility are
+     * exactly the reference's and PHL_FILTER_EXACT is bit-identical to the reference's CPU path at any size.
+     * Costs one host replay of the table per build (csrc/phl_reftable.hip). */
+    PHL_BUILD_REFERENCE_TABLE = 1
+};
+
 /* Limits. */
 #define PHL_MAX_D 16 /* feature dimensions supported by the device build */
 
@@ -84,6 +97,9 @@ int phl_device_count(void);
  * numbering the reference's insertion-ordered hash table produces (permutohedral.h:70-77). */
 int phl_build(phl_lattice **out, const float *ref_dev, int64_t n, int d, int64_t ref_row_stride,
               int64_t ref_col_stride, int device, phl_stream stream);
+/* phl_build with phl_build_flags. */
+int phl_build_ex(phl_lattice **out, const float *ref_dev, int64_t n, int d, int64_t ref_row_stride,
+                 int64_t ref_col_stride, int device, phl_stream stream, unsigned build_flags);
 /* Frees device memory (hipFree): like any free it must not run while a stream capture is in
  * progress on the device (the Python binding parks handles that die during a capture). */
 int phl_destroy(phl_lattice *lat);
@@ -194,6 +210,16 @@ int phl_get_replay(phl_lattice *lat, int32_t *vid_host /* [n][d+1] */, float *w_
 int phl_get_neighbors(phl_lattice *lat, int32_t *nbr_host /* [d+1][M][2], -1 = absent */);
 int phl_get_splat_lists(phl_lattice *lat, int32_t *ptr_host /* [M+1] */, int32_t *pixel_host /* [n(d+1)] */,
                         float *w_host /* [n(d+1)] */);
+
+/* Test hook, host only (no device needed): the table replay behind PHL_BUILD_REFERENCE_TABLE on host arrays.
+ * keys_clean [M][d] = distinct keys in first-touch order, cand_vid [N] = index into them for every
+ * (pixel, remainder) candidate in order.  Returns the reference's key list (insertion order, duplicates
+ * included), the vertex every candidate's lookup resolved to, the vertices its final table cannot reach and
+ * the neighbour a doubling inside blur() decides (-2: no such doubling). */
+int phl_debug_reference_table(const int16_t *keys_clean, const int32_t *cand_vid, int64_t M, int d, int64_t N,
+                              int16_t *keys_ref_out, int64_t keys_ref_cap, int64_t *M_ref_out,
+                              int32_t *cand_ref_vid_out, int32_t *hidden_out, int hidden_cap, int *n_hidden_out,
+                              int *blur_first_nbr_out);
 
 #ifdef __cplusplus
 }

@@ -54,10 +54,14 @@ def sorted_by_key(keys, *arrays):
     return (keys[order],) + tuple(a[order] for a in arrays)
 
 
-def lattice_case(name, n, d, vd, scale, seed, report, store=True):
+def lattice_case(name, n, d, vd, scale, seed, report, store=True, data=None):
     rng = np.random.default_rng(seed)
-    ref = (rng.random((n, d), dtype=np.float32) * np.float32(scale)).astype(np.float32)
-    src = rng.standard_normal((n, vd)).astype(np.float32)
+    recipe = None
+    if data is None:
+        ref = (rng.random((n, d), dtype=np.float32) * np.float32(scale)).astype(np.float32)
+        src = rng.standard_normal((n, vd)).astype(np.float32)
+    else:
+        ref, src, recipe = data
     R = po.reference_filter(src, ref, stages=True)
     grew = R["M"] >= 16383
     O = po.Oracle(ref, faithful_table=True)
@@ -66,6 +70,7 @@ def lattice_case(name, n, d, vd, scale, seed, report, store=True):
     pinned = (O.M == R["M"] and np.array_equal(O.keys(), R["keys"]) and np.array_equal(vid, R["replay_vid"])
               and np.array_equal(w, R["replay_w"]) and np.array_equal(sd, R["splat"])
               and np.array_equal(bd, R["blur"]) and np.array_equal(out, R["out"]))
+    n, d, vd = ref.shape[0], ref.shape[1], src.shape[1]
     entry = dict(case=name, n=n, d=d, vd=vd, scale=scale, seed=seed, M=int(R["M"]), table_grew=bool(grew),
                  oracle_faithful_bit_exact=bool(pinned))
     # clean-table oracle (what the HIP path is held to) versus the reference
@@ -80,12 +85,45 @@ def lattice_case(name, n, d, vd, scale, seed, report, store=True):
     assert pinned, f"oracle is not bit-exact against the reference engine on {name}"
     if not grew:
         assert diff_rows == 0 and Oc.M == R["M"]
-    if store:
+    if store == "growth":
+        # Above the reference's first table doubling (M >= 16383) its stale-slot defect (oracle/phl_oracle.c,
+        # table_lookup) makes a few output rows differ from the defect-free algorithm.  Stored: the REFERENCE's
+        # output, and the mask of rows where the oracle's faithful and clean modes differ (the rows the defect
+        # reaches).  Per-vertex dumps are not stored (duplicate keys make "sorted by key" ambiguous).
+        mask = (outc != out).any(1)
+        assert np.array_equal(out, R["out"])
+        entry["mask_rows"] = int(mask.sum())
+        entry["mask_fraction"] = float(mask.mean())
+        stored = dict(src=src, out=R["out"], M=np.int64(R["M"]), clean_M=np.int64(Oc.M), defect_mask=mask)
+        if recipe is None:
+            stored["ref"] = ref
+        else:       # features are a deterministic function of an 8-bit image: store that (tests/_golden_util.py rebuilds ref)
+            stored.update(recipe)
+            from _golden_util import features_from_recipe
+            assert np.array_equal(features_from_recipe(recipe), ref)
+        np.savez_compressed(os.path.join(HERE, f"{name}.npz"), **stored)
+    elif store:
         keys_s, splat_s, blur_s = sorted_by_key(R["keys"], R["splat"], R["blur"])
         np.savez_compressed(os.path.join(HERE, f"lattice_{name}.npz"), ref=ref, src=src, out=R["out"],
                             M=np.int64(R["M"]), keys_sorted=keys_s, splat_sorted=splat_s, blur_sorted=blur_s,
                             replay_w=R["replay_w"], replay_key=R["keys"][R["replay_vid"]])
     print(entry)
+
+
+def tsukuba_case(vd, seed, sigma_c=0.08, sigma_p=0.03):
+    """BASELINE configs[0] geometry: the reference's Tsukuba left image (Experiments/imL.png, 384x288), 5-D
+    bilateral features (rgb / sigma_c, ij / diag / sigma_p) as Experiments/DenseCrf.ipynb cell 9 builds them,
+    at the (.08, .03) setting of BASELINE.md (M/n ~ 0.21, M ~ 23 k: above the first table doubling).
+    Values: 8-bit-quantised uniform noise (compresses; any values pin the arithmetic)."""
+    from PIL import Image
+    from _golden_util import features_from_recipe
+
+    img = np.asarray(Image.open(os.path.join(REFERENCE, "Experiments", "imL.png")).convert("RGB"))
+    recipe = dict(img_u8=img, sigma_c=np.float64(sigma_c), sigma_p=np.float64(sigma_p))
+    ref = features_from_recipe(recipe)
+    rng = np.random.default_rng(seed)
+    src = (rng.integers(0, 256, size=(ref.shape[0], vd)) / 255.0).astype(np.float32)
+    return ref, src, recipe
 
 
 # ------------------------------------------------------------------------------------------------
@@ -260,6 +298,16 @@ def cost_volume_cases(report):
         report.append(dict(case=f"costvol_{name}", shape=list(want.shape), window=ws, criterion=crit, oracle_bit_exact=pinned))
 
 
+def growth_cases(report):
+    # cases that grow the reference's hash table (M >= 16383, as every BASELINE GPU config does): the
+    # reference's output is stored together with the mask of rows its stale-slot defect reaches
+    lattice_case("growth_n20000_d5_vd4", 20000, 5, 4, 8.0, 21, report=report, store="growth")
+    lattice_case("growth_tsukuba_384x288_vd4", 0, 5, 4, 0.0, 24, report=report, store="growth", data=tsukuba_case(4, 24))
+    # pin-only (too big to store)
+    for args in [("grow_n60000_d5_vd3", 60000, 5, 3, 6.0, 22), ("grow_n200000_d3_vd2", 200000, 3, 2, 40.0, 23)]:
+        lattice_case(*args, report=report, store=False)
+
+
 def main():
     if sys.argv[1:] == ["costvol"]:          # add the cost-volume vectors without regenerating the rest
         report = json.load(open(os.path.join(HERE, "PIN_REPORT.json")))
@@ -268,6 +316,15 @@ def main():
         with open(os.path.join(HERE, "PIN_REPORT.json"), "w") as f:
             json.dump(report, f, indent=1)
         print("wrote", sorted(x for x in os.listdir(HERE) if x.startswith("costvol_")))
+        return
+    if sys.argv[1:] == ["growth"]:           # add / refresh the stored table-growth cases only
+        po.build_oracle(force=True)
+        assert po.build_reference(), "reference engine not built"
+        report = json.load(open(os.path.join(HERE, "PIN_REPORT.json")))
+        report = [r for r in report if not str(r.get("case", "")).startswith("grow")]
+        growth_cases(report)
+        with open(os.path.join(HERE, "PIN_REPORT.json"), "w") as f:
+            json.dump(report, f, indent=1)
         return
     po.build_oracle(force=True)
     assert po.build_reference(), "reference engine not built"
@@ -278,11 +335,7 @@ def main():
                  ("n3000_d8_vd5", 3000, 8, 5, 2.0, 15), ("n4096_d5_vd64", 4096, 5, 64, 2.0, 16),
                  ("n1000_d2_vd7_wide", 1000, 2, 7, 300.0, 17)]:
         lattice_case(*args, report=report)
-    # pin-only cases that grow the reference's hash table (not stored: too big, and the stored
-    # expectation for the HIP path is the clean-table oracle, generated on the fly in tests)
-    for args in [("grow_n20000_d5_vd4", 20000, 5, 4, 8.0, 21), ("grow_n60000_d5_vd3", 60000, 5, 3, 6.0, 22),
-                 ("grow_n200000_d3_vd2", 200000, 3, 2, 40.0, 23)]:
-        lattice_case(*args, report=report, store=False)
+    growth_cases(report)
     python_layer_cases(report)
     cost_volume_cases(report)
     with open(os.path.join(HERE, "PIN_REPORT.json"), "w") as f:

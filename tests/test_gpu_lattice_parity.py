@@ -263,20 +263,25 @@ def test_staged_path_shapes(phl, n, d, vd):
     assert np.array_equal(exact.view(np.uint32), want.view(np.uint32))
 
 
-def test_full_size_properties(phl):
-    """BASELINE.json's full 2048x1536x256 volume is far beyond what the CPU oracle finishes in
-    seconds, so it is checked through size-independent properties of the operator:
-    symmetry <y, Wx> == <x, Wy> (the reference relies on it: gaussian_matrix.py:445-446),
-    linearity, determinism, agreement of the default and reference-exact paths, and W1 >= 0."""
+@pytest.mark.parametrize("workload", ["c3", "c2", "c5"])
+def test_full_size_properties(phl, workload):
+    """BASELINE.json's full-size volumes -- configs[2] 2048x1536x256, configs[1] 1390x1110x256 (ragged 16x16
+    tiling: neither side is a multiple of the chunk edge) and configs[4] 1024x1024x128 (the 128-channel slab
+    path at scale) -- are far beyond what the CPU oracle finishes in seconds, so they are checked through
+    size-independent properties of the operator: symmetry <y, Wx> == <x, Wy> (the reference relies on it:
+    gaussian_matrix.py:445-446), linearity, determinism, agreement of the default and reference-exact paths,
+    W1 >= 0 -- and a crop of the same features against the CPU oracle."""
     sys_path_bench = __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__)))
     __import__("sys").path.insert(0, sys_path_bench)
     import bench
 
-    H, W, L = 1536, 2048, 256
+    H, W, L, _ = bench.WORKLOADS[workload]
     feat = bench.synthetic_features(H, W)
     dev = torch.device("cuda")
     Lat = phl.Lattice(torch.from_numpy(feat.reshape(-1, 5)).to(dev))
-    assert 0.02 < Lat.M / (H * W) < 0.5
+    assert 0.02 < Lat.M / (H * W) < 0.5 and Lat.M >= 16383
+    st = Lat.tile_stats(L)
+    assert st["staged_splat"] == 1 and st["staged_slice"] == 1
     g = torch.Generator(device=dev).manual_seed(1)
     x = torch.rand((H * W, L), device=dev, generator=g)
     y = torch.rand((H * W, L), device=dev, generator=g)
@@ -285,21 +290,157 @@ def test_full_size_properties(phl):
     Wy = Lat.filter(y)
     a, b = torch.sum(y.double() * Wx.double()), torch.sum(x.double() * Wy.double())
     # S^T (B_d ... B_0) S: symmetric up to the non-commutation of the per-axis blurs at missing
-    # neighbours and fp32 rounding -- measured 3e-6; the reference treats it as symmetric
-    assert abs(float(a - b)) <= 1e-4 * abs(float(a))
+    # neighbours (the Jacobi passes run in a fixed axis order) and fp32 rounding; the reference treats it as
+    # symmetric.  Measured 2.9e-6 on c3 (round 1); bound = 10x that.
+    sym = abs(float(a - b)) / abs(float(a))
     Wxy = Lat.filter(x + 2 * y)
-    assert float((Wxy - (Wx + 2 * Wy)).abs().max()) <= 1e-4 * float(Wxy.abs().max())   # linear
+    lin = float((Wxy - (Wx + 2 * Wy)).abs().max()) / float(Wxy.abs().max())
     Wx_exact = Lat.filter(x, exact=True)
-    assert float(((Wx - Wx_exact).abs() / Wx_exact.abs().clamp_min(1e-3 * float(Wx_exact.max()))).max()) <= 1e-4
+    ex = float(((Wx - Wx_exact).abs() / Wx_exact.abs().clamp_min(1e-3 * float(Wx_exact.max()))).max())
+    print(f"[measured] {workload}: M/n={Lat.M / (H * W):.4f} symmetry {sym:.2e} linearity {lin:.2e} default-vs-exact {ex:.2e}")
+    assert sym <= 3e-5
+    assert lin <= 5e-6            # fp32 rounding of two different summation groupings
+    assert ex <= 1e-5             # default path vs the reference-exact arithmetic, per element (<< north star's 1e-4)
+    del Wxy, Wx_exact, Wy, y
     deg = Lat.filter(torch.ones((H * W, 4), device=dev))
     assert float(deg.min()) > 0 and torch.equal(deg[:, 0], deg[:, 3])
-    # a first slice of the volume against the CPU oracle on a crop that shares the lattice scale
+    # crops of the volume against the CPU oracle on features that share the lattice scale: top-left, and the
+    # bottom-right corner (ragged last tiles for c2)
     from oracle import phl_oracle as po
-    crop = np.ascontiguousarray(feat[:96, :128].reshape(-1, 5))
-    xs = x[:96 * 128, :8].cpu().numpy().copy()
-    want = po.Oracle(crop).filter(xs)
-    got = phl.Lattice(torch.from_numpy(crop).to(dev)).filter(torch.from_numpy(xs).to(dev)).cpu().numpy()
-    assert rel_err(got, want) <= 1e-5
+    for (r0, c0) in ((0, 0), (H - 96, W - 128)):
+        crop = np.ascontiguousarray(feat[r0:r0 + 96, c0:c0 + 128].reshape(-1, 5))
+        xs = x[:96 * 128, :8].cpu().numpy().copy()
+        want = po.Oracle(crop).filter(xs)
+        cl = phl.Lattice(torch.from_numpy(crop).to(dev))
+        got = cl.filter(torch.from_numpy(xs).to(dev)).cpu().numpy()
+        assert rel_err(got, want) <= 1e-5
+        gote = cl.filter(torch.from_numpy(xs).to(dev), exact=True).cpu().numpy()
+        assert np.array_equal(gote.view(np.uint32), want.view(np.uint32))
+
+
+def test_wide_crop_of_c2_against_oracle(phl):
+    """A 256-channel, ragged-size crop of configs[1]'s features against the CPU oracle: the full channel
+    count through every slab of the staged kernels, lattice above the reference's first table doubling."""
+    sys_path_bench = __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__)))
+    __import__("sys").path.insert(0, sys_path_bench)
+    import bench
+    from oracle import phl_oracle as po
+
+    H, W, L, _ = bench.WORKLOADS["c2"]
+    feat = bench.synthetic_features(H, W, sigma_xy=3.0)          # sigma_xy = 3 px: M/n ~ 0.3, more vertices per crop
+    crop = np.ascontiguousarray(feat[:250, :330].reshape(-1, 5))   # 250 x 330: not multiples of the chunk edge
+    rng = np.random.default_rng(8)
+    src = rng.random((crop.shape[0], L), dtype=np.float32)
+    O = po.Oracle(crop)
+    assert O.M >= 16383
+    want = O.filter(src)
+    Lat = phl.Lattice(torch.from_numpy(crop).cuda())
+    assert Lat.M == O.M
+    s = torch.from_numpy(src).cuda()
+    assert np.array_equal(Lat.filter(s, exact=True).cpu().numpy().view(np.uint32), want.view(np.uint32))
+    e = rel_err(Lat.filter(s).cpu().numpy(), want)
+    print(f"[measured] c2 crop 330x250x256, M={O.M}: default path vs oracle, per-element relative {e:.2e}")
+    assert e <= 1e-5
+
+
+GROWTH = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "growth_*.npz")))
+
+
+@pytest.mark.parametrize("path", GROWTH, ids=os.path.basename)
+def test_reference_output_above_table_doubling(phl, path):
+    """Stored outputs of the REFERENCE ENGINE at M >= 16383 (its hash table has doubled; every BASELINE GPU
+    config is in this regime).  `defect_mask` marks the rows reached by the reference's stale-slot-after-grow
+    defect (permutohedral.h:59-62,101-103: lookup() hashes before grow(); see oracle/phl_oracle.c).
+      * default build (defect-free table): exact arithmetic is BIT-EQUAL to the reference outside the mask and
+        to the clean oracle everywhere; the default arithmetic is within 1e-4 per element outside the mask;
+      * reference_table=True build: reproduces the reference's table, duplicates included -- bit-equal to the
+        reference's output on EVERY row."""
+    from _golden_util import load_growth_case
+    from oracle import phl_oracle as po
+
+    g = load_growth_case(path)
+    mask = g["mask"]
+    ref = torch.from_numpy(g["ref"]).cuda()
+    s = torch.from_numpy(g["src"]).cuda()
+    L = phl.Lattice(ref)
+    assert L.M == g["clean_M"]
+    out = L.filter(s, exact=True).cpu().numpy()
+    assert np.array_equal(out[~mask].view(np.uint32), g["out"][~mask].view(np.uint32))
+    clean = po.Oracle(g["ref"]).filter(g["src"])
+    assert np.array_equal(out.view(np.uint32), clean.view(np.uint32))
+    fast = L.filter(s).cpu().numpy()
+    e = rel_err(fast[~mask], g["out"][~mask])
+    print(f"[measured] {os.path.basename(path)}: M={g['M']}, defect mask {int(mask.sum())}/{len(mask)} rows = "
+          f"{mask.mean():.3%}; default path outside the mask: {e:.2e} relative")
+    assert e <= 1e-5 if (g["src"] >= 0).all() else scaled_err(fast[~mask], g["out"][~mask]) <= 1e-5
+    assert 0 < mask.mean() < 0.05
+    # the opt-in reference table: identical to the reference everywhere
+    Lr = phl.Lattice(ref, reference_table=True)
+    assert Lr.M == g["M"]
+    outr = Lr.filter(s, exact=True).cpu().numpy()
+    assert np.array_equal(outr.view(np.uint32), g["out"].view(np.uint32))
+    Of = po.Oracle(g["ref"], faithful_table=True)
+    assert np.array_equal(Lr.keys(), Of.keys())
+    vid, w = Lr.replay()
+    ovid, ow = Of.replay()
+    assert np.array_equal(vid, ovid) and np.array_equal(Lr.neighbors(), Of.neighbors())
+    fr = Lr.filter(s).cpu().numpy()
+    assert (rel_err(fr, g["out"]) <= 1e-5) if (g["src"] >= 0).all() else (scaled_err(fr, g["out"]) <= 1e-5)
+
+
+@pytest.mark.parametrize("n,d,vd,scale,seed", [(20000, 5, 3, 8.0, 20000), (40000, 3, 2, 30.0, 40000), (30000, 2, 8, 300.0, 6),
+                                                (50000, 4, 4, 12.0, 8), (200000, 3, 2, 40.0, 23)])
+def test_reference_table_mode_equals_the_reference_engine(phl, n, d, vd, scale, seed):
+    """Lattice(reference_table=True) against the oracle's faithful-table mode (== the reference engine, bit for
+    bit, incl. its duplicate vertices above M = 16383): numbering, replay, blur neighbours, every stage."""
+    from oracle import phl_oracle as po
+
+    rng = np.random.default_rng(seed)
+    ref = (rng.random((n, d), dtype=np.float32) * np.float32(scale)).astype(np.float32)
+    src = rng.standard_normal((n, vd)).astype(np.float32)
+    O = po.Oracle(ref, faithful_table=True)
+    out_o, splat_o, blur_o = O.filter(src, stages=True)
+    L = phl.Lattice(torch.from_numpy(ref).cuda(), reference_table=True)
+    assert L.M == O.M and L.M >= 16383
+    assert np.array_equal(L.keys(), O.keys())
+    vid, w = L.replay()
+    ovid, ow = O.replay()
+    assert np.array_equal(vid, ovid) and np.array_equal(w.view(np.uint32), ow.view(np.uint32))
+    assert np.array_equal(L.neighbors(), O.neighbors())
+    s = torch.from_numpy(src).cuda()
+    vs = L.splat(s, exact=True)
+    assert np.array_equal(vs.cpu().numpy().view(np.uint32), splat_o.view(np.uint32))
+    vb = L.blur(vs)
+    assert np.array_equal(vb.cpu().numpy().view(np.uint32), blur_o.view(np.uint32))
+    assert np.array_equal(L.filter(s, exact=True).cpu().numpy().view(np.uint32), out_o.view(np.uint32))
+    assert scaled_err(L.filter(s).cpu().numpy(), out_o) <= 1e-5
+    if po.reference_available():          # the reference engine itself, when its binary travelled with the tree
+        R = po.reference_filter(src, ref)
+        assert np.array_equal(L.filter(s, exact=True).cpu().numpy().view(np.uint32), R.view(np.uint32))
+
+
+def test_reference_table_doubling_inside_blur(phl):
+    """M == 2^14 - 1 when splat ends: the reference's table doubles inside blur()'s first neighbour lookup, which
+    is then probed from a stale slot (permutohedral.h:62 has no `create` test)."""
+    from oracle import phl_oracle as po
+
+    for seed in range(30):
+        rng = np.random.default_rng(99 + seed)
+        ref = (rng.random((12000, 5), dtype=np.float32) * np.float32(9.0)).astype(np.float32)
+        vid = po.Oracle(ref).replay()[0]
+        first = int(np.nonzero(vid.max(1) >= 16382)[0][0])
+        if vid[first].max() == 16382:
+            break
+    else:
+        pytest.fail("no prefix with exactly 16383 vertices")
+    ref = np.ascontiguousarray(ref[:first + 1])
+    O = po.Oracle(ref, faithful_table=True)
+    assert O.M == 16383
+    L = phl.Lattice(torch.from_numpy(ref).cuda(), reference_table=True)
+    assert L.M == O.M and np.array_equal(L.neighbors(), O.neighbors())
+    src = rng.standard_normal((ref.shape[0], 4)).astype(np.float32)
+    got = L.filter(torch.from_numpy(src).cuda(), exact=True).cpu().numpy()
+    assert np.array_equal(got.view(np.uint32), O.filter(src).view(np.uint32))
 
 
 def test_randomised_shapes_against_oracle(phl):

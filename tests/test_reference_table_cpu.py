@@ -1,0 +1,103 @@
+"""CPU: the host replay behind PHL_BUILD_REFERENCE_TABLE (csrc/phl_reftable.hip, reached through the C ABI's test
+hook; no device needed) against the oracle's faithful-table mode, which is pinned bit for bit to the reference
+engine above its first table doubling (tests/golden/PIN_REPORT.json)."""
+import ctypes as C
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from oracle import phl_oracle as po
+
+
+def _replay(keys_clean, cand_vid):
+    import phl
+
+    lib = phl.load_library()
+    M, d = keys_clean.shape
+    N = cand_vid.size
+    keys_out = np.empty((M + 128, d), np.int16)
+    cand_out = np.empty(N, np.int32)
+    hidden = np.empty(64, np.int32)
+    M_ref, nh, nb = C.c_int64(0), C.c_int(0), C.c_int(0)
+    rc = lib.phl_debug_reference_table(keys_clean.ctypes.data_as(C.c_void_p), cand_vid.ctypes.data_as(C.c_void_p), M, d, N,
+                                       keys_out.ctypes.data_as(C.c_void_p), M + 128, C.byref(M_ref),
+                                       cand_out.ctypes.data_as(C.c_void_p), hidden.ctypes.data_as(C.c_void_p), 64,
+                                       C.byref(nh), C.byref(nb))
+    assert rc == 0, lib.phl_last_error()
+    return keys_out[:M_ref.value].copy(), cand_out, hidden[:nh.value].copy(), nb.value
+
+
+def _check(ref):
+    Oc = po.Oracle(ref)                       # defect-free table: what the device build numbers first
+    Of = po.Oracle(ref, faithful_table=True)  # == the reference engine
+    keys_c = np.ascontiguousarray(Oc.keys())
+    cand = np.ascontiguousarray(Oc.replay()[0].ravel())
+    keys_r, cand_r, hidden, nb = _replay(keys_c, cand)
+    assert len(keys_r) == Of.M
+    assert np.array_equal(keys_r, Of.keys())
+    assert np.array_equal(cand_r, Of.replay()[0].ravel())
+    # a hidden vertex is never anybody's blur neighbour in the reference
+    nbr = Of.neighbors()
+    assert not np.isin(nbr, hidden).any() or len(hidden) == 0
+    # ... and of the vertices sharing a key at most one is reachable (a key whose only vertex was filed from a
+    # stale slot at the last doubling and never looked up again is hidden too, without being a duplicate)
+    _, inv, cnt = np.unique(keys_r, axis=0, return_inverse=True, return_counts=True)
+    inv = inv.ravel()
+    for grp in np.nonzero(cnt > 1)[0]:
+        members = np.nonzero(inv == grp)[0]
+        assert len(set(members.tolist()) - set(hidden.tolist())) <= 1
+    return Of.M - Oc.M, len(hidden)
+
+
+@pytest.mark.parametrize("n,d,scale,seed", [(3000, 5, 3.0, 1), (20000, 5, 8.0, 21), (60000, 5, 6.0, 22), (200000, 3, 40.0, 23),
+                                            (9000, 8, 2.0, 5), (30000, 2, 300.0, 6), (12000, 5, 9.0, 7), (50000, 4, 12.0, 8)])
+def test_replay_equals_faithful_oracle_random(n, d, scale, seed):
+    rng = np.random.default_rng(seed)
+    ref = (rng.random((n, d), dtype=np.float32) * np.float32(scale)).astype(np.float32)
+    extra, nh = _check(ref)
+    print(f"n={n} d={d}: {extra} duplicate vertices, {nh} hidden")
+
+
+def test_replay_equals_faithful_oracle_many_seeds():
+    """Sweep seeds so that all the sub-cases occur: stale slot == proper slot (no duplicate), in-flight key new /
+    already present, the duplicate found again only after the next doubling, several doublings."""
+    seen = set()
+    for seed in range(40):
+        rng = np.random.default_rng(1000 + seed)
+        n = int(rng.integers(6000, 40000))
+        d = int(rng.integers(2, 7))
+        ref = (rng.random((n, d), dtype=np.float32) * np.float32(rng.choice([6.0, 10.0, 25.0]))).astype(np.float32)
+        seen.add(_check(ref))
+    assert any(e > 0 for e, _ in seen) and any(e == 0 for e, _ in seen), seen
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "growth_*.npz"))),
+                         ids=os.path.basename)
+def test_replay_on_stored_growth_cases(path):
+    from _golden_util import load_growth_case
+
+    g = load_growth_case(path)
+    extra, _ = _check(g["ref"])
+    assert extra == g["M"] - g["clean_M"]
+
+
+def test_threshold_hit_exactly_at_the_last_vertex():
+    """M == 2^k - 1 after splat: the doubling happens inside blur()'s first neighbour lookup (latent
+    hazard).  Build such a lattice by truncating a random feature set at the pixel that creates vertex 16383."""
+    for seed in range(30):
+        rng = np.random.default_rng(99 + seed)
+        ref = (rng.random((12000, 5), dtype=np.float32) * np.float32(9.0)).astype(np.float32)
+        vid = po.Oracle(ref).replay()[0]
+        first = int(np.nonzero(vid.max(1) >= 16382)[0][0])    # pixel whose lookups create vertex id 16382 (the 16383rd)
+        if vid[first].max() != 16382:
+            continue                                           # that pixel goes on to create more: M would overshoot
+        O = po.Oracle(ref[:first + 1])
+        assert O.M == 16383
+        _check(ref[:first + 1])
+        Of = po.Oracle(ref[:first + 1], faithful_table=True)
+        keys_r, _, _, nb = _replay(np.ascontiguousarray(O.keys()), np.ascontiguousarray(O.replay()[0].ravel()))
+        assert nb != -2 and nb == Of.neighbors()[0, 0, 0]
+        return
+    pytest.fail("no prefix with exactly 16383 vertices in 30 draws")
