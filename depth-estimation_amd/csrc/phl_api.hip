@@ -42,6 +42,132 @@ int grow(float **p, int64_t *cap, int64_t need)
 }
 }  // namespace
 
+// ---- value workspaces --------------------------------------------------------------------------------
+// SURVEY 8(b), threading row: "re-entrant; autograd may call from any thread".  A lattice's tables are
+// read-only after the build; what a filter call WRITES (the [M][vd] ping-pong pair, partial rows, staging
+// copies) lives in a workspace the call takes for the duration of its launches.  A workspace is handed out
+// again when (a) it has never carried work, (b) the caller enqueues on the stream that used it last (stream
+// order protects it), or (c) the event recorded behind its last launch has completed.  Otherwise a new one is
+// allocated: two threads on two streams run concurrently on separate buffers.  A workspace whose launches were
+// captured into a HIP graph stays bound to that stream and is never resized (the graph holds its pointers).
+struct phl_shared {
+    std::mutex mu;                       // guards `ws` and the workspaces' state flags
+    std::vector<phl_workspace *> ws;
+    std::mutex csr_mu;                   // one-time build of the pixel-sorted lists (phl_ensure_csr)
+};
+
+namespace {
+void ws_free_buffers(phl_workspace *w)
+{
+    void *ptrs[] = {w->buf[0], w->buf[1], w->partial, w->stage_in, w->stage_out};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    w->buf[0] = w->buf[1] = w->partial = w->stage_in = w->stage_out = nullptr;
+    w->buf_elems = w->partial_elems = w->stage_elems = 0;
+}
+
+__global__ void k_mark_done(unsigned long long *word, unsigned long long ticket)
+{
+    __threadfence_system();
+    *reinterpret_cast<volatile unsigned long long *>(word) = ticket;
+}
+
+bool ws_drained(const phl_workspace *w)
+{
+    return w->done_word && *reinterpret_cast<volatile unsigned long long *>(w->done_word) == w->ticket;
+}
+
+bool is_capturing(hipStream_t st)
+{
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    return cs != hipStreamCaptureStatusNone;
+}
+}  // namespace
+
+std::mutex *phl_csr_mutex(phl_lattice *lat) { return &lat->shared->csr_mu; }
+
+int phl_ws_acquire(phl_lattice *lat, hipStream_t st, int64_t buf_elems, int64_t partial_elems, int64_t stage_elems,
+                   phl_workspace **out)
+{
+    phl_shared *sh = lat->shared;
+    phl_workspace *w = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(sh->mu);
+        phl_workspace *fits = nullptr, *any = nullptr;
+        for (phl_workspace *c : sh->ws) {
+            if (c->in_enqueue) continue;
+            if (c->stream_bound && c->last_stream != st) {
+                if (c->captured || !ws_drained(c)) continue;
+                c->stream_bound = false;       // its work has drained
+            }
+            const bool big = c->buf_elems >= buf_elems && c->partial_elems >= partial_elems && c->stage_elems >= stage_elems;
+            if (big && !fits) fits = c;
+            if (!c->captured && !any) any = c;  // may be grown
+        }
+        w = fits ? fits : any;
+        if (!w) {
+            w = new phl_workspace();
+            memset(w, 0, sizeof(*w));
+            // pinned, device-visible host word for the completion mark (cannot be allocated during a capture:
+            // such a workspace then simply stays bound to its stream)
+            void *hw = nullptr;
+            if (hipHostMalloc(&hw, sizeof(unsigned long long), hipHostMallocMapped) == hipSuccess) {
+                w->done_word = (unsigned long long *)hw;
+                *w->done_word = 0;
+            } else {
+                (void)hipGetLastError();
+            }
+            sh->ws.push_back(w);
+        }
+        w->in_enqueue = true;
+    }
+    int rc = PHL_OK;
+    if (buf_elems > w->buf_elems) {
+        int64_t c0 = w->buf_elems, c1 = w->buf_elems;
+        rc = grow(&w->buf[0], &c0, buf_elems);
+        if (!rc) rc = grow(&w->buf[1], &c1, buf_elems);
+        w->buf_elems = rc ? 0 : buf_elems;
+    }
+    if (!rc && partial_elems > w->partial_elems) {
+        rc = grow(&w->partial, &w->partial_elems, partial_elems);
+    }
+    if (!rc && stage_elems > w->stage_elems) {
+        int64_t c0 = w->stage_elems, c1 = w->stage_elems;
+        rc = grow(&w->stage_in, &c0, stage_elems);
+        if (!rc) rc = grow(&w->stage_out, &c1, stage_elems);
+        w->stage_elems = rc ? 0 : stage_elems;
+    }
+    if (rc) {
+        std::lock_guard<std::mutex> lk(sh->mu);
+        w->in_enqueue = false;
+        return rc;
+    }
+    *out = w;
+    return PHL_OK;
+}
+
+void phl_ws_release(phl_lattice *lat, phl_workspace *w, hipStream_t st, bool idle)
+{
+    if (!idle) {
+        if (is_capturing(st)) w->captured = true;      // the graph keeps the pointers: bound to this stream for good
+        w->ticket++;
+        if (w->done_word) {
+            hipLaunchKernelGGL(k_mark_done, dim3(1), dim3(1), 0, st, w->done_word, w->ticket);
+            if (hipGetLastError() != hipSuccess) w->ticket += 1ull << 32;   // never reads as drained
+        }
+    }
+    std::lock_guard<std::mutex> lk(lat->shared->mu);
+    if (!idle) {
+        w->last_stream = st;
+        w->stream_bound = true;
+    }
+    w->in_enqueue = false;
+}
+
 // ---- cached scratch block for build temporaries -------------------------------------------------
 namespace {
 std::mutex g_scratch_mu;
@@ -177,6 +303,7 @@ int phl_build_ex(phl_lattice **out, const float *ref_dev, int64_t n, int d, int6
     lat->n = n;
     lat->build_flags = build_flags;
     lat->nbr00_override = -2;
+    lat->shared = new phl_shared();
     int rc = phl_build_device(lat, ref_dev, rs, cs, (hipStream_t)stream);
     if (rc == PHL_OK) rc = phl_tiles_build(lat, ref_dev, rs, cs, (hipStream_t)stream);
     if (rc != PHL_OK) {
@@ -192,9 +319,17 @@ int phl_destroy(phl_lattice *lat)
     if (!lat) return PHL_OK;
     device_guard g(lat->device);
     phl_tiles_free(lat);
-    void *ptrs[] = {lat->vkeys, lat->replay, lat->csr_ptr, lat->csr, lat->nbr, lat->nbr2, lat->table, lat->buf[0], lat->buf[1], lat->stage_in, lat->stage_out};
+    void *ptrs[] = {lat->vkeys, lat->replay, lat->csr_ptr, lat->csr, lat->nbr, lat->nbr2, lat->table};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
+    if (lat->shared) {
+        for (phl_workspace *w : lat->shared->ws) {
+            ws_free_buffers(w);
+            if (w->done_word) (void)hipHostFree(w->done_word);
+            delete w;
+        }
+        delete lat->shared;
+    }
     delete lat;
     return PHL_OK;
 }
@@ -206,7 +341,11 @@ int phl_device(const phl_lattice *lat) { return lat ? lat->device : -1; }
 int64_t phl_device_bytes(const phl_lattice *lat)
 {
     if (!lat) return -1;
-    return lat->table_bytes + lat->tile_bytes + lat->partial_elems * (int64_t)sizeof(float) + 2 * lat->buf_elems * (int64_t)sizeof(float) + 2 * lat->stage_elems * (int64_t)sizeof(float);
+    int64_t b = lat->table_bytes + lat->tile_bytes;
+    std::lock_guard<std::mutex> lk(lat->shared->mu);
+    for (const phl_workspace *w : lat->shared->ws)
+        b += (w->partial_elems + 2 * w->buf_elems + 2 * w->stage_elems) * (int64_t)sizeof(float);
+    return b;
 }
 
 int64_t phl_num_local_vertices(const phl_lattice *lat) { return lat ? lat->M_local : -1; }
@@ -218,7 +357,13 @@ int phl_add_vertices(phl_lattice *lat, const int16_t *keys_host, int64_t count, 
     device_guard g(lat->device);
     const int64_t M_before = lat->M;
     int rc = phl_add_vertices_device(lat, keys_host, count, vid_host, (hipStream_t)stream);
-    if (rc == PHL_OK && lat->M != M_before) rc = phl_tiles_link_vertices(lat, (hipStream_t)stream);
+    if (rc == PHL_OK && lat->M != M_before) {
+        rc = phl_tiles_link_vertices(lat, (hipStream_t)stream);
+        // the value workspaces are sized by M and S_multi: drop them (not a concurrent operation: the lattice is
+        // still being assembled)
+        std::lock_guard<std::mutex> lk(lat->shared->mu);
+        for (phl_workspace *w : lat->shared->ws) ws_free_buffers(w);
+    }
     return rc;
 }
 
@@ -249,29 +394,50 @@ int phl_tile_stats(const phl_lattice *lat, int vd, int64_t out[7])
     return PHL_OK;
 }
 
-int phl_reserve(phl_lattice *lat, int vd)
+namespace {
+// workspace sizes of a filter call over vd channels
+int64_t need_partial(const phl_lattice *lat, int vd, unsigned flags)
+{
+    if (flags & (PHL_FILTER_EXACT | PHL_FILTER_NO_TILES)) return 0;
+    if (phl_tiles_lprs(lat, vd, 0) < 0 || lat->S_multi > lat->n) return 0;
+    return lat->S_multi * (int64_t)vd;
+}
+}  // namespace
+
+int phl_reserve_ex(phl_lattice *lat, int vd, unsigned reserve_flags)
 {
     if (!lat || vd < 0) { phl_set_error("phl_reserve: bad arguments"); return PHL_ERR_INVALID; }
     device_guard g(lat->device);
-    const int64_t need = lat->M * (int64_t)vd;
-    if (need <= lat->buf_elems) {
-        if (phl_tiles_lprs(lat, vd, 0) >= 0 && lat->S_multi <= lat->n) return phl_tiles_reserve(lat, vd);
-        return phl_ensure_csr(lat, nullptr);   // gather splat will run: its lists must exist before a capture
+    const unsigned fflags = (reserve_flags & PHL_RESERVE_EXACT) ? PHL_FILTER_EXACT : 0;
+    const int64_t partial = need_partial(lat, vd, fflags);
+    // the gather splat (exact mode, or shapes the chunk splat does not take) needs its pixel-sorted lists
+    const bool gather = partial == 0 && !use_tiled_splat(lat, vd, fflags, nullptr, nullptr, 0);
+    if (gather) {
+        const int rc = phl_ensure_csr(lat, nullptr);
+        if (rc) return rc;
     }
-    int64_t cap0 = lat->buf_elems, cap1 = lat->buf_elems;
-    int rc = grow(&lat->buf[0], &cap0, need);
-    if (rc) { lat->buf_elems = 0; return rc; }
-    rc = grow(&lat->buf[1], &cap1, need);
-    if (rc) { lat->buf_elems = 0; return rc; }
-    lat->buf_elems = need;
+    phl_workspace *w = nullptr;
+    const int64_t stage = (reserve_flags & PHL_RESERVE_STRIDED_IO) ? lat->n * (int64_t)vd : 0;
+    int rc = phl_ws_acquire(lat, nullptr, lat->M * (int64_t)vd, partial, stage, &w);
+    if (rc) return rc;
+    phl_ws_release(lat, w, nullptr, /*idle=*/true);      // sized, carries no work: the next call on any stream takes it
     return PHL_OK;
 }
+
+int phl_reserve(phl_lattice *lat, int vd) { return phl_reserve_ex(lat, vd, 0); }
 
 int phl_splat(phl_lattice *lat, const float *src, int vd, int64_t src_rs, float *vert, unsigned flags, phl_stream st)
 {
     if (!lat || vd < 0 || (lat->n > 0 && vd > 0 && (!src || !vert))) { phl_set_error("phl_splat: bad arguments"); return PHL_ERR_INVALID; }
     device_guard g(lat->device);
-    if (use_tiled_splat(lat, vd, flags, src, vert, src_rs)) return phl_launch_splat_tiled(lat, src, src_rs, vd, vert, (hipStream_t)st);
+    if (use_tiled_splat(lat, vd, flags, src, vert, src_rs)) {
+        phl_workspace *w = nullptr;       // only the partial rows come from the workspace here
+        int rc = phl_ws_acquire(lat, (hipStream_t)st, 0, need_partial(lat, vd, flags), 0, &w);
+        if (rc) return rc;
+        rc = phl_launch_splat_tiled(lat, src, src_rs, vd, vert, w->partial, (hipStream_t)st);
+        phl_ws_release(lat, w, (hipStream_t)st, false);
+        return rc;
+    }
     return phl_launch_splat(lat, src, src_rs, vd, vert, (hipStream_t)st);
 }
 
@@ -336,6 +502,41 @@ int phl_slice(phl_lattice *lat, const float *vert, int vd, float *out, int64_t o
     return phl_launch_slice(lat, vert, vd, out, out_rs, sub, sub_rs, flags, (hipStream_t)st);
 }
 
+static int filter_on(phl_lattice *lat, phl_workspace *w, const float *src, int vd, int64_t src_rs, int64_t src_cs, float *out,
+                     int64_t out_rs, int64_t out_cs, unsigned flags, bool stage_src, bool stage_dst, hipStream_t st)
+{
+    const int64_t n = lat->n;
+    const float *src_eff = src;
+    int64_t src_eff_rs = src_rs;
+    float *out_eff = out;
+    int64_t out_eff_rs = out_rs;
+    int rc = PHL_OK;
+    if (stage_src) {
+        rc = phl_launch_copy2d(src, src_rs, src_cs, w->stage_in, vd, 1, n, vd, st);
+        if (rc) return rc;
+        src_eff = w->stage_in;
+        src_eff_rs = vd;
+    }
+    if (stage_dst) {
+        out_eff = w->stage_out;
+        out_eff_rs = vd;
+    }
+    if (use_tiled_splat(lat, vd, flags, src_eff, w->buf[0], src_eff_rs)) rc = phl_launch_splat_tiled(lat, src_eff, src_eff_rs, vd, w->buf[0], w->partial, st);
+    else rc = phl_launch_splat(lat, src_eff, src_eff_rs, vd, w->buf[0], st);
+    if (rc) return rc;
+    int cur = 0;
+    rc = blur_all(lat, w->buf, vd, st, &cur);
+    if (rc) return rc;
+    const float *sub = (flags & PHL_FILTER_SUBTRACT_INPUT) ? src_eff : nullptr;
+    if (use_tiled_slice(lat, vd, flags, w->buf[cur], out_eff, sub, out_eff_rs, sub ? src_eff_rs : 0))
+        rc = phl_launch_slice_tiled(lat, w->buf[cur], vd, out_eff, out_eff_rs, sub, src_eff_rs, flags, st);
+    else
+        rc = phl_launch_slice(lat, w->buf[cur], vd, out_eff, out_eff_rs, sub, src_eff_rs, flags, st);
+    if (rc) return rc;
+    if (stage_dst) rc = phl_launch_copy2d(w->stage_out, vd, 1, out, out_rs, out_cs, n, vd, st);
+    return rc;
+}
+
 int phl_filter(phl_lattice *lat, const float *src, int vd, int64_t src_rs, int64_t src_cs, float *out, int64_t out_rs,
                int64_t out_cs, unsigned flags, phl_stream stream)
 {
@@ -346,51 +547,17 @@ int phl_filter(phl_lattice *lat, const float *src, int vd, int64_t src_rs, int64
     if (src == out) { phl_set_error("phl_filter: out may not alias src"); return PHL_ERR_INVALID; }
     hipStream_t st = (hipStream_t)stream;
     device_guard g(lat->device);
-    int rc = phl_reserve(lat, vd);
-    if (rc) return rc;
 
     // pixel-major rows are consumed in place; anything else (e.g. the [n,L] view of an NCHW
     // tensor, gaussian_matrix.py:348) is staged through one coalesced transpose
-    const float *src_eff = src;
-    int64_t src_eff_rs = src_rs;
-    float *out_eff = out;
-    int64_t out_eff_rs = out_rs;
     const bool stage_src = (src_cs != 1) && vd > 1;
     const bool stage_dst = (out_cs != 1) && vd > 1;
-    if (stage_src || stage_dst) {
-        const int64_t need = n * (int64_t)vd;
-        if (need > lat->stage_elems) {
-            int64_t c0 = lat->stage_elems, c1 = lat->stage_elems;
-            rc = grow(&lat->stage_in, &c0, need);
-            if (!rc) rc = grow(&lat->stage_out, &c1, need);
-            if (rc) { lat->stage_elems = 0; return rc; }
-            lat->stage_elems = need;
-        }
-    }
-    if (stage_src) {
-        rc = phl_launch_copy2d(src, src_rs, src_cs, lat->stage_in, vd, 1, n, vd, st);
-        if (rc) return rc;
-        src_eff = lat->stage_in;
-        src_eff_rs = vd;
-    }
-    if (stage_dst) {
-        out_eff = lat->stage_out;
-        out_eff_rs = vd;
-    }
-
-    if (use_tiled_splat(lat, vd, flags, src_eff, lat->buf[0], src_eff_rs)) rc = phl_launch_splat_tiled(lat, src_eff, src_eff_rs, vd, lat->buf[0], st);
-    else rc = phl_launch_splat(lat, src_eff, src_eff_rs, vd, lat->buf[0], st);
+    phl_workspace *w = nullptr;
+    int rc = phl_ws_acquire(lat, st, lat->M * (int64_t)vd, need_partial(lat, vd, flags),
+                            (stage_src || stage_dst) ? n * (int64_t)vd : 0, &w);
     if (rc) return rc;
-    int cur = 0;
-    rc = blur_all(lat, lat->buf, vd, st, &cur);
-    if (rc) return rc;
-    const float *sub = (flags & PHL_FILTER_SUBTRACT_INPUT) ? src_eff : nullptr;
-    if (use_tiled_slice(lat, vd, flags, lat->buf[cur], out_eff, sub, out_eff_rs, sub ? src_eff_rs : 0))
-        rc = phl_launch_slice_tiled(lat, lat->buf[cur], vd, out_eff, out_eff_rs, sub, src_eff_rs, flags, st);
-    else
-        rc = phl_launch_slice(lat, lat->buf[cur], vd, out_eff, out_eff_rs, sub, src_eff_rs, flags, st);
-    if (rc) return rc;
-    if (stage_dst) rc = phl_launch_copy2d(lat->stage_out, vd, 1, out, out_rs, out_cs, n, vd, st);
+    rc = filter_on(lat, w, src, vd, src_rs, src_cs, out, out_rs, out_cs, flags, stage_src, stage_dst, st);
+    phl_ws_release(lat, w, st, false);
     return rc;
 }
 

@@ -21,6 +21,8 @@
 // The whole translation unit is compiled with -ffp-contract=off: elevate must round exactly
 // like the reference's scalar C++ (mul and add separately) so that keys, ranks and weights
 // are bit-identical to the CPU path.
+#include <mutex>
+
 #include "phl_device_utils.h"
 
 namespace {
@@ -225,17 +227,23 @@ __global__ __launch_bounds__(256) void k_count_vid(const phl_replay_t *__restric
     if (e < N) atomicAdd(&cnt[replay[e].vid], 1);
 }
 
-__global__ __launch_bounds__(256) void k_fill(const phl_replay_t *__restrict__ replay, const int *__restrict__ ptr,
-                                              int *cursor, int N, int dp1, phl_contrib_t *__restrict__ tmp)
+__global__ __launch_bounds__(256) void k_replay_vids(const phl_replay_t *__restrict__ replay, int N, int *__restrict__ vid)
 {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= N) return;
-    const phl_replay_t r = replay[e];
-    const int pos = ptr[r.vid] + atomicAdd(&cursor[r.vid], 1);
+    if (e < N) vid[e] = replay[e].vid;
+}
+
+// candidates in (vertex, candidate index) order -> (pixel, weight)
+__global__ __launch_bounds__(256) void k_fill_sorted(const phl_replay_t *__restrict__ replay, const int *__restrict__ perm,
+                                                     int N, int dp1, phl_contrib_t *__restrict__ csr)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const int e = perm[i];
     phl_contrib_t c;
     c.pixel = e / dp1;
-    c.w = r.w;
-    tmp[pos] = c;
+    c.w = replay[e].w;
+    csr[i] = c;
 }
 
 // Thread per (axis, vertex): neighbour keys are key +- 1 in every stored coordinate, with
@@ -495,6 +503,7 @@ int phl_build_device(phl_lattice *lat, const float *ref, int64_t rs, int64_t cs,
 // need them, so they are built on first use, from `replay` alone.
 int phl_ensure_csr(phl_lattice *lat, hipStream_t st)
 {
+    std::lock_guard<std::mutex> once(*phl_csr_mutex(lat));     // several threads may filter through one lattice
     if (lat->csr_ptr && lat->csr) return PHL_OK;
     const int M = (int)lat->M, N = (int)lat->N, dp1 = lat->d + 1;
     if (lat->csr_ptr) PHL_HIP(hipFree(lat->csr_ptr));
@@ -509,22 +518,24 @@ int phl_ensure_csr(phl_lattice *lat, hipStream_t st)
         return PHL_OK;
     }
     temp_pool tmp;
-    int *cursor, *tile_sums;
-    phl_contrib_t *csr_tmp;
-    PHL_HIP(tmp.get(&cursor, (size_t)M * 2));  // cursor | cnt
-    PHL_HIP(tmp.get(&csr_tmp, (size_t)N));
+    int *cnt, *tile_sums, *vkey, *perm;
+    PHL_HIP(tmp.get(&cnt, (size_t)M));
     PHL_HIP(tmp.get(&tile_sums, (size_t)M / SCAN_TILE + 2));
-    int *cnt = cursor + M;
-    PHL_HIP(hipMemsetAsync(cursor, 0, sizeof(int) * (size_t)M * 2, st));
+    PHL_HIP(tmp.get(&vkey, (size_t)N));
+    PHL_HIP(tmp.get(&perm, (size_t)N));
+    PHL_HIP(hipMemsetAsync(cnt, 0, sizeof(int) * (size_t)M, st));
     const unsigned gN = (unsigned)((N + 255) / 256);
     hipLaunchKernelGGL(k_count_vid, dim3(gN), dim3(256), 0, st, lat->replay, N, cnt);
     PHL_HIP(hipGetLastError());
     int rc = exclusive_scan(cnt, lat->csr_ptr, M, tile_sums, st);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_fill, dim3(gN), dim3(256), 0, st, lat->replay, lat->csr_ptr, cursor, N, dp1, csr_tmp);
-    int blocks = (M + 3) / 4;
-    if (blocks > 256 * 16) blocks = 256 * 16;
-    hipLaunchKernelGGL(k_sort_lists, dim3(blocks), dim3(256), 0, st, csr_tmp, lat->csr_ptr, M, lat->csr);
+    // a pixel holds a vertex at most once (the d+1 vertices of a simplex are distinct), so a STABLE sort of the
+    // candidates by vertex id leaves every list in ascending pixel order; O(N) for any list lengths
+    hipLaunchKernelGGL(k_replay_vids, dim3(gN), dim3(256), 0, st, lat->replay, N, vkey);
+    PHL_HIP(hipGetLastError());
+    rc = stable_sort_perm(vkey, N, M, perm, tmp, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_fill_sorted, dim3(gN), dim3(256), 0, st, lat->replay, perm, N, dp1, lat->csr);
     PHL_HIP(hipGetLastError());
     PHL_HIP(hipStreamSynchronize(st));  // temporaries go back to the scratch cache
     return PHL_OK;
@@ -577,11 +588,7 @@ int phl_add_vertices_device(phl_lattice *lat, const int16_t *keys_host, int64_t 
         lat->M = M_new;
         rc = phl_rebuild_table_and_neighbors(lat, st);
         if (rc) return rc;
-        // value workspace is sized by M: force re-reservation
-        if (lat->buf[0]) PHL_HIP(hipFree(lat->buf[0]));
-        if (lat->buf[1]) PHL_HIP(hipFree(lat->buf[1]));
-        lat->buf[0] = lat->buf[1] = nullptr;
-        lat->buf_elems = 0;
+        // (the value workspaces are sized by M: phl_add_vertices drops them)
     }
     PHL_HIP(hipMemcpyAsync(vid_host, vid, sizeof(int32_t) * (size_t)K, hipMemcpyDeviceToHost, st));
     PHL_HIP(hipStreamSynchronize(st));

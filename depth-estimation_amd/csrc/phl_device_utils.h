@@ -7,33 +7,6 @@
 
 namespace {
 
-// One wave per vertex: rank-sort its contribution list by pixel index (pixels are distinct
-// inside a list because the d+1 vertices of one pixel's simplex are distinct).
-__global__ __launch_bounds__(256) void k_sort_lists(const phl_contrib_t *__restrict__ tmp, const int *__restrict__ ptr,
-                                                    int M, phl_contrib_t *__restrict__ out)
-{
-    const int lane = threadIdx.x & 63;
-    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int nwaves = (gridDim.x * blockDim.x) >> 6;
-    for (int v = wave; v < M; v += nwaves) {
-        const int beg = ptr[v], k = ptr[v + 1] - beg;
-        for (int i0 = 0; i0 < k; i0 += 64) {
-            const bool valid = (i0 + lane) < k;
-            phl_contrib_t mine;
-            mine.pixel = 0x7FFFFFFF;
-            mine.w = 0.f;
-            if (valid) mine = tmp[beg + i0 + lane];
-            int rank = 0;
-            for (int j0 = 0; j0 < k; j0 += 64) {
-                const int other = (j0 + lane) < k ? tmp[beg + j0 + lane].pixel : 0x7FFFFFFF;
-                const int cnt = min(64, k - j0);
-                for (int t = 0; t < cnt; t++) rank += (__shfl(other, t) < mine.pixel) ? 1 : 0;
-            }
-            if (valid) out[beg + rank] = mine;
-        }
-    }
-}
-
 // Run aggregation for atomics whose keys repeat in CONSECUTIVE lanes (neighbouring pixels hit the
 // same lattice vertex / grid cell): only the first lane of a run touches memory.
 // head_of_run: lane index of the first lane of my run; run_len (valid on head lanes): its length.
@@ -194,5 +167,108 @@ struct temp_pool {
         return e;
     }
 };
+
+// ------------------------------------------------------------------------------------------
+// Stable sort of n int32 keys in [0, key_bound): returns the permutation (perm[i] = original index of the
+// i-th smallest key; equal keys keep their original order).  LSD radix sort, 8 bits per pass, O(n) work for
+// ANY key distribution -- the per-vertex / per-cell lists built from it have no length limit (a constant
+// feature tensor puts every pixel into one list).  Per pass: block histograms [digit][block] -> one exclusive
+// scan -> stable scatter (a block walks its 2048 keys in rounds of 256; inside a round a lane's rank among
+// the lanes of its wavefront with the same digit comes from eight ballots).
+constexpr int RS_TILE = 2048;
+
+__global__ __launch_bounds__(256) void k_radix_hist(const int *__restrict__ keys, int n, int shift, int nblocks,
+                                                    int *__restrict__ hist)
+{
+    __shared__ int h[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const int base = blockIdx.x * RS_TILE;
+    for (int i = threadIdx.x; i < RS_TILE; i += 256) {
+        const int e = base + i;
+        if (e < n) atomicAdd(&h[(keys[e] >> shift) & 255], 1);
+    }
+    __syncthreads();
+    hist[threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
+}
+
+__global__ __launch_bounds__(256) void k_radix_scatter(const int *__restrict__ keys, const int *__restrict__ idx, int n,
+                                                       int shift, int nblocks, const int *__restrict__ base,
+                                                       int *__restrict__ keys_out, int *__restrict__ idx_out)
+{
+    __shared__ int run[256];        // next output position of each digit for this block
+    __shared__ int wcnt[4][256];    // digit counts of each wavefront in the current round
+    run[threadIdx.x] = base[threadIdx.x * nblocks + blockIdx.x];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int r = 0; r < RS_TILE; r += 256) {
+        for (int j = threadIdx.x; j < 4 * 256; j += 256) (&wcnt[0][0])[j] = 0;
+        __syncthreads();
+        const int e = blockIdx.x * RS_TILE + r + threadIdx.x;
+        const bool act = e < n;
+        const int key = act ? keys[e] : 0;
+        const int dg = (key >> shift) & 255;
+        unsigned long long peers = __ballot(act);       // active lanes of my wavefront with my digit
+#pragma unroll
+        for (int b = 0; b < 8; b++) {
+            const unsigned long long m = __ballot((dg >> b) & 1);
+            peers &= ((dg >> b) & 1) ? m : ~m;
+        }
+        const int rank = __popcll(peers & ((1ull << lane) - 1ull));
+        if (act && rank == 0) wcnt[w][dg] = __popcll(peers);
+        __syncthreads();
+        int pos = 0;
+        if (act) {
+            pos = run[dg] + rank;
+            for (int k = 0; k < w; k++) pos += wcnt[k][dg];
+        }
+        __syncthreads();
+        run[threadIdx.x] += wcnt[0][threadIdx.x] + wcnt[1][threadIdx.x] + wcnt[2][threadIdx.x] + wcnt[3][threadIdx.x];
+        if (act) {
+            keys_out[pos] = key;
+            idx_out[pos] = idx ? idx[e] : e;
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void k_iota(int *p, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = i;
+}
+
+__attribute__((unused)) int stable_sort_perm(const int *keys, int n, int64_t key_bound, int *perm_out, temp_pool &tmp, hipStream_t st)
+{
+    if (n <= 0) return PHL_OK;
+    int passes = 0;
+    for (int64_t b = key_bound > 1 ? key_bound - 1 : 0; b > 0; b >>= 8) passes++;
+    if (passes == 0) {
+        hipLaunchKernelGGL(k_iota, dim3((n + 255) / 256), dim3(256), 0, st, perm_out, n);
+        PHL_HIP(hipGetLastError());
+        return PHL_OK;
+    }
+    const int nblocks = (n + RS_TILE - 1) / RS_TILE;
+    int *hist, *base, *tile_sums, *kA, *kB, *iA;
+    PHL_HIP(tmp.get(&hist, (size_t)256 * nblocks));
+    PHL_HIP(tmp.get(&base, (size_t)256 * nblocks + 1));
+    PHL_HIP(tmp.get(&tile_sums, (size_t)256 * nblocks / SCAN_TILE + 2));
+    PHL_HIP(tmp.get(&kA, (size_t)n));
+    PHL_HIP(tmp.get(&kB, (size_t)n));
+    PHL_HIP(tmp.get(&iA, (size_t)n));
+    const int *kin = keys, *iin = nullptr;
+    for (int p = 0; p < passes; p++) {
+        int *kout = (p & 1) ? kB : kA;
+        int *iout = ((passes - 1 - p) & 1) ? iA : perm_out;     // the last pass lands in perm_out
+        hipLaunchKernelGGL(k_radix_hist, dim3(nblocks), dim3(256), 0, st, kin, n, 8 * p, nblocks, hist);
+        PHL_HIP(hipGetLastError());
+        const int rc = exclusive_scan(hist, base, 256 * nblocks, tile_sums, st);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_radix_scatter, dim3(nblocks), dim3(256), 0, st, kin, iin, n, 8 * p, nblocks, base, kout, iout);
+        PHL_HIP(hipGetLastError());
+        kin = kout;
+        iin = iout;
+    }
+    return PHL_OK;
+}
 
 }  // namespace

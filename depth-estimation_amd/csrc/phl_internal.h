@@ -57,16 +57,11 @@ struct phl_lattice {
     int32_t *vs_ptr;        // [M+1] slots of each vertex ...
     phl_contrib_t *vs;      // [S]   ... ascending (slot index in .pixel)
     int32_t *vorder;        // [M] vertices in chunk-major order (gather splat locality); may be null
-    float *partial;         // [S_multi][vd] partial splat sums
-    int64_t partial_elems;
     int64_t tile_bytes;
 
-    // value workspace, grown on demand
-    float *buf[2];
-    int64_t buf_elems;      // capacity of each buffer in floats
-    float *stage_in;        // [n][vd] staging for non pixel-major inputs
-    float *stage_out;
-    int64_t stage_elems;
+    // value workspaces (phl_api.hip): a filter call takes one for the duration of its launches, so any number
+    // of host threads / streams may filter through one lattice at the same time
+    struct phl_shared *shared;
 
     int64_t table_bytes;    // device bytes of the persistent tables
 
@@ -98,6 +93,30 @@ int phl_reference_table_sim(const int16_t *keys_clean, const int32_t *efirst, in
                             phl_reftable_query &q, phl_reftable_result &out);
 int phl_apply_reference_table(phl_lattice *lat, const int *flag, const int *rankv, hipStream_t st);
 
+// Buffers one filter call writes: the [M][vd] Jacobi ping-pong pair, the partial rows of the chunk splat and
+// the staging copies of non pixel-major inputs / outputs.  Grown on demand, reused in stream order.
+struct phl_workspace {
+    float *buf[2];
+    int64_t buf_elems;      // capacity of each buffer in floats
+    float *partial;         // [S_multi][vd] partial splat sums
+    int64_t partial_elems;
+    float *stage_in;        // [n][vd]
+    float *stage_out;
+    int64_t stage_elems;
+    hipStream_t last_stream;
+    bool stream_bound;      // work that uses the buffers may still be pending on last_stream
+    // completion mark: a one-thread kernel behind the last launch stores `ticket` into this pinned host word, so
+    // "has its work drained?" is a plain host load -- legal at any time, also while some stream is being captured
+    // (event queries are not)
+    unsigned long long *done_word;
+    unsigned long long ticket;
+    bool in_enqueue;        // a host thread is issuing launches on it right now
+    bool captured;          // a HIP graph holds its pointers: never resized or handed to another stream
+};
+int phl_ws_acquire(phl_lattice *lat, hipStream_t st, int64_t buf_elems, int64_t partial_elems, int64_t stage_elems,
+                   phl_workspace **out);
+void phl_ws_release(phl_lattice *lat, phl_workspace *ws, hipStream_t st, bool idle);
+
 // thread-local error message
 void phl_set_error(const char *fmt, ...);
 int phl_hip_fail(hipError_t e, const char *what, const char *file, int line);
@@ -114,6 +133,8 @@ void phl_scratch_release(size_t wanted_bytes);
 // ---- launchers implemented in phl_build.hip ----
 int phl_build_device(phl_lattice *lat, const float *ref, int64_t rs, int64_t cs, hipStream_t st);
 int phl_ensure_csr(phl_lattice *lat, hipStream_t st);  // pixel-sorted lists, built on first use
+namespace std { class mutex; }
+std::mutex *phl_csr_mutex(phl_lattice *lat);
 int phl_add_vertices_device(phl_lattice *lat, const int16_t *keys_host, int64_t count, int32_t *vid_host, hipStream_t st);
 
 // ---- implemented in phl_tiles.hip ----
@@ -121,8 +142,8 @@ int phl_tiles_build(phl_lattice *lat, const float *ref, int64_t rs, int64_t cs, 
 int phl_tiles_link_vertices(phl_lattice *lat, hipStream_t st);
 int phl_tiles_free(phl_lattice *lat);
 int phl_tiles_lprs(const phl_lattice *lat, int vd, int for_slice);  // -1: LDS-staged path unavailable
-int phl_tiles_reserve(phl_lattice *lat, int vd);
-int phl_launch_splat_tiled(phl_lattice *lat, const float *src, int64_t src_rs, int vd, float *vert, hipStream_t st);
+int phl_launch_splat_tiled(phl_lattice *lat, const float *src, int64_t src_rs, int vd, float *vert, float *partial,
+                           hipStream_t st);
 int phl_launch_slice_tiled(const phl_lattice *lat, const float *vert, int vd, float *out, int64_t out_rs, const float *sub,
                            int64_t sub_rs, unsigned flags, hipStream_t st);
 

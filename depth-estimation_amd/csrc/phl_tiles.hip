@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256) void k_minmax(const float *__restrict__ ref, i
 
 __global__ __launch_bounds__(256) void k_cell_ids(const float *__restrict__ ref, int64_t rs, int64_t cs, int64_t n, int da,
                                                   int db, float lo_a, float lo_b, float inv_t, int nca, int ncb,
-                                                  int *__restrict__ cell, int *cnt)
+                                                  int *__restrict__ cell)
 {
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool active = p < n;
@@ -81,27 +81,23 @@ __global__ __launch_bounds__(256) void k_cell_ids(const float *__restrict__ ref,
     }
     const int c = cb * nca + ca;   // the wider dimension runs fastest inside a row of cells
     if (active) cell[p] = c;
-    (void)run_atomic_add(cnt, c, active);   // consecutive pixels mostly share a cell: one atomic per run
 }
 
-__global__ __launch_bounds__(256) void k_group_fill(const int *__restrict__ key, const int *__restrict__ ptr, int *cursor,
-                                                    int n, phl_contrib_t *__restrict__ tmp)
+// vertex of every slot without the sole mark: the sort key of the vertex -> slots lists
+__global__ __launch_bounds__(256) void k_slot_keys(const int *__restrict__ slot_vert, int S, int *__restrict__ key)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool active = i < n;
-    const int k = key[active ? i : n - 1] & 0x7FFFFFFF;
-    const int off = run_atomic_add(cursor, k, active);
-    if (!active) return;
+    if (i < S) key[i] = slot_vert[i] & 0x7FFFFFFF;
+}
+
+__global__ __launch_bounds__(256) void k_perm_to_contrib(const int *__restrict__ perm, int n, phl_contrib_t *__restrict__ out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
     phl_contrib_t c;
-    c.pixel = i;
+    c.pixel = perm[i];
     c.w = 0.f;
-    tmp[ptr[k] + off] = c;
-}
-
-__global__ __launch_bounds__(256) void k_extract_index(const phl_contrib_t *__restrict__ in, int n, int *__restrict__ out)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = in[i].pixel;
+    out[i] = c;
 }
 
 // ---- per-chunk structure: one workgroup sorts the chunk's (vertex, entry) pairs in LDS -----------
@@ -782,7 +778,7 @@ inline int pick_lpr_row(int vd)
 int phl_tiles_free(phl_lattice *lat)
 {
     void *ptrs[] = {lat->pix_order, lat->chunk_vptr, lat->slot_vert, lat->slot_pidx, lat->seg_rng, lat->seg,
-                    lat->lidx, lat->vs_ptr, lat->vs, lat->partial, lat->vorder};
+                    lat->lidx, lat->vs_ptr, lat->vs, lat->vorder};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     lat->pix_order = lat->chunk_vptr = lat->slot_vert = lat->slot_pidx = lat->vs_ptr = nullptr;
@@ -790,8 +786,6 @@ int phl_tiles_free(phl_lattice *lat)
     lat->vorder = nullptr;
     lat->seg = lat->vs = nullptr;
     lat->lidx = nullptr;
-    lat->partial = nullptr;
-    lat->partial_elems = 0;
     lat->nchunks = 0;
     lat->S = lat->S_multi = 0;
     lat->nv_max = 0;
@@ -819,27 +813,25 @@ int phl_tiles_link_vertices(phl_lattice *lat, hipStream_t st)
         return PHL_OK;
     }
     temp_pool tmp;
-    int *cnt, *cursor, *multi, *tile_sums;
-    phl_contrib_t *vtmp;
-    PHL_HIP(tmp.get(&cnt, (size_t)M * 2 + 2));
+    int *cnt, *multi, *tile_sums, *skey, *sperm;
+    PHL_HIP(tmp.get(&cnt, (size_t)M + 1));
     PHL_HIP(tmp.get(&multi, (size_t)S + 1));
     PHL_HIP(tmp.get(&tile_sums, (size_t)(S > M ? S : M) / SCAN_TILE + 2));
-    PHL_HIP(tmp.get(&vtmp, (size_t)S + 1));
-    cursor = cnt + M + 1;
-    PHL_HIP(hipMemsetAsync(cnt, 0, sizeof(int) * ((size_t)M * 2 + 2), st));
+    PHL_HIP(tmp.get(&skey, (size_t)S));
+    PHL_HIP(tmp.get(&sperm, (size_t)S));
+    PHL_HIP(hipMemsetAsync(cnt, 0, sizeof(int) * ((size_t)M + 1), st));
     const unsigned gS = (unsigned)((S + 255) / 256);
     hipLaunchKernelGGL(k_strip_marks, dim3(gS), dim3(256), 0, st, lat->slot_vert, S);
     hipLaunchKernelGGL(k_count_slots, dim3(gS), dim3(256), 0, st, lat->slot_vert, S, cnt);
     PHL_HIP(hipGetLastError());
     int rc = exclusive_scan(cnt, lat->vs_ptr, M, tile_sums, st);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_group_fill, dim3(gS), dim3(256), 0, st, lat->slot_vert, lat->vs_ptr, cursor, S, vtmp);
-    {
-        int blocks = (M + 3) / 4;
-        if (blocks > 256 * 16) blocks = 256 * 16;
-        if (blocks < 1) blocks = 1;
-        hipLaunchKernelGGL(k_sort_lists, dim3(blocks), dim3(256), 0, st, vtmp, lat->vs_ptr, M, lat->vs);
-    }
+    // slots grouped by vertex, ascending slot (= ascending chunk) inside a vertex: a stable sort by vertex id
+    hipLaunchKernelGGL(k_slot_keys, dim3(gS), dim3(256), 0, st, lat->slot_vert, S, skey);
+    PHL_HIP(hipGetLastError());
+    rc = stable_sort_perm(skey, S, M, sperm, tmp, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_perm_to_contrib, dim3(gS), dim3(256), 0, st, sperm, S, lat->vs);
     hipLaunchKernelGGL(k_mark_sole, dim3(gS), dim3(256), 0, st, lat->slot_vert, S, lat->vs_ptr, multi);
     PHL_HIP(hipGetLastError());
     rc = exclusive_scan(multi, lat->slot_pidx, S, tile_sums, st);
@@ -931,32 +923,19 @@ int phl_tiles_build(phl_lattice *lat, const float *ref, int64_t rs, int64_t cs, 
     }
     const int ncell = nca * ncb;
 
-    // 2. pixels in cell-major order (ascending pixel inside a cell)
-    int *cell, *ccnt, *cptr, *ccur, *tile_sums;
-    phl_contrib_t *gtmp, *gsorted;
+    // 2. pixels in cell-major order (ascending pixel inside a cell): a stable sort of the pixels by cell id.
+    //    O(n) whatever the features look like -- a constant or heavily clustered `ref` puts (nearly) all
+    //    pixels into one cell
+    int *cell, *tile_sums;
     PHL_HIP(tmp.get(&cell, (size_t)n));
-    PHL_HIP(tmp.get(&ccnt, (size_t)ncell * 2 + 2));
-    PHL_HIP(tmp.get(&cptr, (size_t)ncell + 1));
-    PHL_HIP(tmp.get(&tile_sums, (size_t)(n > ncell ? n : ncell) / SCAN_TILE + 2));
-    PHL_HIP(tmp.get(&gtmp, (size_t)n));
-    PHL_HIP(tmp.get(&gsorted, (size_t)n));
-    ccur = ccnt + ncell + 1;
-    PHL_HIP(hipMemsetAsync(ccnt, 0, sizeof(int) * ((size_t)ncell * 2 + 2), st));
+    PHL_HIP(tmp.get(&tile_sums, (size_t)n / SCAN_TILE + 2));
     const unsigned gn = (unsigned)((n + 255) / 256);
     hipLaunchKernelGGL(k_cell_ids, dim3(gn), dim3(256), 0, st, ref, rs, cs, (int64_t)n, da, db, lo[da],
-                       db >= 0 ? lo[db] : 0.f, inv_t, nca, ncb, cell, ccnt);
+                       db >= 0 ? lo[db] : 0.f, inv_t, nca, ncb, cell);
     PHL_HIP(hipGetLastError());
-    rc = exclusive_scan(ccnt, cptr, ncell, tile_sums, st);
-    if (rc) return rc;
-    hipLaunchKernelGGL(k_group_fill, dim3(gn), dim3(256), 0, st, cell, cptr, ccur, n, gtmp);
-    {
-        int blocks = (ncell + 3) / 4;
-        if (blocks > 256 * 16) blocks = 256 * 16;
-        hipLaunchKernelGGL(k_sort_lists, dim3(blocks), dim3(256), 0, st, gtmp, cptr, ncell, gsorted);
-    }
     PHL_HIP(hipMalloc((void **)&lat->pix_order, sizeof(int) * (size_t)n));
-    hipLaunchKernelGGL(k_extract_index, dim3(gn), dim3(256), 0, st, gsorted, n, lat->pix_order);
-    PHL_HIP(hipGetLastError());
+    rc = stable_sort_perm(cell, n, ncell, lat->pix_order, tmp, st);
+    if (rc) return rc;
 
     // 3. per-chunk local vertex lists, segments and local indices
     nchunks = (n + P - 1) / P;
@@ -1029,19 +1008,8 @@ int phl_tiles_lprs(const phl_lattice *lat, int vd, int for_slice)
                      : pick_lprs(vd, lat->P + 1, lds_extra(lat->P, lat->d + 1, lat->nv_max));
 }
 
-int phl_tiles_reserve(phl_lattice *lat, int vd)
-{
-    const int64_t need = lat->S_multi * (int64_t)vd;
-    if (need <= lat->partial_elems) return PHL_OK;
-    if (lat->partial) PHL_HIP(hipFree(lat->partial));
-    lat->partial = nullptr;
-    lat->partial_elems = 0;
-    PHL_HIP(hipMalloc((void **)&lat->partial, sizeof(float) * (size_t)(need ? need : 1)));
-    lat->partial_elems = need;
-    return PHL_OK;
-}
-
-int phl_launch_splat_tiled(phl_lattice *lat, const float *src, int64_t src_rs, int vd, float *vert, hipStream_t st)
+int phl_launch_splat_tiled(phl_lattice *lat, const float *src, int64_t src_rs, int vd, float *vert, float *partial,
+                           hipStream_t st)
 {
     const int M = (int)lat->M;
     if (M == 0 || vd == 0) return PHL_OK;
@@ -1051,8 +1019,7 @@ int phl_launch_splat_tiled(phl_lattice *lat, const float *src, int64_t src_rs, i
         phl_set_error("tiled splat: chunk does not fit LDS");
         return PHL_ERR_UNSUPPORTED;
     }
-    int rc = phl_tiles_reserve(lat, vd);
-    if (rc) return rc;
+    int rc = PHL_OK;
     const size_t lds = (size_t)(lat->P + 1) * lprs * 16 + (size_t)extra;
     unsigned cgrid;
     int xcd_chunk;
@@ -1069,7 +1036,7 @@ int phl_launch_splat_tiled(phl_lattice *lat, const float *src, int64_t src_rs, i
         if ((rc = allow_lds(k_splat_tiled<LPRS>, lds)) != PHL_OK) return;
         k_splat_tiled<LPRS><<<dim3(cgrid), dim3(TPB_S), lds, st>>>(
             src, src_rs, vd, (int)lat->n, lat->P, lat->d + 1, lat->nv_max, lat->pix_order, lat->chunk_vptr, lat->slot_vert,
-            lat->slot_pidx, lat->seg_rng, lat->seg, vert, lat->partial, lat->nchunks, xcd_chunk, tl);
+            lat->slot_pidx, lat->seg_rng, lat->seg, vert, partial, lat->nchunks, xcd_chunk, tl);
     });
     if (tl) {
         std::vector<unsigned long long> h(tl_n);
@@ -1087,7 +1054,7 @@ int phl_launch_splat_tiled(phl_lattice *lat, const float *src, int64_t src_rs, i
     int64_t blocks = (waves + 3) / 4;
     if (blocks > 2048) blocks = 2048;
 #define PHL_RED(LPR_)                                                                                                  \
-    k_splat_reduce<LPR_><<<dim3((unsigned)blocks), dim3(256), 0, st>>>(lat->partial, lat->vs_ptr, lat->vs, lat->slot_pidx, \
+    k_splat_reduce<LPR_><<<dim3((unsigned)blocks), dim3(256), 0, st>>>(partial, lat->vs_ptr, lat->vs, lat->slot_pidx, \
                                                                        M, vd, vert)
     switch (lpr) {
         case 64: PHL_RED(64); break;

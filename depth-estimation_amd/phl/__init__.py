@@ -67,6 +67,7 @@ def load_library():
         lib.phl_num_dims.argtypes = [vp]
         lib.phl_device.argtypes = [vp]
         lib.phl_reserve.argtypes = [vp, i32]
+        lib.phl_reserve_ex.argtypes = [vp, i32, u32]
         lib.phl_add_vertices.argtypes = [vp, vp, i64, vp, vp]
         lib.phl_num_local_vertices.restype = i64
         lib.phl_num_local_vertices.argtypes = [vp]
@@ -119,7 +120,8 @@ class Lattice:
     """Permutohedral lattice of a feature tensor ``ref`` [n, d] (fp32, any strides).
 
     Build cost is paid once; ``filter`` then runs splat -> blur -> slice for any [n, vd] values.
-    Not re-entrant: use one Lattice per concurrent stream.
+    Re-entrant: any number of threads / streams may filter through one Lattice at the same time (the C library
+    hands every call its own value workspace; see phl_reserve in include/phl.h).
     """
 
     def __init__(self, ref, device=None, reference_table=False):
@@ -165,8 +167,11 @@ class Lattice:
     def device_bytes(self):
         return int(load_library().phl_device_bytes(self._h))
 
-    def reserve(self, vd):
-        _check(load_library().phl_reserve(self._h, int(vd)))
+    def reserve(self, vd, strided_io=False, exact=False):
+        """Pre-size everything a ``filter`` over ``vd`` channels needs, so that the next call -- on any stream,
+        e.g. inside a HIP-graph capture -- allocates nothing.  strided_io: also the staging copies channel-major
+        (NCHW) views go through; exact: prepare for ``exact=True`` calls."""
+        _check(load_library().phl_reserve_ex(self._h, int(vd), (1 if strided_io else 0) | (2 if exact else 0)))
 
     # ---- hot path ---------------------------------------------------------------------------
     def filter(self, src, subtract_input=False, out=None, exact=False, no_tiles=False):

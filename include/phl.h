@@ -127,10 +127,19 @@ int phl_add_vertices(phl_lattice *lat, const int16_t *keys_host, int64_t count, 
 int64_t phl_num_local_vertices(const phl_lattice *lat); /* vertices created by this lattice's own pixels */
 
 /* Pre-size everything phl_filter(vd) needs (the [M][vd] ping-pong buffers, the partial-row buffer
- * of the chunk splat or the contribution lists of the gather splat) so that the call itself
- * allocates nothing and never synchronises: required before hipGraph capture.  For
- * PHL_FILTER_EXACT call phl_filter once un-captured first (it builds its lists on first use). */
+ * of the chunk splat or the contribution lists of the gather splat) so that the NEXT call, on any stream,
+ * allocates nothing and never synchronises: required before hipGraph capture.
+ *
+ * Threading: a lattice is re-entrant.  Its tables are read-only after the build; the buffers a filter call
+ * writes live in workspaces handed out per call (reused in stream order, a second one is allocated when two
+ * streams are in flight at once), so any number of host threads / streams may call phl_filter, phl_splat,
+ * phl_blur, phl_slice on one handle concurrently.  phl_add_vertices and phl_destroy are not concurrent with
+ * anything. */
 int phl_reserve(phl_lattice *lat, int vd);
+/* phl_reserve with options: PHL_RESERVE_STRIDED_IO also sizes the staging copies that channel-major (NCHW) views
+ * go through, PHL_RESERVE_EXACT prepares for PHL_FILTER_EXACT calls (builds the pixel-sorted lists). */
+enum phl_reserve_flags { PHL_RESERVE_STRIDED_IO = 1, PHL_RESERVE_EXACT = 2 };
+int phl_reserve_ex(phl_lattice *lat, int vd, unsigned reserve_flags);
 
 /* ---- the hot path -----------------------------------------------------------------------
  * out = slice(blur(splat(src)))  == lattice.filter(src, ref) of the reference

@@ -31,13 +31,16 @@ def test_mean_field_tsukuba_crop(golden_dir):
     assert rel(WQ0.cpu().numpy(), g["WQ0"]) <= RTOL
     for it, key in ((1, "1"), (5, "5")):
         Q = mean_field_infer(E0, W, Mu, it)
-        assert rel(Q.cpu().numpy(), g["Q" + key]) <= RTOL * 10      # probabilities span many decades
+        eq = rel(Q.cpu().numpy(), g["Q" + key])
         disp = (Q @ labels).cpu().numpy()
-        assert np.abs(disp - g["disp" + key]).max() <= RTOL * np.abs(g["disp" + key]).max()
-        assert (np.abs(disp - g["disp" + key]) / np.maximum(g["disp" + key], 1e-2)).max() <= RTOL * 5
+        # north star: "output disparity maps match the reference CPU path within 1e-4 relative per pixel"
+        ed = float((np.abs(disp - g["disp" + key]) / np.maximum(np.abs(g["disp" + key]), 1e-2)).max())
+        print(f"[measured] mean field, {it} iteration(s): Q rel {eq:.2e}, disparity rel per pixel {ed:.2e}")
+        assert eq <= RTOL            # probabilities (floored at 1e-3 of the largest), same bar
+        assert ed <= RTOL
     # CPU tensors in, CPU tensors out (the notebook runs on device('cpu'))
     Qc = mean_field_infer(E0.cpu(), LatticeGaussian(ref.cpu()), Mu.cpu(), 1)
-    assert not Qc.is_cuda and rel(Qc.numpy(), g["Q1"]) <= RTOL * 10
+    assert not Qc.is_cuda and rel(Qc.numpy(), g["Q1"]) <= RTOL
 
 
 @pytest.mark.parametrize("name", ["grad_n80_d3_L2", "grad_n2000_d5_L4"])
@@ -53,7 +56,9 @@ def test_lattice_filter_backward(golden_dir, name):
     assert np.abs(out.detach().cpu().numpy() - g["out"]).max() <= 1e-5 * np.abs(g["out"]).max()
     out.backward(gout)
     assert rel(src.grad.cpu().numpy(), g["grad_src"]) <= RTOL
-    assert rel(ref.grad.cpu().numpy(), g["grad_ref"]) <= 5e-4      # reference's own gradcheck rtol (gaussian_matrix.py:516)
+    eg = rel(ref.grad.cpu().numpy(), g["grad_ref"])
+    print(f"[measured] {name}: grad_ref rel {eg:.2e}")
+    assert eg <= 5e-4      # reference's own gradcheck rtol (gaussian_matrix.py:516); a sum of 4L cancelling products
     src2 = src.detach().clone().requires_grad_(True)
     LatticeFilter.apply(src2, ref.detach()).backward(gout)
     assert rel(src2.grad.cpu().numpy(), g["grad_src_only"]) <= RTOL
@@ -82,7 +87,9 @@ def test_laplacians(golden_dir):
     for mode in ("sym", "right", "none"):
         opc = RbfLaplacianC(ref, normalize=mode)
         assert rel(opc.D.cpu().numpy(), g["rbfc_D"]) <= RTOL
-        assert rel((opc @ U).cpu().numpy(), g["rbfc_" + mode]) <= RTOL * 3   # "- U" cancellation
+        el = rel((opc @ U).cpu().numpy(), g["rbfc_" + mode])
+        print(f"[measured] RbfLaplacianC {mode}: {el:.2e}")
+        assert el <= RTOL * 3   # "- U" cancellation
 
 
 def test_crf_as_rnn_lattice_runs():

@@ -581,6 +581,118 @@ def test_filter_is_graph_capturable(phl):
     assert torch.equal(out, want2) and not torch.equal(out, want1)
 
 
+@pytest.mark.parametrize("layout", ["pixel_major", "nchw_view", "exact"])
+def test_reserve_then_capture_without_warm_up(phl, layout):
+    """phl_reserve's contract (include/phl.h): after it the NEXT filter call allocates nothing -- so a capture
+    may follow a single reserve() directly, with no un-captured warm-up call, in the pixel-major layout, through
+    the channel-major views BatchedAdjacency passes (gaussian_matrix.py:348-349) and for exact-mode calls."""
+    rng = np.random.default_rng(19)
+    n, d, L = 30000, 5, 32
+    ref = np.cumsum(rng.random((n, d), dtype=np.float32) * 0.02, axis=0).astype(np.float32)
+    Lat = phl.Lattice(torch.from_numpy(ref).cuda())
+    exact = layout == "exact"
+    Lat.reserve(L, strided_io=(layout == "nchw_view"), exact=exact)
+    if layout == "nchw_view":
+        x = torch.rand((L, n), device="cuda").permute(1, 0)
+        out = torch.empty((L, n), device="cuda").permute(1, 0)
+    else:
+        x = torch.rand((n, L), device="cuda")
+        out = torch.empty_like(x)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        Lat.filter(x, out=out, exact=exact)
+    g.replay()
+    torch.cuda.synchronize()
+    want = phl.Lattice(torch.from_numpy(ref).cuda()).filter(x.contiguous(), exact=exact)
+    assert torch.equal(out.contiguous(), want)
+
+
+def test_two_threads_two_streams_one_lattice(phl):
+    """SURVEY 8(b) threading row: "re-entrant; autograd may call from any thread".  Two host threads, each on its
+    own stream, filter different values through ONE cached lattice at the same time; every result must equal
+    the single-threaded one bit for bit (each call works on its own value workspace)."""
+    import threading
+
+    rng = np.random.default_rng(23)
+    n, d, L = 120000, 5, 64
+    ref_np = np.cumsum(rng.random((n, d), dtype=np.float32) * 0.01, axis=0).astype(np.float32)
+    ref = torch.from_numpy(ref_np).cuda()
+    phl.clear_cache()
+    xs = [torch.rand((n, L), device="cuda") for _ in range(4)]
+    want = [phl.filter(x, ref) for x in xs]
+    torch.cuda.synchronize()
+    errors = []
+
+    def worker(tid):
+        try:
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st):
+                for it in range(25):
+                    k = (tid + it) % len(xs)
+                    got = phl.filter(xs[k], ref)             # same cached Lattice in both threads
+                    if it % 5 == 4:
+                        st.synchronize()
+                        if not torch.equal(got, want[k]):
+                            errors.append((tid, it, float((got - want[k]).abs().max())))
+                st.synchronize()
+                if not torch.equal(got, want[k]):
+                    errors.append((tid, "last", float((got - want[k]).abs().max())))
+        except Exception as e:      # noqa: BLE001
+            errors.append((tid, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    assert phl.lattice_for(ref) is phl.lattice_for(ref)
+
+
+@pytest.mark.parametrize("kind", ["constant", "half_flat_colour", "outliers"])
+def test_degenerate_features_build_in_bounded_time(phl, kind):
+    """Clustered features: a constant `ref` puts every pixel into one grid cell and one vertex list, a colour-only
+    ref with a flat background half of them.  The build's grouping steps are O(n) radix sorts, so this takes
+    milliseconds (a rank sort per list would take minutes here and look like a hang)."""
+    import time
+    from oracle import phl_oracle as po
+
+    n, L = 1 << 20, 8
+    rng = np.random.default_rng(31)
+    if kind == "constant":
+        ref = np.full((n, 5), 0.37, np.float32)
+    elif kind == "half_flat_colour":
+        ref = (rng.random((n, 3), dtype=np.float32) * 4).astype(np.float32)
+        ref[: n // 2] = np.float32(1.25)                    # flat background
+    else:
+        ref = (rng.random((n, 2), dtype=np.float32) * 0.5).astype(np.float32)
+        ref[::100000] += np.float32(3000.0)                 # range outliers: the uniform grid collapses
+    src = rng.random((n, L), dtype=np.float32)
+    r = torch.from_numpy(ref).cuda()
+    s = torch.from_numpy(src).cuda()
+    torch.cuda.synchronize()
+    t0 = time.time()
+    Lat = phl.Lattice(r)
+    out = Lat.filter(s)
+    torch.cuda.synchronize()
+    t_default = time.time() - t0
+    t0 = time.time()
+    oute = Lat.filter(s, exact=True)                        # builds the pixel-sorted lists: one list of n entries
+    torch.cuda.synchronize()
+    t_exact = time.time() - t0
+    print(f"[measured] {kind}: n={n} M={Lat.M} build+filter {t_default * 1e3:.1f} ms, exact (lists + filter) {t_exact * 1e3:.1f} ms")
+    assert t_default < 5.0 and t_exact < 20.0
+    cut = 40000                                             # oracle on a prefix (same clustering)
+    O = po.Oracle(ref[:cut])
+    Lc = phl.Lattice(r[:cut].contiguous())
+    assert Lc.M == O.M
+    want = O.filter(src[:cut])
+    assert np.array_equal(Lc.filter(s[:cut].contiguous(), exact=True).cpu().numpy().view(np.uint32), want.view(np.uint32))
+    assert rel_err(Lc.filter(s[:cut].contiguous()).cpu().numpy(), want) <= 1e-4
+    assert torch.isfinite(out).all() and rel_err(out.cpu().numpy(), oute.cpu().numpy()) <= 1e-4
+
+
 def test_very_wide_values_many_slabs(phl):
     """vd = 3072 (the reference's ref-gradient filter for L=256, d=5 has 2L(1+d) channels): 48
     slabs through the staged kernels."""
