@@ -110,6 +110,16 @@ def potts(num_classes):
     return conv
 
 
+def _compat_matrix(mu, L, labels, device):
+    """[L, L] matrix M with ``mu(Q)[:, c] = sum_b M[b, c] Q[:, b]`` for the compatibility modules CRFasRNN is
+    used with (``charb``, or a bias-free 1x1 conv such as ``potts``); None for anything else."""
+    if isinstance(mu, charb):
+        return mu.matrix(L, labels, device)
+    if isinstance(mu, nn.Conv2d) and mu.kernel_size == (1, 1) and mu.bias is None and mu.groups == 1 and mu.weight.shape[:2] == (L, L):
+        return mu.weight.detach()[:, :, 0, 0].t().to(device, torch.float32)      # conv: out[c] = sum_b w[c, b] q[b]
+    return None
+
+
 def _maybe_learnable(value, trainable):
     """A scalar hyper-parameter: nn.Parameter when it is to be trained, the plain number otherwise
     (the reference's ``nn.Parameter(torch.tensor(v)) if trainable else v`` idiom, crf_module.py:109-110)."""
@@ -135,6 +145,13 @@ class charb(nn.Module):
         weight = compatibility_matrix(lambda p, q: charbonneir(q, p, self.gamma), labels)     # symmetric in (p, q)
         return F.conv2d(x, weight[..., None, None]) * self._scale()
 
+    def matrix(self, L, labels=None, device=None):
+        """The same compatibility as a dense [L, L] matrix for pixel-major data: forward(x)[:, c] = (x @ M)[:, c]."""
+        if labels is None:
+            labels = torch.arange(L, dtype=torch.float32, device=device)
+        weight = compatibility_matrix(lambda p, q: charbonneir(q, p, self.gamma), labels.to(device))
+        return (weight * self._scale()).detach().t().contiguous()
+
     def get_energies_from_scalar(self, x, labels):
         return charbonneir(labels, x, self.gamma * labels.max()) * self._scale()
 
@@ -146,6 +163,30 @@ def _mean_field_nchw(E0, message, niters):
         E = E0 + message(Q)
         Q = F.softmax(-E, dim=1)
     return E
+
+
+def _mean_field_nchw_fused(E0, refs, M, niters):
+    """The same iteration for a lattice W, without autograd, the way the device wants it: one transpose to
+    pixel-major [n, L] per image on entry, then per iteration ONE lattice filter with the ``- Q`` fused
+    (phl_filter) and ONE fused compatibility-product + softmax kernel (phl_compat_softmax), and one transpose
+    back at the end -- Q, G and E never make extra passes over HBM.  The reference evaluates
+    W(Mu(Q)); here (W Q) Mu: W acts on pixels, Mu on labels, so they commute (fp32 rounding differs)."""
+    import phl
+
+    bs, L, h, w = E0.shape
+    d = refs.shape[1]
+    out = torch.empty_like(E0)
+    for b in range(bs):
+        e0 = E0[b].reshape(L, h * w).t().contiguous()                      # [n, L]
+        lat = phl.lattice_for(refs[b].detach().reshape(d, h * w).t())       # strided [n, d] view, no copy
+        Q = phl.softmax_neg_add(e0)
+        for it in range(niters):
+            X = lat.filter(Q, subtract_input=True)
+            last = it == niters - 1
+            Q = phl.compat_softmax(e0, X, M, out=Q, logits=last)
+        res = Q if niters > 0 else e0
+        out[b].reshape(L, h * w).copy_(res.t())
+    return out if niters > 0 else E0
 
 
 class CRFasRNN(nn.Module):
@@ -165,6 +206,12 @@ class CRFasRNN(nn.Module):
         """refs [B, C, H, W], logits [B, L, H, W]."""
         E0 = -logits if confidence is None else -logits * confidence
         extra = () if labels is None else (labels,)
+        if (isinstance(self.W, BatchedAdjacency) and self.niters > 0 and E0.is_cuda and E0.dtype == torch.float32
+                and not (torch.is_grad_enabled() and (E0.requires_grad or refs.requires_grad
+                                                      or any(p.requires_grad for p in self.Mu.parameters())))):
+            M = _compat_matrix(self.Mu, E0.shape[1], labels, E0.device)
+            if M is not None:
+                return _mean_field_nchw_fused(E0.contiguous(), refs, M, self.niters)      # already -E
         return -_mean_field_nchw(E0, lambda Q: self.W(self.Mu(Q, *extra), refs), self.niters)
 
 

@@ -87,9 +87,11 @@ class LatticeFilter(Function):
 
 def batched_filter(flat_srcs, flat_refs, num_threads=None):
     """Independent lattice per batch item (:370-377).  The reference forks a process pool of
-    ``num_threads`` CPU workers per call; here every item is one lattice on the GPU, launched
-    back to back on the current stream (``num_threads`` is accepted for signature parity)."""
-    return torch.stack([latticefilter(s, r) for s, r in zip(flat_srcs, flat_refs)])
+    ``num_threads`` CPU workers per call, one image per worker; here every item is one cached lattice on a
+    GPU, the items dealt round-robin over the visible GPUs (phl.batch_devices: all of them for CPU tensors, the
+    tensors' own device otherwise), each GPU on its own stream, no collective.  ``num_threads`` is accepted for
+    signature parity."""
+    return phl.batched_filter(flat_srcs, flat_refs)
 
 
 class BatchedLatticeFilter(Function):

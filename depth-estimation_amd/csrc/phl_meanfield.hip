@@ -119,6 +119,143 @@ __global__ __launch_bounds__(256) void k_stream_copy(const float4 *__restrict__ 
     for (; i < n4; i += stride) dst[i] = src[i];
 }
 
+
+// ------------------------------------------------------------------------------------------------------------
+// k_compat_softmax: out[p,:] = softmax(-(E0[p,:] + X[p,:] @ Mu)) -- everything of a mean-field iteration that is
+// not the lattice filter (crf/crf_module.py:51-52 with X = W@Q), in ONE kernel: the [n,L]x[L,L] compatibility
+// product on the fp32-input matrix cores (v_mfma_f32_32x32x2_f32: exact f32, bitwise an fmaf chain in k order;
+// gfx950 has no xf32/TF32 path and the reference computes in f32), with +E0, negate and the row softmax done on
+// the accumulators.  Neither G = X@Mu nor E ever exists in HBM: the iteration's non-lattice half moves 3 x [n,L]
+// (read X, read E0, write Q) instead of the 7 x [n,L] of GEMM + fused softmax, and is MFMA-bound
+// (2 n L^2 flop at ~155 TF f32: 2.7 ms for 2048x1536x256).
+//
+// Tiling.  L = 32*NT <= 256, so a pixel's whole label row fits one workgroup: 256 threads = 4 waves, a wave owns
+// 32 pixels x all L labels = NT accumulator tiles of 32x32 (16 VGPRs each, 128 at L = 256), two workgroups per CU
+// so that one wave's epilogue (exp, stores) runs under its SIMD partner's MFMAs.  K = L is walked in chunks of
+// 32: Mu's chunk (32 k x L labels, 32 KiB) is shared by the four waves through LDS, double buffered; X comes
+// straight from global memory (each value is used by one wave only).
+//
+// Operand maps (32x32x2: lane l = (i = l&31, h = l>>5) supplies A[i][k-slot h] and B[k-slot h][j = i]).  The k
+// order of a contraction is free as long as A and B agree, so a lane loads 16 B = X[row i][8q+4h .. 8q+4h+3]
+// and the four values feed MFMAs u = 0..3 of group q: MFMA (q,u) contracts k = 8q+u (lower half-wave) and
+// k = 8q+4+u (upper).  B must follow: lane (j,h) takes Mu[8q+4h+u][32t+j], u = 0..3 -- 16 contiguous bytes of
+// the TRANSPOSED compatibility matrix, which is what the caller passes (MuT[c][k]) and what the LDS image
+// holds: Bt[label][k], 128-byte rows whose 16-byte slots are XOR-swizzled (see the chunk loader).
+// 16 bytes global -> LDS without a register in between (global_load_lds_dwordx4): the LDS address is the
+// wave-uniform `l` plus lane*16, the global address is per lane
+__device__ __forceinline__ void glds16(const float *g, float *l)
+{
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
+                                     (__attribute__((address_space(3))) void *)l, 16, 0, 0);
+}
+
+template <int NT, bool LOGITS>
+__global__ __launch_bounds__(256, 2) void k_compat_softmax(const float *__restrict__ E0, int64_t e_rs,
+                                                           const float *__restrict__ X, int64_t x_rs,
+                                                           const float *__restrict__ MuT, float *__restrict__ out,
+                                                           int64_t o_rs, int64_t n)
+{
+    typedef float f32x16 __attribute__((ext_vector_type(16)));
+    constexpr int L = 32 * NT;
+    extern __shared__ __attribute__((aligned(16))) float lds[];   // 2 x [L labels][32 k], 16-byte slots XOR-swizzled
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 31, h = lane >> 5;
+    const int64_t row0 = (int64_t)blockIdx.x * 128 + wave * 32;
+    const int64_t arow = min(row0 + i, n - 1);          // clamped: loads stay in bounds, stores are predicated
+    const float *xrow = X + arow * x_rs + 4 * h;
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; t++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[t][r] = 0.f;
+
+    // Chunk loader (LDS-DMA, no staging registers): a chunk is L labels x 8 slots of 16 B; one wave-instruction
+    // fills 64 consecutive slots = 8 labels.  LDS stays linear (that is all the DMA can write); the bank
+    // swizzle lives in WHICH 16 bytes a lane fetches: slot s of label r holds k-part s ^ ((r >> 1) & 7), and the
+    // reads below apply the same XOR (the 16 lanes a ds_read_b128 serves at a time then hit 16 different
+    // 16-byte bank groups).
+    auto load_mu = [&](int kc, int buf) {
+#pragma unroll
+        for (int r = 0; r < NT; r++) {
+            const int g0 = (wave * NT + r) * 64;             // first slot of this wave-instruction
+            const int g = g0 + lane;
+            const int lab = g >> 3, part = (g & 7) ^ ((lab >> 1) & 7);
+            glds16(MuT + (int64_t)lab * L + 32 * kc + 4 * part, lds + buf * (L * 32) + g0 * 4);
+        }
+    };
+    float4 a_cur[4], a_nxt[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) a_nxt[q] = *reinterpret_cast<const float4 *>(xrow + 8 * q);
+    load_mu(0, 0);
+    __syncthreads();
+    const int sw = (i >> 1) & 7;            // the swizzle of the labels this lane reads (32t + i)
+    for (int kc = 0; kc < NT; kc++) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) a_cur[q] = a_nxt[q];
+        const bool more = kc + 1 < NT;       // uniform
+        if (more) {
+            // next chunk: the other buffer was last read in chunk kc-1, behind the previous barrier
+            load_mu(kc + 1, (kc + 1) & 1);
+#pragma unroll
+            for (int q = 0; q < 4; q++) a_nxt[q] = *reinterpret_cast<const float4 *>(xrow + 32 * (kc + 1) + 8 * q);
+        }
+        const float *bbase = lds + (kc & 1) * (L * 32) + i * 32;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            float4 b[NT];
+            const int slot = ((2 * q + h) ^ sw) * 4;
+#pragma unroll
+            for (int t = 0; t < NT; t++) b[t] = *reinterpret_cast<const float4 *>(bbase + t * 32 * 32 + slot);
+#pragma unroll
+            for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[q].x, b[t].x, acc[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[q].y, b[t].y, acc[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[q].z, b[t].z, acc[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[q].w, b[t].w, acc[t], 0, 0, 0);
+        }
+        __syncthreads();                     // (drains the DMA of the next chunk: issued 8k MFMA cycles ago)
+    }
+
+    // epilogue on the accumulators.  C/D map: column = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5):
+    // for one register the 32 lanes of a half-wave hold 32 consecutive labels of one pixel (128 B per access).
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const int64_t prow = row0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const int64_t pr = min(prow, n - 1);
+        float m = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < NT; t++) {
+            acc[t][r] = -(E0[pr * e_rs + 32 * t + i] + acc[t][r]);
+            m = fmaxf(m, acc[t][r]);
+        }
+        if (LOGITS) {          // CRFasRNN returns -E of the last iteration, not Q (crf_module.py:103)
+            if (prow < n) {
+#pragma unroll
+                for (int t = 0; t < NT; t++) out[prow * o_rs + 32 * t + i] = acc[t][r];
+            }
+            continue;
+        }
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));      // the 32 lanes of this half-wave
+        float s = 0.f;
+#pragma unroll
+        for (int t = 0; t < NT; t++) {
+            acc[t][r] = __builtin_amdgcn_exp2f((acc[t][r] - m) * 1.4426950408889634f);
+            s += acc[t][r];
+        }
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        const float inv = 1.0f / s;
+        if (prow < n) {
+#pragma unroll
+            for (int t = 0; t < NT; t++) out[prow * o_rs + 32 * t + i] = acc[t][r] * inv;
+        }
+    }
+}
+
 inline unsigned rows_grid(int64_t n)
 {
     int64_t b = (n + 3) / 4;
@@ -143,6 +280,32 @@ int phl_softmax_neg_add(const float *E0, int64_t e_rs, const float *G, int64_t g
     else if (v4 && L <= 512) k_softmax_neg_add<2><<<dim3(grid), dim3(256), 0, st>>>(E0, e_rs, G, g_rs, out, o_rs, n, L);
     else if (v4 && L <= 1024) k_softmax_neg_add<4><<<dim3(grid), dim3(256), 0, st>>>(E0, e_rs, G, g_rs, out, o_rs, n, L);
     else k_softmax_neg_add_generic<<<dim3(grid), dim3(256), 0, st>>>(E0, e_rs, G, g_rs, out, o_rs, n, L);
+    PHL_HIP(hipGetLastError());
+    return PHL_OK;
+}
+
+int phl_compat_softmax(const float *E0, int64_t e_rs, const float *X, int64_t x_rs, const float *MuT, float *out, int64_t o_rs,
+                       int64_t n, int L, unsigned flags, phl_stream stream)
+{
+    if (n < 0 || L < 1 || (n > 0 && (!E0 || !X || !MuT || !out))) { phl_set_error("phl_compat_softmax: bad arguments"); return PHL_ERR_INVALID; }
+    if (n == 0) return PHL_OK;
+    if (L % 32 || L > 256 || x_rs % 4 || (reinterpret_cast<uintptr_t>(X) & 15) || (reinterpret_cast<uintptr_t>(MuT) & 15)) {
+        phl_set_error("phl_compat_softmax: needs L %% 32 == 0, L <= 256 and 16-byte aligned X rows (L=%d)", L);
+        return PHL_ERR_UNSUPPORTED;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned grid = (unsigned)((n + 127) / 128);
+    const size_t lds = (size_t)2 * L * 32 * sizeof(float);
+    const bool logits = (flags & PHL_COMPAT_LOGITS) != 0;     // LDS is 2*L*128 B <= 64 KiB: no attribute needed
+#define PHL_CS(NT_)                                                                                                       \
+    case NT_:                                                                                                             \
+        if (logits) k_compat_softmax<NT_, true><<<dim3(grid), dim3(256), lds, st>>>(E0, e_rs, X, x_rs, MuT, out, o_rs, n); \
+        else k_compat_softmax<NT_, false><<<dim3(grid), dim3(256), lds, st>>>(E0, e_rs, X, x_rs, MuT, out, o_rs, n);      \
+        break;
+    switch (L / 32) {
+        PHL_CS(1) PHL_CS(2) PHL_CS(3) PHL_CS(4) PHL_CS(5) PHL_CS(6) PHL_CS(7) PHL_CS(8)
+    }
+#undef PHL_CS
     PHL_HIP(hipGetLastError());
     return PHL_OK;
 }

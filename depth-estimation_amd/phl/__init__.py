@@ -82,6 +82,7 @@ def load_library():
         lib.phl_slice.argtypes = [vp, vp, i32, vp, i64, vp, i64, u32, vp]
         lib.phl_softmax_neg_add.argtypes = [vp, i64, vp, i64, vp, i64, i64, i32, vp]
         lib.phl_expected_value.argtypes = [vp, i64, vp, vp, i64, i32, vp]
+        lib.phl_compat_softmax.argtypes = [vp, i64, vp, i64, vp, vp, i64, i64, i32, u32, vp]
         lib.phl_stream_copy.argtypes = [vp, vp, i64, vp]
         lib.phl_cost_volume.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, vp, i64, vp]
         lib.phl_get_keys.argtypes = [vp, vp]
@@ -329,12 +330,41 @@ def softmax_neg_add(E0, G=None, out=None):
     return out
 
 
-def compat_softmax(E0, X, Mu, out=None):
+_mu_t_cache = {}
+
+
+def _mu_transposed(Mu, device):
+    """Mu^T as a dense fp32 device tensor, cached per (storage, version): Mu is fixed during inference."""
+    key = (Mu.data_ptr(), Mu._version, tuple(Mu.shape), tuple(Mu.stride()), str(device))
+    hit = _mu_t_cache.get(key)
+    if hit is None:
+        if len(_mu_t_cache) > 8:
+            _mu_t_cache.clear()
+        hit = _mu_t_cache[key] = (Mu.detach().to(device, torch.float32).t().contiguous(), Mu)    # keeps Mu alive
+    return hit[0]
+
+
+def compat_softmax(E0, X, Mu, out=None, logits=False):
     """softmax(-(E0 + X @ Mu), dim=1): the whole non-lattice half of a mean-field iteration
-    (crf/crf_module.py:51-52) for fp32 CUDA E0, X [n, L] and Mu [L, L]."""
+    (crf/crf_module.py:51-52) for fp32 CUDA E0, X [n, L] and Mu [L, L], in one fused MFMA kernel
+    (phl_compat_softmax) when L % 32 == 0 and L <= 256; other label counts take a library GEMM followed by the
+    fused add + softmax pass.  logits=True returns -(E0 + X @ Mu) instead (CRFasRNN's output)."""
     if not (_rowmajor(E0) and _rowmajor(X) and X.shape == E0.shape and Mu.shape == (E0.shape[1], E0.shape[1])):
         raise TypeError("compat_softmax: expects fp32 CUDA E0, X [n, L] with unit channel stride and Mu [L, L]")
+    n, L = E0.shape
+    if L % 32 == 0 and L <= 256 and X.stride(0) % 4 == 0 and X.data_ptr() % 16 == 0:
+        if out is None:
+            out = torch.empty((n, L), dtype=torch.float32, device=E0.device)
+        mu_t = _mu_transposed(Mu, E0.device)
+        with torch.cuda.device(E0.device):
+            _check(load_library().phl_compat_softmax(
+                C.c_void_p(E0.data_ptr()), E0.stride(0), C.c_void_p(X.data_ptr()), X.stride(0), C.c_void_p(mu_t.data_ptr()),
+                C.c_void_p(out.data_ptr()), out.stride(0), n, L, 1 if logits else 0, _stream(E0.device)))
+        return out
     G = X @ Mu.to(E0.device, torch.float32)
+    if logits:
+        res = -(E0 + G)
+        return res if out is None else out.copy_(res)
     return softmax_neg_add(E0, G, out=out)
 
 
@@ -399,32 +429,90 @@ _cache_lock = threading.Lock()
 _REFERENCE_TABLE = os.environ.get("PHL_REFERENCE_TABLE", "0") not in ("", "0")
 
 
-def _cache_key(ref):
-    return (ref.device.type, ref.device.index, ref.data_ptr(), tuple(ref.shape), tuple(ref.stride()), ref._version)
+def _cache_key(ref, device=None):
+    dev = None if device is None else (torch.device(device).type, torch.device(device).index)
+    return (ref.device.type, ref.device.index, ref.data_ptr(), tuple(ref.shape), tuple(ref.stride()), ref._version, dev)
 
 
-def lattice_for(ref):
-    """Cached Lattice for ``ref``.  The entry keeps ``ref`` alive, so its storage address cannot be
-    recycled while cached; an in-place update bumps ``ref._version`` and misses."""
+def lattice_for(ref, device=None):
+    """Cached Lattice for ``ref`` (built on ``device``; default: ref's own device, or the current one for a CPU
+    tensor).  The entry keeps ``ref`` alive, so its storage address cannot be recycled while cached; an in-place
+    update bumps ``ref._version`` and misses."""
     if _CACHE_SIZE <= 0:
-        return Lattice(ref, reference_table=_REFERENCE_TABLE)
-    key = _cache_key(ref)
+        return Lattice(ref, device=device, reference_table=_REFERENCE_TABLE)
+    key = _cache_key(ref, device)
     with _cache_lock:
         hit = _cache.get(key)
         if hit is not None:
             _cache.move_to_end(key)
             return hit[0]
-    lat = Lattice(ref, reference_table=_REFERENCE_TABLE)
+    lat = Lattice(ref, device=device, reference_table=_REFERENCE_TABLE)
     with _cache_lock:
         _cache[key] = (lat, ref)
-        while len(_cache) > _CACHE_SIZE:
+        while len(_cache) > max(_CACHE_SIZE, _cache_floor[0]):
             _cache.popitem(last=False)
     return lat
+
+
+_cache_floor = [0]      # batched_filter keeps one lattice per batch item alive across mean-field iterations
 
 
 def clear_cache():
     with _cache_lock:
         _cache.clear()
+
+
+def batch_devices(t=None):
+    """Devices a batch of independent volumes is spread over (first row: "one image per GPU, no
+    RCCL; host-side scatter of inputs / gather of outputs only").  CPU inputs -- the reference's calling
+    convention, whose batch mode runs one worker process per image (crf/gaussian_matrix.py:370-377) -- go to all
+    visible GPUs; tensors that already live on a GPU stay there (moving an [n, L] volume over xGMI costs more
+    than filtering it) unless PHL_BATCH_DEVICES says otherwise ("all" or a comma list of indices)."""
+    _require_gpu()
+    env = os.environ.get("PHL_BATCH_DEVICES", "")
+    ndev = torch.cuda.device_count()
+    if env == "all":
+        return [torch.device("cuda", i) for i in range(ndev)]
+    if env:
+        return [torch.device("cuda", int(i)) for i in env.split(",")]
+    if t is not None and t.is_cuda:
+        return [t.device]
+    return [torch.device("cuda", i) for i in range(ndev)]
+
+
+_batch_streams = {}
+
+
+def batched_filter(srcs, refs, devices=None, subtract_input=False):
+    """Independent lattice per batch item: srcs [bs, n, vd], refs [bs, n, d] (any strides) -> [bs, n, vd] on
+    srcs' device.  Item i runs on devices[i % len(devices)], each device on its own side stream, so that with
+    several GPUs the items (and, for CPU inputs, their PCIe copies) proceed in parallel; no collective."""
+    bs = srcs.shape[0]
+    assert refs.shape[0] == bs and srcs.shape[1] == refs.shape[1], "Incompatible shapes {}, and {}".format(tuple(srcs.shape), tuple(refs.shape))
+    devices = [torch.device(d) for d in (devices or batch_devices(srcs))]
+    _cache_floor[0] = max(_cache_floor[0], min(bs, 64))
+    home = srcs.device
+    out = torch.empty((bs,) + tuple(srcs.shape[1:]), dtype=torch.float32, device=home)
+    used = []
+    for i in range(bs):
+        dev = devices[i % len(devices)]
+        st = _batch_streams.get(dev)
+        if st is None:
+            st = _batch_streams[dev] = torch.cuda.Stream(device=dev)
+        if home.type == "cuda":
+            st.wait_stream(torch.cuda.current_stream(home))      # inputs may still be in flight on the caller's stream
+        with torch.cuda.device(dev), torch.cuda.stream(st):
+            lat = lattice_for(refs[i].detach(), device=dev)
+            s = srcs[i].detach()
+            res = lat.filter(s.to(dev, non_blocking=True) if s.device != dev else s, subtract_input=subtract_input)
+            out[i].copy_(res, non_blocking=True)
+        used.append((dev, st))
+    for dev, st in used:
+        if home.type == "cuda":
+            torch.cuda.current_stream(home).wait_stream(st)
+        else:
+            st.synchronize()
+    return out
 
 
 def filter(src, ref):

@@ -187,6 +187,19 @@ int phl_slice(phl_lattice *lat, const float *vert_dev, int vd, float *out_dev, i
  * into one pass.  Rows are pixel-major with unit channel stride; row strides in elements. */
 int phl_softmax_neg_add(const float *E0_dev, int64_t e0_row_stride, const float *G_dev, int64_t g_row_stride,
                         float *out_dev, int64_t out_row_stride, int64_t n, int L, phl_stream stream);
+/* out[p,:] = softmax(-(E0[p,:] + X[p,:] @ Mu)): the whole non-lattice half of a mean-field iteration
+ * (`E = E_0 + (W@Q)@Mu; Q = softmax(-E)`, crf/crf_module.py:51-52, with X = W@Q) in ONE kernel -- the
+ * compatibility product on the fp32-input matrix cores (exact f32, as the reference computes), +E0 and the row
+ * softmax applied to the accumulators, so G and E never exist in memory.
+ * mu_t_dev is Mu TRANSPOSED, [L][L] dense: mu_t[c*L + k] = Mu[k][c] (Charbonnier / Potts compatibilities are
+ * symmetric: their own transpose).  Needs L % 32 == 0, L <= 256, x_row_stride % 4 == 0 and 16-byte aligned X / mu_t
+ * (else PHL_ERR_UNSUPPORTED: the caller keeps its GEMM + phl_softmax_neg_add).  Rows have unit channel stride.
+ * flags: PHL_COMPAT_LOGITS writes -(E0 + X @ Mu) instead of its softmax (CRFasRNN returns the logits of the last
+ * iteration, crf_module.py:103). */
+enum phl_compat_flags { PHL_COMPAT_SOFTMAX = 0, PHL_COMPAT_LOGITS = 1 };
+int phl_compat_softmax(const float *E0_dev, int64_t e0_row_stride, const float *X_dev, int64_t x_row_stride,
+                       const float *mu_t_dev, float *out_dev, int64_t out_row_stride, int64_t n, int L, unsigned flags,
+                       phl_stream stream);
 /* out[p] = sum_c Q[p,c]*labels[c] : the expected disparity `mf @ labels`
  * (Experiments/DenseCrf.ipynb cell 11). */
 int phl_expected_value(const float *Q_dev, int64_t q_row_stride, const float *labels_dev, float *out_dev,

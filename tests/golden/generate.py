@@ -134,8 +134,11 @@ def import_reference_python():
 
     placeholder = types.ModuleType("guided_filter_pytorch")
     sub = types.ModuleType("guided_filter_pytorch.guided_filter")
-    sub.GuidedFilter = type("GuidedFilter", (torch.nn.Module,), {})
-    sub.BoxFilter = type("BoxFilter", (torch.nn.Module,), {})
+    # constructible (CRFasRNN.__init__ builds its default guided-filter W before the lattice W is substituted),
+    # never called
+    init = lambda self, *a, **k: torch.nn.Module.__init__(self)  # noqa: E731
+    sub.GuidedFilter = type("GuidedFilter", (torch.nn.Module,), {"__init__": init})
+    sub.BoxFilter = type("BoxFilter", (torch.nn.Module,), {"__init__": init})
     placeholder.guided_filter = sub
     sys.modules["guided_filter_pytorch"] = placeholder
     sys.modules["guided_filter_pytorch.guided_filter"] = sub
@@ -258,6 +261,61 @@ def python_layer_cases(report):
     report.append(dict(case="laplacians", n=n, d=d, k=k))
 
 
+def mean_field_wide_cases(report):
+    """Vectors for the fused compatibility + softmax kernel (L a multiple of 32) and for the NCHW CRFasRNN path,
+    both from the reference's own Python (crf/crf_module.py) over the reference engine."""
+    import torch
+
+    torch.manual_seed(1)
+    # the reference's BatchedAdjacency fork()s a process pool (gaussian_matrix.py:370-377): OpenMP worker threads
+    # started by an earlier matmul would leave the forked children waiting forever
+    torch.set_num_threads(1)
+    crf_module, gm = import_reference_python()
+    imL = read_image(os.path.join(REFERENCE, "Experiments", "imL.png"))
+    imR = read_image(os.path.join(REFERENCE, "Experiments", "imR.png"))
+
+    # ---- flat mean field, L = 32 (crf_module.py:41-53) ------------------------------------------
+    L, sigma_c, sigma_p, gamma = 32, 0.1, 0.1, 3
+    full = disparity_badness(imL, imR, L)
+    r0, c0, h, w = 120, 180, 40, 56
+    E0 = torch.from_numpy(full[r0:r0 + h, c0:c0 + w].reshape(-1, L)).float()
+    H, W_ = imL.shape[:2]
+    position = np.mgrid[:H, :W_].transpose((1, 2, 0)) / np.sqrt(H ** 2 + W_ ** 2)
+    refimg = np.zeros((h, w, 5))
+    refimg[..., :3] = imL[r0:r0 + h, c0:c0 + w] / sigma_c
+    refimg[..., 3:] = position[r0:r0 + h, c0:c0 + w] / sigma_p
+    flat_ref = torch.from_numpy(refimg.reshape(h * w, -1).astype(np.float32))
+    labels = torch.arange(L).float()
+    Mu = crf_module.compatibility_matrix(lambda a, b: crf_module.charbonneir(a, b, gamma), labels)
+    Wop = gm.LatticeGaussian(flat_ref)
+    with torch.no_grad():
+        Q1 = crf_module.mean_field_infer(E0, Wop, Mu, 1)
+        Q5 = crf_module.mean_field_infer(E0, Wop, Mu, 5)
+    np.savez_compressed(os.path.join(HERE, "meanfield_tsukuba_L32.npz"), E0=E0.numpy(), ref=flat_ref.numpy(),
+                        labels=labels.numpy(), Mu=Mu.numpy(), gamma=np.float32(gamma), Q1=Q1.numpy(), Q5=Q5.numpy(),
+                        disp1=(Q1 @ labels).numpy(), disp5=(Q5 @ labels).numpy(), h=np.int64(h), w=np.int64(w))
+    report.append(dict(case="meanfield_tsukuba_L32", n=h * w, L=L, d=5))
+
+    # ---- CRFasRNN, NCHW, lattice W (crf_module.py:66-104 with BatchedAdjacency as self.W) -------
+    g_ = torch.Generator().manual_seed(321)
+    bs, L2, hh, ww = 2, 32, 20, 24
+    img = torch.from_numpy(np.stack([imL[60:60 + hh, 100:100 + ww], imL[150:150 + hh, 220:220 + ww]]).transpose(0, 3, 1, 2)).float()
+    logits = torch.randn(bs, L2, hh, ww, generator=g_) * 2.0
+    lab = torch.arange(L2).float()
+    net = crf_module.CRFasRNN(crf_module.charb(3.0), niters=3)
+    net.W = gm.BatchedAdjacency(num_threads=2)          # the lattice alternative the reference imports (:5) but does not wire in
+    guide = crf_module.ijrgbGuide(trainable=False)
+    with torch.no_grad():
+        refs = guide(img)
+        out = net(refs, logits, labels=lab)
+        conf = torch.rand(bs, 1, hh, ww, generator=g_) + 0.5
+        out_conf = net(refs, logits, confidence=conf, labels=lab)
+    np.savez_compressed(os.path.join(HERE, "crfasrnn_nchw.npz"), img=img.numpy(), logits=logits.numpy(), refs=refs.numpy(),
+                        labels=lab.numpy(), gamma=np.float32(3.0), niters=np.int64(3), out=out.numpy(),
+                        confidence=conf.numpy(), out_conf=out_conf.numpy())
+    report.append(dict(case="crfasrnn_nchw", shape=list(logits.shape), niters=3))
+
+
 def import_reference_depth():
     import importlib.util
 
@@ -317,6 +375,14 @@ def main():
             json.dump(report, f, indent=1)
         print("wrote", sorted(x for x in os.listdir(HERE) if x.startswith("costvol_")))
         return
+    if sys.argv[1:] == ["meanfield2"]:
+        assert po.build_reference(), "reference engine not built"
+        report = json.load(open(os.path.join(HERE, "PIN_REPORT.json")))
+        report = [r for r in report if r.get("case") not in ("meanfield_tsukuba_L32", "crfasrnn_nchw")]
+        mean_field_wide_cases(report)
+        with open(os.path.join(HERE, "PIN_REPORT.json"), "w") as f:
+            json.dump(report, f, indent=1)
+        return
     if sys.argv[1:] == ["growth"]:           # add / refresh the stored table-growth cases only
         po.build_oracle(force=True)
         assert po.build_reference(), "reference engine not built"
@@ -337,6 +403,7 @@ def main():
         lattice_case(*args, report=report)
     growth_cases(report)
     python_layer_cases(report)
+    mean_field_wide_cases(report)
     cost_volume_cases(report)
     with open(os.path.join(HERE, "PIN_REPORT.json"), "w") as f:
         json.dump(report, f, indent=1)

@@ -172,3 +172,124 @@ def test_notebook_flow_end_to_end_on_a_synthetic_pair():
     spec.loader.exec_module(mod)
     err_wta, err_crf = mod.run(h=120, w=240, iters=5, quiet=True)
     assert err_crf < err_wta and err_crf < 0.5, (err_wta, err_crf)
+
+
+def test_batched_filter_spreads_items_over_devices():
+    """SURVEY 8(e) row 1 / BASELINE configs[4]: independent volumes, one lattice each, dealt over the visible
+    GPUs with no collective (the reference: one worker process per image, gaussian_matrix.py:370-377).  On a
+    one-GPU box the device list is given twice, which still takes the per-device side streams; results must
+    equal the item-by-item filter, for GPU-resident and for CPU (reference calling convention) inputs."""
+    import phl
+
+    g = torch.Generator().manual_seed(5)
+    bs, n, L, d = 5, 3000, 12, 5
+    srcs = torch.rand((bs, n, L), generator=g)
+    refs = torch.rand((bs, n, d), generator=g) * 3
+    want = torch.stack([phl.Lattice(refs[i].cuda()).filter(srcs[i].cuda()) for i in range(bs)])
+    devs = phl.batch_devices(srcs)
+    assert len(devs) == torch.cuda.device_count() and phl.batch_devices(srcs.cuda()) == [torch.device("cuda", 0)]
+    got_cpu = phl.batched_filter(srcs, refs)                                  # CPU in -> CPU out, all GPUs
+    assert not got_cpu.is_cuda and torch.equal(got_cpu, want.cpu())
+    two = [torch.device("cuda", 0)] * 2 if torch.cuda.device_count() == 1 else None
+    got = phl.batched_filter(srcs.cuda(), refs.cuda(), devices=two)
+    assert got.is_cuda and torch.equal(got, want)
+    # channel-major views, as BatchedAdjacency passes them
+    nchw = srcs.cuda().permute(0, 2, 1).contiguous().permute(0, 2, 1)
+    assert torch.equal(phl.batched_filter(nchw, refs.cuda(), devices=two), want)
+    # second call: lattices come from the cache (one per item kept alive)
+    assert torch.equal(phl.batched_filter(srcs.cuda(), refs.cuda(), devices=two), want)
+
+
+@pytest.mark.parametrize("n,L", [(4097, 256), (128, 32), (1000, 64), (333, 96), (5000, 160), (129, 224), (1, 32)])
+def test_fused_compat_softmax_kernel(n, L):
+    """phl_compat_softmax: softmax(-(E0 + X @ Mu)) on the fp32-input matrix cores with the softmax as epilogue,
+    against an fp64 reference and torch's fp32 GEMM + softmax.  Mu is deliberately ASYMMETRIC (the kernel takes
+    Mu transposed: a swapped operand would pass a symmetric one), n is ragged against the 128-row tiles, X and
+    E0 are row-padded views."""
+    import phl
+
+    g = torch.Generator(device="cuda").manual_seed(7 * n + L)
+    E0 = torch.rand((n, L), device="cuda", generator=g) * 20
+    Xp = torch.zeros((n, L + 8), device="cuda")
+    Xp[:, :L] = torch.rand((n, L), device="cuda", generator=g) - 0.3
+    X = Xp[:, :L]
+    Mu = torch.rand((L, L), device="cuda", generator=g) * 4 + torch.arange(L, device="cuda")[:, None] * 0.05
+    assert not torch.allclose(Mu, Mu.t())
+    G64 = X.double() @ Mu.double()
+    want = torch.softmax(-(E0.double() + G64), dim=1)
+    got = phl.compat_softmax(E0, X, Mu)
+    ref32 = torch.softmax(-(E0 + X @ Mu), dim=1)
+    e_fused = float((got.double() - want).abs().max())
+    e_torch = float((ref32.double() - want).abs().max())
+    print(f"[measured] compat_softmax n={n} L={L}: max abs err vs fp64 {e_fused:.2e} (torch fp32 GEMM+softmax: {e_torch:.2e})")
+    assert e_fused <= max(2e-6, 2 * e_torch)                 # exact-f32 MFMA: no worse than the fp32 library path
+    assert float((got.sum(1) - 1).abs().max()) <= 1e-5
+    # logits mode: -(E0 + X @ Mu)
+    lg = phl.compat_softmax(E0, X, Mu, logits=True)
+    assert float((lg.double() + (E0.double() + G64)).abs().max()) <= 1e-4 * float((E0.double() + G64).abs().max())
+    # in place over a buffer that is not X
+    out = torch.empty_like(E0)
+    assert phl.compat_softmax(E0, X, Mu, out=out) is out and torch.equal(out, got)
+
+
+def test_compat_softmax_falls_back_for_other_label_counts():
+    import phl
+
+    g = torch.Generator(device="cuda").manual_seed(3)
+    for L in (16, 48 + 2, 288):
+        E0 = torch.rand((500, L), device="cuda", generator=g) * 10
+        X = torch.rand((500, L), device="cuda", generator=g)
+        Mu = torch.rand((L, L), device="cuda", generator=g)
+        want = torch.softmax(-(E0.double() + X.double() @ Mu.double()), dim=1)
+        assert float((phl.compat_softmax(E0, X, Mu).double() - want).abs().max()) <= 5e-6
+
+
+def test_mean_field_L32_golden(golden_dir):
+    """Reference-generated vectors (crf_module.py:41-53 over the reference engine) at L = 32: the label count
+    takes the fused MFMA kernel inside mean_field_infer."""
+    from crf.crf_module import charbonneir, compatibility_matrix, mean_field_infer
+    from crf.gaussian_matrix import LatticeGaussian
+
+    g = np.load(os.path.join(golden_dir, "meanfield_tsukuba_L32.npz"))
+    dev = torch.device("cuda")
+    E0 = torch.from_numpy(g["E0"]).to(dev)
+    ref = torch.from_numpy(g["ref"]).to(dev)
+    labels = torch.from_numpy(g["labels"]).to(dev)
+    Mu = compatibility_matrix(lambda a, b: charbonneir(a, b, float(g["gamma"])), labels)
+    W = LatticeGaussian(ref)
+    for it, key in ((1, "1"), (5, "5")):
+        Q = mean_field_infer(E0, W, Mu, it)
+        eq = rel(Q.cpu().numpy(), g["Q" + key])
+        disp = (Q @ labels).cpu().numpy()
+        ed = float((np.abs(disp - g["disp" + key]) / np.maximum(np.abs(g["disp" + key]), 1e-2)).max())
+        print(f"[measured] mean field L=32, {it} iteration(s): Q rel {eq:.2e}, disparity rel per pixel {ed:.2e}")
+        assert eq <= 5e-4 and ed <= 1e-4
+
+
+def test_crf_as_rnn_nchw_golden(golden_dir):
+    """CRFasRNN + charb over NCHW tensors with the lattice W (crf_module.py:66-104 with BatchedAdjacency as self.W),
+    expected logits from the reference's own classes.  The no-grad path runs fused (pixel-major inside, one filter
+    + one compat/softmax kernel per iteration); the autograd path runs the plain modules; both must match."""
+    from crf.crf_module import CRFasRNN, charb
+
+    g = np.load(os.path.join(golden_dir, "crfasrnn_nchw.npz"))
+    dev = torch.device("cuda")
+    refs, logits, lab = (torch.from_numpy(g[k]).to(dev) for k in ("refs", "logits", "labels"))
+    net = CRFasRNN(charb(float(g["gamma"])), niters=int(g["niters"]), lattice=True).to(dev)
+    with torch.no_grad():
+        out = net(refs, logits, labels=lab)
+        outc = net(refs, logits, confidence=torch.from_numpy(g["confidence"]).to(dev), labels=lab)
+    scale = np.abs(g["out"]).max()
+    e1 = float(np.abs(out.cpu().numpy() - g["out"]).max() / scale)
+    e2 = float(np.abs(outc.cpu().numpy() - g["out_conf"]).max() / np.abs(g["out_conf"]).max())
+    lg = logits.clone().requires_grad_(True)
+    out_ag = net(refs, lg, labels=lab)                       # autograd path: BatchedAdjacency / conv modules
+    e3 = float(np.abs(out_ag.detach().cpu().numpy() - g["out"]).max() / scale)
+    print(f"[measured] CRFasRNN NCHW: fused {e1:.2e}, with confidence {e2:.2e}, autograd path {e3:.2e} (of the largest logit)")
+    assert e1 <= 1e-5 and e2 <= 1e-5 and e3 <= 1e-5
+    out_ag.sum().backward()
+    assert torch.isfinite(lg.grad).all()
+    # the ijrgbGuide mirror builds the same guide features the reference built
+    from crf.crf_module import ijrgbGuide
+    mine = ijrgbGuide(trainable=False)(torch.from_numpy(g["img"]).to(dev))
+    assert float((mine - refs).abs().max()) <= 1e-6 * float(refs.abs().max())
