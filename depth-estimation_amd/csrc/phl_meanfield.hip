@@ -164,11 +164,17 @@ __global__ __launch_bounds__(256, 2) void k_compat_softmax(const float *__restri
     const int64_t arow = min(row0 + i, n - 1);          // clamped: loads stay in bounds, stores are predicated
     const float *xrow = X + arow * x_rs + 4 * h;
 
+    // The accumulators START as the E0 tile (the MFMA's C input), so E = E0 + X @ Mu comes out of the matrix
+    // pipe itself and the epilogue has no loads left to wait for.  C/D map: column = lane&31,
+    // row = (reg&3) + 8*(reg>>2) + 4*(lane>>5): for one register the 32 lanes of a half-wave hold 32
+    // consecutive labels of one pixel (128 B per access).
     f32x16 acc[NT];
 #pragma unroll
-    for (int t = 0; t < NT; t++)
+    for (int r = 0; r < 16; r++) {
+        const int64_t pr = min(row0 + (r & 3) + 8 * (r >> 2) + 4 * h, n - 1);
 #pragma unroll
-        for (int r = 0; r < 16; r++) acc[t][r] = 0.f;
+        for (int t = 0; t < NT; t++) acc[t][r] = E0[pr * e_rs + 32 * t + i];
+    }
 
     // Chunk loader (LDS-DMA, no staging registers): a chunk is L labels x 8 slots of 16 B; one wave-instruction
     // fills 64 consecutive slots = 8 labels.  LDS stays linear (that is all the DMA can write); the bank
@@ -200,6 +206,9 @@ __global__ __launch_bounds__(256, 2) void k_compat_softmax(const float *__restri
 #pragma unroll
             for (int q = 0; q < 4; q++) a_nxt[q] = *reinterpret_cast<const float4 *>(xrow + 32 * (kc + 1) + 8 * q);
         }
+        // keep the prefetch HERE: left alone, the scheduler sinks these loads to the end of the chunk (their
+        // results are not needed before the next one) and the wave then waits out a full HBM miss per chunk
+        __builtin_amdgcn_sched_barrier(0);
         const float *bbase = lds + (kc & 1) * (L * 32) + i * 32;
 #pragma unroll
         for (int q = 0; q < 4; q++) {
@@ -219,36 +228,50 @@ __global__ __launch_bounds__(256, 2) void k_compat_softmax(const float *__restri
         __syncthreads();                     // (drains the DMA of the next chunk: issued 8k MFMA cycles ago)
     }
 
-    // epilogue on the accumulators.  C/D map: column = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5):
-    // for one register the 32 lanes of a half-wave hold 32 consecutive labels of one pixel (128 B per access).
+    // epilogue on the accumulators (acc = E now).  The 16 pixel rows a lane holds are reduced TOGETHER: sixteen
+    // independent butterfly chains per step, so the cross-lane latency is paid once per step, not per row.
+    if (LOGITS) {              // CRFasRNN returns -E of the last iteration, not Q (crf_module.py:103)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int64_t prow = row0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (prow < n) {
+#pragma unroll
+                for (int t = 0; t < NT; t++) out[prow * o_rs + 32 * t + i] = -acc[t][r];
+            }
+        }
+        return;
+    }
+    float m[16], sum[16];
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        m[r] = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < NT; t++) {
+            acc[t][r] = -acc[t][r];
+            m[r] = fmaxf(m[r], acc[t][r]);
+        }
+    }
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1)                     // the 32 lanes of this half-wave
+#pragma unroll
+        for (int r = 0; r < 16; r++) m[r] = fmaxf(m[r], __shfl_xor(m[r], o));
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        sum[r] = 0.f;
+#pragma unroll
+        for (int t = 0; t < NT; t++) {
+            acc[t][r] = __builtin_amdgcn_exp2f((acc[t][r] - m[r]) * 1.4426950408889634f);
+            sum[r] += acc[t][r];
+        }
+    }
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1)
+#pragma unroll
+        for (int r = 0; r < 16; r++) sum[r] += __shfl_xor(sum[r], o);
 #pragma unroll
     for (int r = 0; r < 16; r++) {
         const int64_t prow = row0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        const int64_t pr = min(prow, n - 1);
-        float m = -INFINITY;
-#pragma unroll
-        for (int t = 0; t < NT; t++) {
-            acc[t][r] = -(E0[pr * e_rs + 32 * t + i] + acc[t][r]);
-            m = fmaxf(m, acc[t][r]);
-        }
-        if (LOGITS) {          // CRFasRNN returns -E of the last iteration, not Q (crf_module.py:103)
-            if (prow < n) {
-#pragma unroll
-                for (int t = 0; t < NT; t++) out[prow * o_rs + 32 * t + i] = acc[t][r];
-            }
-            continue;
-        }
-#pragma unroll
-        for (int o = 16; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));      // the 32 lanes of this half-wave
-        float s = 0.f;
-#pragma unroll
-        for (int t = 0; t < NT; t++) {
-            acc[t][r] = __builtin_amdgcn_exp2f((acc[t][r] - m) * 1.4426950408889634f);
-            s += acc[t][r];
-        }
-#pragma unroll
-        for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o);
-        const float inv = 1.0f / s;
+        const float inv = 1.0f / sum[r];
         if (prow < n) {
 #pragma unroll
             for (int t = 0; t < NT; t++) out[prow * o_rs + 32 * t + i] = acc[t][r] * inv;

@@ -241,7 +241,8 @@ def test_compat_softmax_falls_back_for_other_label_counts():
         X = torch.rand((500, L), device="cuda", generator=g)
         Mu = torch.rand((L, L), device="cuda", generator=g)
         want = torch.softmax(-(E0.double() + X.double() @ Mu.double()), dim=1)
-        assert float((phl.compat_softmax(E0, X, Mu).double() - want).abs().max()) <= 5e-6
+        e_torch = float((torch.softmax(-(E0 + X @ Mu), dim=1).double() - want).abs().max())
+        assert float((phl.compat_softmax(E0, X, Mu).double() - want).abs().max()) <= max(2e-6, 2 * e_torch)
 
 
 def test_mean_field_L32_golden(golden_dir):
