@@ -97,6 +97,20 @@ int main()
         hipEventElapsedTime(&ms, a, b);
         printf("write only  blocks=%6d : %7.1f GB/s\n", blocks, 1.0 * n4 * 16 * 5 / (ms * 1e-3) / 1e9);
     }
+    // size sweep of the best form: is a higher published copy rate (MI355X_MICROARCH.md quotes 6.29 TB/s) a
+    // matter of footprint (buffers that fit the 256 MiB Infinity Cache) rather than of the access form?
+    for (long mb : {32L, 64L, 128L, 256L, 512L, 1024L, 3072L}) {
+        const long m4 = mb * 1024 * 1024 / 16;
+        const int blocks = (int)((m4 + 1023) / 1024 < 65536 ? (m4 + 1023) / 1024 : 65536);
+        float ms;
+        k_copy<3, 4><<<blocks, 256>>>(s, d, m4);
+        hipDeviceSynchronize();
+        hipEventRecord(a);
+        for (int r = 0; r < 20; r++) k_copy<3, 4><<<blocks, 256>>>(s, d, m4);
+        hipEventRecord(b); hipEventSynchronize(b);
+        hipEventElapsedTime(&ms, a, b);
+        printf("copy of %5ld MiB (nt, %d blocks): %7.1f GB/s (R+W)\n", mb, blocks, 2.0 * m4 * 16 * 20 / (ms * 1e-3) / 1e9);
+    }
     hipEventRecord(a);
     for (int r = 0; r < 5; r++) hipMemcpyAsync(d, s, n4 * 16, hipMemcpyDeviceToDevice, 0);
     hipEventRecord(b); hipEventSynchronize(b);
