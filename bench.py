@@ -400,7 +400,8 @@ def main():
 
         job = rowtile.RowTileFilter(feat, L, rank, world, device, dist)
         src = synthetic_values(torch, job.own_rows, W, L, job.row0, device)
-        step = lambda: job.filter(src)
+        out_rt = torch.empty_like(src)
+        step = lambda: job.filter(src, out=out_rt)
         build_ms, M, n_local = job.build_ms, job.M, job.n_local
         extra = job.describe()
     else:

@@ -199,11 +199,12 @@ class Lattice:
         return res if src.device == self.device else res.to(src.device)
 
     # ---- stages (profiling / parity of intermediates) ---------------------------------------
-    def splat(self, src, exact=False, no_tiles=False):
+    def splat(self, src, exact=False, no_tiles=False, out=None):
         src_d = _as_device(src.detach(), self.device)
         assert src_d.stride(1) == 1, "stage API takes pixel-major rows"
         vd = int(src_d.shape[1])
-        vert = torch.empty((self.M, vd), dtype=torch.float32, device=self.device)
+        vert = torch.empty((self.M, vd), dtype=torch.float32, device=self.device) if out is None else out
+        assert vert.shape == (self.M, vd) and vert.is_contiguous()
         with torch.cuda.device(self.device):
             _check(load_library().phl_splat(self._h, C.c_void_p(src_d.data_ptr()), vd, src_d.stride(0),
                                             C.c_void_p(vert.data_ptr()),

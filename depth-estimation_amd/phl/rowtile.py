@@ -169,21 +169,27 @@ class RowBand:
         self._send_keys = None
 
     # -- filter phases --------------------------------------------------------------------------
-    def splat_outbox(self, src):
-        """src [n_local, C] (any channel subset, unit column stride) -> (vertex sums, {peer: rows to send})"""
-        vert = self.eng.splat(src)
-        if self.sides and hasattr(self.eng, "gather_rows"):
-            buf = self.eng.gather_rows(vert, self._send_all)        # one launch for both neighbours
+    def splat_outbox(self, src, vert=None, sendbuf=None):
+        """src [n_local, C] (any channel subset, unit column stride) -> (vertex sums, {peer: rows to send}).
+        vert / sendbuf: optional preallocated [M, C] / [rows to send, C] buffers (engines with the phl.Lattice
+        stage surface write into them, so a steady-state call allocates nothing)."""
+        fused = hasattr(self.eng, "gather_rows")
+        vert = self.eng.splat(src, out=vert) if (vert is not None and fused) else self.eng.splat(src)
+        if self.sides and fused:
+            buf = self.eng.gather_rows(vert, self._send_all, out=sendbuf)        # one launch for both neighbours
             return vert, {p: buf[a:b] for p, (a, b) in self._send_rng.items()}
         return vert, {peer: vert.index_select(0, s["send_idx"]) for peer, s in self.sides.items()}
+
+    def send_rows(self):
+        return int(self._send_all.numel()) if self.sides else 0
 
     def recv_range(self, peer):
         """Row range of `peer`'s rows inside a packed receive buffer (peers in ascending order)."""
         return self._recv_rng[peer]
 
-    def finish(self, vert, inbox, out=None, packed=None):
+    def finish(self, vert, inbox, out=None, packed=None, scratch=None):
         """inbox: {peer: rows}; packed: the same rows as ONE [sum of rows, C] tensor in ascending peer order
-        (lets the engine add them in a single launch)."""
+        (lets the engine add them in a single launch); scratch: optional second [M, C] buffer for the blur."""
         fused = hasattr(self.eng, "scatter_add_rows")
         if fused and packed is not None and self.sides and self._map_disjoint:
             self.eng.scatter_add_rows(vert, self._map_all, packed)
@@ -193,7 +199,7 @@ class RowBand:
                     self.eng.scatter_add_rows(vert, self.sides[peer]["map_idx"], inbox[peer])
                 else:
                     vert.index_add_(0, self.sides[peer]["map_idx"], inbox[peer])
-        vert = self.eng.blur(vert)
+        vert = self.eng.blur(vert) if scratch is None else self.eng.blur(vert, scratch)
         return self.eng.slice(vert) if out is None else self.eng.slice(vert, out=out)
 
     @property
@@ -235,6 +241,26 @@ class RowTileFilter:
         total = sum(self.band.recv_rows(p) for p in self.band.sides)
         self._rpack = [torch.empty((total, c1 - c0), dtype=torch.float32, device=self.comm_device) for c0, c1 in self.groups]
         self._rbuf = [{p: pack[slice(*self.band.recv_range(p))] for p in self.band.sides} for pack in self._rpack]
+        # Steady state allocates nothing and rebuilds nothing: vertex buffers, blur scratch, send buffers and the
+        # point-to-point op lists of every channel group exist once (the host side of a 0.35 ms band step must
+        # not be on the critical path).
+        self._fused = hasattr(self.band.eng, "gather_rows") and self.comm_device == self.band.device
+        self._vert = self._scratch = self._sbuf = self._ops = None
+        if self._fused:
+            M = self.band.M
+            self._vert = [torch.empty((M, c1 - c0), dtype=torch.float32, device=device) for c0, c1 in self.groups]
+            self._scratch = [torch.empty((M, c1 - c0), dtype=torch.float32, device=device) for c0, c1 in self.groups[:1]]
+            self._scratch += [self._scratch[0] if (c1 - c0) == self._scratch[0].shape[1] else
+                              torch.empty((M, c1 - c0), dtype=torch.float32, device=device) for c0, c1 in self.groups[1:]]
+            self._sbuf = [torch.empty((self.band.send_rows(), c1 - c0), dtype=torch.float32, device=device) for c0, c1 in self.groups]
+            self._ops = []
+            for gi in range(len(self.groups)):
+                ops = []
+                for peer in sorted(self.band.sides):
+                    a, b = self.band._send_rng[peer]
+                    ops.append(dist.P2POp(dist.isend, self._sbuf[gi][a:b], peer))
+                    ops.append(dist.P2POp(dist.irecv, self._rbuf[gi][peer], peer))
+                self._ops.append(ops)
         if hasattr(self.band.eng, "reserve"):
             self.band.eng.reserve(max(c1 - c0 for c0, c1 in self.groups))
 
@@ -261,10 +287,13 @@ class RowTileFilter:
                 req.wait()
         return recv
 
-    def filter(self, src):
-        """src: this rank's rows, [own_rows*W, L] on the engine device -> same shape."""
+    def filter(self, src, out=None):
+        """src: this rank's rows, [own_rows*W, L] on the engine device -> same shape (written to ``out`` if given)."""
         dist = self.dist
-        out = torch.empty((self.band.n_local, self.L), dtype=torch.float32, device=self.band.device)
+        if out is None:
+            out = torch.empty((self.band.n_local, self.L), dtype=torch.float32, device=self.band.device)
+        if self._fused:
+            return self._filter_fused(src, out)
         pending = []
         for gi, (c0, c1) in enumerate(self.groups):
             vert, outbox = self.band.splat_outbox(src[:, c0:c1])
@@ -283,6 +312,19 @@ class RowTileFilter:
             pack = self._rpack[gi] if self._rpack[gi].device == self.band.device else self._rpack[gi].to(self.band.device)
             inbox = {p: pack[slice(*self.band.recv_range(p))] for p in self.band.sides}
             self.band.finish(vert, inbox, out=out[:, c0:c1], packed=pack)
+        return out
+
+    def _filter_fused(self, src, out):
+        """Same schedule on preallocated buffers and persistent op lists (RCCL: payloads stay in HBM)."""
+        dist, band = self.dist, self.band
+        reqs = []
+        for gi, (c0, c1) in enumerate(self.groups):
+            band.splat_outbox(src[:, c0:c1], vert=self._vert[gi], sendbuf=self._sbuf[gi])
+            reqs.append(dist.batch_isend_irecv(self._ops[gi]) if self._ops[gi] else [])
+        for gi, (c0, c1) in enumerate(self.groups):
+            for req in reqs[gi]:
+                req.wait()
+            band.finish(self._vert[gi], self._rbuf[gi], out=out[:, c0:c1], packed=self._rpack[gi], scratch=self._scratch[gi])
         return out
 
     def describe(self):

@@ -123,3 +123,88 @@ def test_two_processes_share_the_gpu_over_gloo():
     want = phl.Lattice(torch.from_numpy(feat.reshape(-1, 5)).cuda()).filter(torch.from_numpy(src).cuda()).cpu().numpy()
     got = np.concatenate([r[1] for r in res], 0)
     assert rel(got, want) <= RTOL
+
+
+class _LoopbackDist:
+    """In-process stand-in for torch.distributed with device-resident payloads (what RCCL gives the driver):
+    every rank is a thread, isend/irecv meet in queues and copy GPU tensor to GPU tensor.  Lets the
+    preallocated-buffer / persistent-op path of RowTileFilter -- the one the RCCL run takes -- execute on a
+    one-GPU box."""
+
+    class P2POp:
+        def __init__(self, op, tensor, peer):
+            self.op, self.tensor, self.peer = op, tensor, peer
+
+    class _Req:
+        def wait(self):
+            return True
+
+    def __init__(self, world):
+        import queue
+        import threading
+
+        self.world = world
+        self.q = {(a, b): queue.Queue() for a in range(world) for b in range(world)}
+        self.local = threading.local()
+        self.isend, self.irecv = "isend", "irecv"
+
+    def get_backend(self):
+        return "nccl"
+
+    def batch_isend_irecv(self, ops):
+        me = self.local.rank
+        for o in ops:
+            if o.op == "isend":
+                torch.cuda.synchronize()
+                self.q[(me, o.peer)].put(o.tensor.clone())
+        for o in ops:
+            if o.op == "irecv":
+                got = self.q[(o.peer, me)].get(timeout=120)
+                if o.tensor.dtype == torch.uint8 or got.dtype == torch.uint8:
+                    o.tensor.view(torch.uint8).copy_(got.view(torch.uint8))
+                else:
+                    o.tensor.copy_(got)
+        return [self._Req() for _ in ops]
+
+
+@pytest.mark.parametrize("world,groups", [(2, 1), (3, 2), (4, 2)])
+def test_preallocated_rccl_shaped_path_in_process(world, groups):
+    """RowTileFilter's steady-state path (device payloads, preallocated vertex / send / receive buffers,
+    persistent P2P op lists) with all ranks as threads of this process; result == the single lattice."""
+    import threading
+
+    import phl
+    from phl import rowtile
+    from test_rowtile_cpu import make_image
+
+    H, W, L = 64 * world, 48, 16
+    feat, src = make_image(H, W, L, sigma_xy=3.0)
+    dev = torch.device("cuda")
+    fake = _LoopbackDist(world)
+    outs, errs = {}, []
+
+    def run(rank):
+        try:
+            fake.local.rank = rank
+            job = rowtile.RowTileFilter(feat, L, rank, world, dev, fake, groups=groups)
+            assert job._fused and len(job._ops) == groups
+            mine = torch.from_numpy(src[job.row0 * W:(job.row0 + job.own_rows) * W]).to(dev)
+            buf = torch.empty_like(mine)
+            a = job.filter(mine, out=buf).clone()
+            b = job.filter(mine)                       # second call: same buffers, same op lists
+            assert torch.equal(a, b)
+            outs[rank] = a.cpu().numpy()
+        except Exception as e:      # noqa: BLE001
+            import traceback
+
+            errs.append((rank, traceback.format_exc()))
+
+    ts = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=300)
+    assert not errs, errs
+    want = phl.Lattice(torch.from_numpy(feat.reshape(-1, 5)).to(dev)).filter(torch.from_numpy(src).to(dev)).cpu().numpy()
+    got = np.concatenate([outs[r] for r in range(world)], 0)
+    assert rel(got, want) <= RTOL
