@@ -8,7 +8,9 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <map>
 #include <mutex>
+#include <utility>
 #include <vector>
 
 #include "phl_internal.h"
@@ -33,14 +35,114 @@ struct device_guard {
 int grow(float **p, int64_t *cap, int64_t need)
 {
     if (need <= *cap) return PHL_OK;
-    if (*p) PHL_HIP(hipFree(*p));
+    if (*p) {
+        PHL_HIP(hipDeviceSynchronize());      // (rare) the old buffer may still be read by launches in flight
+        PHL_HIP(phl_dev_free(*p));
+    }
     *p = nullptr;
     *cap = 0;
-    PHL_HIP(hipMalloc((void **)p, sizeof(float) * (size_t)need));
+    PHL_HIP(phl_dev_malloc((void **)p, sizeof(float) * (size_t)need));
     *cap = need;
     return PHL_OK;
 }
 }  // namespace
+
+// ---- device block cache --------------------------------------------------------------------------------
+// hipMalloc / hipFree cost 50-300 us each and hipFree synchronises the device; a lattice owns ~20 device arrays,
+// so the reference-shaped call (build, filter, destroy per call: phl_filter_once) spent as long in the allocator
+// as in its kernels.  Blocks released by a lattice are kept, by device and size class (sizes rounded up to 1/8 of
+// their power of two, so that the arrays of a slightly different image fit the same blocks), and handed to the
+// next build.  A caller of phl_dev_free guarantees that no launch still uses the block, or that its next user
+// is ordered behind it (phl_destroy synchronises the device first, as hipFree itself would).
+// PHL_CACHE_MAX_MB (default 8192, 0 = off) caps the cached bytes; phl_trim_scratch() releases everything.
+namespace {
+struct dev_cache_t {
+    std::mutex mu;
+    std::map<std::pair<int, size_t>, std::vector<void *>> free_blocks;
+    std::map<void *, std::pair<int, size_t>> live;      // every block handed out: device, class size
+    size_t cached = 0;
+};
+dev_cache_t &dev_cache()
+{
+    static dev_cache_t *c = new dev_cache_t();          // never destroyed: the HIP runtime may be gone at exit
+    return *c;
+}
+size_t cache_limit()
+{
+    static const size_t lim = [] {
+        const char *e = getenv("PHL_CACHE_MAX_MB");
+        return (size_t)(e ? atoll(e) : 8192) << 20;
+    }();
+    return lim;
+}
+size_t size_class(size_t bytes)
+{
+    if (bytes < 4096) return 4096;
+    size_t p2 = 1;
+    while (p2 * 2 <= bytes) p2 *= 2;
+    const size_t step = p2 / 8;
+    return (bytes + step - 1) / step * step;
+}
+void cache_flush_locked(dev_cache_t &c)
+{
+    int prev = -1;
+    (void)hipGetDevice(&prev);
+    for (auto &kv : c.free_blocks) {
+        (void)hipSetDevice(kv.first.first);
+        for (void *p : kv.second) (void)hipFree(p);
+    }
+    c.free_blocks.clear();
+    c.cached = 0;
+    if (prev >= 0) (void)hipSetDevice(prev);
+}
+}  // namespace
+
+hipError_t phl_dev_malloc(void **p, size_t bytes)
+{
+    dev_cache_t &c = dev_cache();
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const size_t cls = size_class(bytes);
+    {
+        std::lock_guard<std::mutex> lk(c.mu);
+        auto it = c.free_blocks.find({dev, cls});
+        if (it != c.free_blocks.end() && !it->second.empty()) {
+            *p = it->second.back();
+            it->second.pop_back();
+            c.cached -= cls;
+            c.live[*p] = {dev, cls};
+            return hipSuccess;
+        }
+    }
+    e = hipMalloc(p, cls);
+    if (e != hipSuccess) {                               // out of memory: give the cached blocks back and retry once
+        (void)hipGetLastError();
+        std::lock_guard<std::mutex> lk(c.mu);
+        cache_flush_locked(c);
+        e = hipMalloc(p, cls);
+        if (e != hipSuccess) return e;
+    }
+    std::lock_guard<std::mutex> lk(c.mu);
+    c.live[*p] = {dev, cls};
+    return hipSuccess;
+}
+
+hipError_t phl_dev_free(void *p)
+{
+    if (!p) return hipSuccess;
+    dev_cache_t &c = dev_cache();
+    std::lock_guard<std::mutex> lk(c.mu);
+    auto it = c.live.find(p);
+    if (it == c.live.end()) return hipFree(p);           // not ours
+    const std::pair<int, size_t> key = it->second;
+    c.live.erase(it);
+    if (cache_limit() == 0 || key.second > cache_limit()) return hipFree(p);
+    if (c.cached + key.second > cache_limit()) cache_flush_locked(c);
+    c.free_blocks[key].push_back(p);
+    c.cached += key.second;
+    return hipSuccess;
+}
 
 // ---- value workspaces --------------------------------------------------------------------------------
 // SURVEY 8(b), threading row: "re-entrant; autograd may call from any thread".  A lattice's tables are
@@ -61,7 +163,7 @@ void ws_free_buffers(phl_workspace *w)
 {
     void *ptrs[] = {w->buf[0], w->buf[1], w->partial, w->stage_in, w->stage_out};
     for (void *p : ptrs)
-        if (p) (void)hipFree(p);
+        if (p) (void)phl_dev_free(p);
     w->buf[0] = w->buf[1] = w->partial = w->stage_in = w->stage_out = nullptr;
     w->buf_elems = w->partial_elems = w->stage_elems = 0;
 }
@@ -265,6 +367,11 @@ int phl_trim_scratch(void)
     }
     g_scratch = nullptr;
     g_scratch_cap = 0;
+    {
+        dev_cache_t &c = dev_cache();
+        std::lock_guard<std::mutex> lk2(c.mu);
+        cache_flush_locked(c);
+    }
     return PHL_OK;
 }
 
@@ -318,10 +425,11 @@ int phl_destroy(phl_lattice *lat)
 {
     if (!lat) return PHL_OK;
     device_guard g(lat->device);
+    (void)hipDeviceSynchronize();      // what hipFree would do: nothing may still be using the arrays (they are cached, not freed)
     phl_tiles_free(lat);
     void *ptrs[] = {lat->vkeys, lat->replay, lat->csr_ptr, lat->csr, lat->nbr, lat->nbr2, lat->table};
     for (void *p : ptrs)
-        if (p) (void)hipFree(p);
+        if (p) (void)phl_dev_free(p);
     if (lat->shared) {
         for (phl_workspace *w : lat->shared->ws) {
             ws_free_buffers(w);

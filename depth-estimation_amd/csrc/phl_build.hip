@@ -378,17 +378,17 @@ static int phl_rebuild_table_and_neighbors(phl_lattice *lat, hipStream_t st)
 {
     const int d = lat->d;
     const int M = (int)lat->M;
-    if (lat->table) PHL_HIP(hipFree(lat->table));
-    if (lat->nbr) PHL_HIP(hipFree(lat->nbr));
-    if (lat->nbr2) PHL_HIP(hipFree(lat->nbr2));
+    if (lat->table) PHL_HIP(phl_dev_free(lat->table));
+    if (lat->nbr) PHL_HIP(phl_dev_free(lat->nbr));
+    if (lat->nbr2) PHL_HIP(phl_dev_free(lat->nbr2));
     lat->table = nullptr;
     lat->nbr = nullptr;
     lat->nbr2 = nullptr;
     uint64_t cap = 1024;
     while (cap < (uint64_t)M * 2) cap <<= 1;
     lat->table_mask = (uint32_t)(cap - 1);
-    PHL_HIP(hipMalloc((void **)&lat->table, sizeof(int) * cap));
-    PHL_HIP(hipMalloc((void **)&lat->nbr, sizeof(int32_t) * (size_t)(M ? M : 1) * (d + 1) * 2));
+    PHL_HIP(phl_dev_malloc((void **)&lat->table, sizeof(int) * cap));
+    PHL_HIP(phl_dev_malloc((void **)&lat->nbr, sizeof(int32_t) * (size_t)(M ? M : 1) * (d + 1) * 2));
     hipLaunchKernelGGL(k_fill_i32, dim3(1024), dim3(256), 0, st, lat->table, (int64_t)cap, PHL_EMPTY);
     if (M > 0) {
         hidden_t hidden;
@@ -402,7 +402,7 @@ static int phl_rebuild_table_and_neighbors(phl_lattice *lat, hipStream_t st)
         if (lat->nbr00_override != -2)    // a table doubling inside the reference's blur(): phl_reftable.hip
             PHL_HIP(hipMemcpyAsync(lat->nbr, &lat->nbr00_override, sizeof(int32_t), hipMemcpyHostToDevice, st));
         const int npairs = (d + 1) / 2;
-        PHL_HIP(hipMalloc((void **)&lat->nbr2, sizeof(int32_t) * (size_t)M * npairs * 8));
+        PHL_HIP(phl_dev_malloc((void **)&lat->nbr2, sizeof(int32_t) * (size_t)M * npairs * 8));
         const int64_t totp = (int64_t)M * npairs;
         hipLaunchKernelGGL(k_compose_pairs, dim3((unsigned)((totp + 255) / 256)), dim3(256), 0, st,
                            reinterpret_cast<const int2 *>(lat->nbr), M, npairs, reinterpret_cast<int4 *>(lat->nbr2));
@@ -446,7 +446,7 @@ int phl_build_device(phl_lattice *lat, const float *ref, int64_t rs, int64_t cs,
     PHL_HIP(tmp.get(&rankv, (size_t)N + 1));
     PHL_HIP(tmp.get(&tile_sums, (size_t)N / SCAN_TILE + 2));
     PHL_HIP(tmp.get(&err, 1));
-    PHL_HIP(hipMalloc((void **)&lat->replay, sizeof(phl_replay_t) * (size_t)N));
+    PHL_HIP(phl_dev_malloc((void **)&lat->replay, sizeof(phl_replay_t) * (size_t)N));
     PHL_HIP(hipMemsetAsync(err, 0, sizeof(int), st));
 
     switch (d) {
@@ -479,7 +479,7 @@ int phl_build_device(phl_lattice *lat, const float *ref, int64_t rs, int64_t cs,
     const int M = host[0];
     lat->M = M;
 
-    PHL_HIP(hipMalloc((void **)&lat->vkeys, sizeof(int16_t) * (size_t)M * d));
+    PHL_HIP(phl_dev_malloc((void **)&lat->vkeys, sizeof(int16_t) * (size_t)M * d));
     hipLaunchKernelGGL(k_assign, dim3(gN), dim3(256), 0, st, flag, rankv, slot_of, ckeys, d, N, table, lat->vkeys);
     hipLaunchKernelGGL(k_set_vid, dim3(gN), dim3(256), 0, st, table, slot_of, N, lat->replay);
     PHL_HIP(hipGetLastError());
@@ -506,12 +506,12 @@ int phl_ensure_csr(phl_lattice *lat, hipStream_t st)
     std::lock_guard<std::mutex> once(*phl_csr_mutex(lat));     // several threads may filter through one lattice
     if (lat->csr_ptr && lat->csr) return PHL_OK;
     const int M = (int)lat->M, N = (int)lat->N, dp1 = lat->d + 1;
-    if (lat->csr_ptr) PHL_HIP(hipFree(lat->csr_ptr));
-    if (lat->csr) PHL_HIP(hipFree(lat->csr));
+    if (lat->csr_ptr) PHL_HIP(phl_dev_free(lat->csr_ptr));
+    if (lat->csr) PHL_HIP(phl_dev_free(lat->csr));
     lat->csr_ptr = nullptr;
     lat->csr = nullptr;
-    PHL_HIP(hipMalloc((void **)&lat->csr_ptr, sizeof(int32_t) * ((size_t)M + 1)));
-    PHL_HIP(hipMalloc((void **)&lat->csr, sizeof(phl_contrib_t) * (size_t)(N ? N : 1)));
+    PHL_HIP(phl_dev_malloc((void **)&lat->csr_ptr, sizeof(int32_t) * ((size_t)M + 1)));
+    PHL_HIP(phl_dev_malloc((void **)&lat->csr, sizeof(phl_contrib_t) * (size_t)(N ? N : 1)));
     if (N == 0 || M == 0) {
         PHL_HIP(hipMemsetAsync(lat->csr_ptr, 0, sizeof(int32_t) * ((size_t)M + 1), st));
         PHL_HIP(hipStreamSynchronize(st));
@@ -570,18 +570,18 @@ int phl_add_vertices_device(phl_lattice *lat, const int16_t *keys_host, int64_t 
     if (n_new > 0) {
         const int M_new = M_old + n_new;
         int16_t *vkeys_new;
-        PHL_HIP(hipMalloc((void **)&vkeys_new, sizeof(int16_t) * (size_t)M_new * d));
+        PHL_HIP(phl_dev_malloc((void **)&vkeys_new, sizeof(int16_t) * (size_t)M_new * d));
         if (M_old > 0)
             PHL_HIP(hipMemcpyAsync(vkeys_new, lat->vkeys, sizeof(int16_t) * (size_t)M_old * d, hipMemcpyDeviceToDevice, st));
         hipLaunchKernelGGL(k_append_missing, dim3((K + 255) / 256), dim3(256), 0, st, qkeys, d, K, mrank, M_old, vkeys_new,
                            vid);
         PHL_HIP(hipGetLastError());
         PHL_HIP(hipStreamSynchronize(st));
-        if (lat->vkeys) PHL_HIP(hipFree(lat->vkeys));
+        if (lat->vkeys) PHL_HIP(phl_dev_free(lat->vkeys));
         // the per-vertex contribution lists are indexed by M: drop them, they are rebuilt on demand
         // (ghosts get empty lists)
-        if (lat->csr_ptr) PHL_HIP(hipFree(lat->csr_ptr));
-        if (lat->csr) PHL_HIP(hipFree(lat->csr));
+        if (lat->csr_ptr) PHL_HIP(phl_dev_free(lat->csr_ptr));
+        if (lat->csr) PHL_HIP(phl_dev_free(lat->csr));
         lat->csr_ptr = nullptr;
         lat->csr = nullptr;
         lat->vkeys = vkeys_new;

@@ -126,6 +126,10 @@ int phl_hip_fail(hipError_t e, const char *what, const char *file, int line);
         if (e__ != hipSuccess) return phl_hip_fail(e__, #call, __FILE__, __LINE__); \
     } while (0)
 
+// cached device blocks for the arrays a lattice owns (phl_api.hip)
+hipError_t phl_dev_malloc(void **p, size_t bytes);
+hipError_t phl_dev_free(void *p);
+
 // cached device scratch for build temporaries (phl_api.hip); one user at a time per process
 bool phl_scratch_acquire(void **base, size_t *cap);
 void phl_scratch_release(size_t wanted_bytes);

@@ -357,10 +357,10 @@ int phl_apply_reference_table(phl_lattice *lat, const int *flag, const int *rank
                            seg_e_dev, seg_id_dev);
         PHL_HIP(hipGetLastError());
         int16_t *vkeys_new;
-        PHL_HIP(hipMalloc((void **)&vkeys_new, sizeof(int16_t) * (size_t)R.M_ref * d));
+        PHL_HIP(phl_dev_malloc((void **)&vkeys_new, sizeof(int16_t) * (size_t)R.M_ref * d));
         PHL_HIP(hipMemcpyAsync(vkeys_new, R.keys.data(), sizeof(int16_t) * (size_t)R.M_ref * d, hipMemcpyHostToDevice, st));
         PHL_HIP(hipStreamSynchronize(st));            // host vectors and pool temporaries die on return
-        PHL_HIP(hipFree(lat->vkeys));
+        PHL_HIP(phl_dev_free(lat->vkeys));
         lat->vkeys = vkeys_new;
         lat->M = R.M_ref;
     }

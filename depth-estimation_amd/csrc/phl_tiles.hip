@@ -780,7 +780,7 @@ int phl_tiles_free(phl_lattice *lat)
     void *ptrs[] = {lat->pix_order, lat->chunk_vptr, lat->slot_vert, lat->slot_pidx, lat->seg_rng, lat->seg,
                     lat->lidx, lat->vs_ptr, lat->vs, lat->vorder};
     for (void *p : ptrs)
-        if (p) (void)hipFree(p);
+        if (p) (void)phl_dev_free(p);
     lat->pix_order = lat->chunk_vptr = lat->slot_vert = lat->slot_pidx = lat->vs_ptr = nullptr;
     lat->seg_rng = nullptr;
     lat->vorder = nullptr;
@@ -797,16 +797,16 @@ int phl_tiles_free(phl_lattice *lat)
 int phl_tiles_link_vertices(phl_lattice *lat, hipStream_t st)
 {
     const int M = (int)lat->M, S = (int)lat->S;
-    if (lat->vs_ptr) PHL_HIP(hipFree(lat->vs_ptr));
-    if (lat->vs) PHL_HIP(hipFree(lat->vs));
-    if (lat->slot_pidx) PHL_HIP(hipFree(lat->slot_pidx));
+    if (lat->vs_ptr) PHL_HIP(phl_dev_free(lat->vs_ptr));
+    if (lat->vs) PHL_HIP(phl_dev_free(lat->vs));
+    if (lat->slot_pidx) PHL_HIP(phl_dev_free(lat->slot_pidx));
     lat->vs_ptr = nullptr;
     lat->vs = nullptr;
     lat->slot_pidx = nullptr;
     lat->S_multi = 0;
-    PHL_HIP(hipMalloc((void **)&lat->vs_ptr, sizeof(int) * ((size_t)M + 1)));
-    PHL_HIP(hipMalloc((void **)&lat->vs, sizeof(phl_contrib_t) * ((size_t)S + 1)));
-    PHL_HIP(hipMalloc((void **)&lat->slot_pidx, sizeof(int) * ((size_t)S + 1)));
+    PHL_HIP(phl_dev_malloc((void **)&lat->vs_ptr, sizeof(int) * ((size_t)M + 1)));
+    PHL_HIP(phl_dev_malloc((void **)&lat->vs, sizeof(phl_contrib_t) * ((size_t)S + 1)));
+    PHL_HIP(phl_dev_malloc((void **)&lat->slot_pidx, sizeof(int) * ((size_t)S + 1)));
     if (S == 0) {
         PHL_HIP(hipMemsetAsync(lat->vs_ptr, 0, sizeof(int) * ((size_t)M + 1), st));
         PHL_HIP(hipStreamSynchronize(st));
@@ -839,9 +839,9 @@ int phl_tiles_link_vertices(phl_lattice *lat, hipStream_t st)
     int s_multi = 0;
     PHL_HIP(hipMemcpyAsync(&s_multi, lat->slot_pidx + S, sizeof(int), hipMemcpyDeviceToHost, st));
     // chunk-major vertex order for the gather splat
-    if (lat->vorder) PHL_HIP(hipFree(lat->vorder));
+    if (lat->vorder) PHL_HIP(phl_dev_free(lat->vorder));
     lat->vorder = nullptr;
-    PHL_HIP(hipMalloc((void **)&lat->vorder, sizeof(int) * ((size_t)M + 1)));
+    PHL_HIP(phl_dev_malloc((void **)&lat->vorder, sizeof(int) * ((size_t)M + 1)));
     {
         int *first, *frank;
         PHL_HIP(tmp.get(&first, (size_t)S + 1));
@@ -933,7 +933,7 @@ int phl_tiles_build(phl_lattice *lat, const float *ref, int64_t rs, int64_t cs, 
     hipLaunchKernelGGL(k_cell_ids, dim3(gn), dim3(256), 0, st, ref, rs, cs, (int64_t)n, da, db, lo[da],
                        db >= 0 ? lo[db] : 0.f, inv_t, nca, ncb, cell);
     PHL_HIP(hipGetLastError());
-    PHL_HIP(hipMalloc((void **)&lat->pix_order, sizeof(int) * (size_t)n));
+    PHL_HIP(phl_dev_malloc((void **)&lat->pix_order, sizeof(int) * (size_t)n));
     rc = stable_sort_perm(cell, n, ncell, lat->pix_order, tmp, st);
     if (rc) return rc;
 
@@ -942,7 +942,7 @@ int phl_tiles_build(phl_lattice *lat, const float *ref, int64_t rs, int64_t cs, 
     lat->nchunks = nchunks;
     int *nv;
     PHL_HIP(tmp.get(&nv, (size_t)nchunks + 1));
-    PHL_HIP(hipMalloc((void **)&lat->chunk_vptr, sizeof(int) * ((size_t)nchunks + 1)));
+    PHL_HIP(phl_dev_malloc((void **)&lat->chunk_vptr, sizeof(int) * ((size_t)nchunks + 1)));
     static const bool force64 = getenv("PHL_SORT_KEY64") != nullptr;       // tests: take the wide-key kernels on small inputs
     const bool key32 = lat->M < (1 << 21) && !force64;                     // (vertex id, entry < 2048) fits 32 bits
 #define PHL_CHUNK_SORT_K(WRITE_, KT_, ...)                                                                                    \
@@ -962,8 +962,8 @@ int phl_tiles_build(phl_lattice *lat, const float *ref, int64_t rs, int64_t cs, 
     int2 *t_rng;
     PHL_HIP(tmp.get(&t_vert, (size_t)nchunks * SLOT_STRIDE));
     PHL_HIP(tmp.get(&t_rng, (size_t)nchunks * SLOT_STRIDE));
-    PHL_HIP(hipMalloc((void **)&lat->seg, sizeof(phl_contrib_t) * (size_t)N));
-    PHL_HIP(hipMalloc((void **)&lat->lidx, sizeof(unsigned short) * (size_t)N));
+    PHL_HIP(phl_dev_malloc((void **)&lat->seg, sizeof(phl_contrib_t) * (size_t)N));
+    PHL_HIP(phl_dev_malloc((void **)&lat->lidx, sizeof(unsigned short) * (size_t)N));
     PHL_CHUNK_SORT(true, lat->pix_order, n, P, dp1, lat->replay, nv, (const int *)nullptr, SLOT_STRIDE, t_vert, t_rng,
                    lat->seg, lat->lidx)
     PHL_HIP(hipGetLastError());
@@ -979,8 +979,8 @@ int phl_tiles_build(phl_lattice *lat, const float *ref, int64_t rs, int64_t cs, 
     }
     lat->S = S;
     lat->nv_max = nv_max;
-    PHL_HIP(hipMalloc((void **)&lat->slot_vert, sizeof(int) * ((size_t)S + 1)));
-    PHL_HIP(hipMalloc((void **)&lat->seg_rng, sizeof(int2) * ((size_t)S + 1)));
+    PHL_HIP(phl_dev_malloc((void **)&lat->slot_vert, sizeof(int) * ((size_t)S + 1)));
+    PHL_HIP(phl_dev_malloc((void **)&lat->seg_rng, sizeof(int2) * ((size_t)S + 1)));
     if (nv_max <= SLOT_STRIDE) {
         hipLaunchKernelGGL(k_compact_slots, dim3(nchunks), dim3(256), 0, st, lat->chunk_vptr, nchunks, SLOT_STRIDE, t_vert,
                            t_rng, lat->slot_vert, lat->seg_rng);
@@ -1028,7 +1028,7 @@ int phl_launch_splat_tiled(phl_lattice *lat, const float *src, int64_t src_rs, i
     unsigned long long *tl = nullptr;
     const size_t tl_n = (size_t)cgrid * 8;
     if (tl_path) {
-        PHL_HIP(hipMalloc((void **)&tl, tl_n * 8));
+        PHL_HIP(phl_dev_malloc((void **)&tl, tl_n * 8));
         PHL_HIP(hipMemsetAsync(tl, 0, tl_n * 8, st));
     }
     dispatch_lprs(lprs, [&](auto L) {
@@ -1042,7 +1042,7 @@ int phl_launch_splat_tiled(phl_lattice *lat, const float *src, int64_t src_rs, i
         std::vector<unsigned long long> h(tl_n);
         PHL_HIP(hipMemcpyAsync(h.data(), tl, tl_n * 8, hipMemcpyDeviceToHost, st));
         PHL_HIP(hipStreamSynchronize(st));
-        (void)hipFree(tl);
+        (void)phl_dev_free(tl);
         if (FILE *f = fopen(tl_path, "wb")) {
             fwrite(h.data(), 8, tl_n, f);
             fclose(f);
