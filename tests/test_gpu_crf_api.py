@@ -294,3 +294,42 @@ def test_crf_as_rnn_nchw_golden(golden_dir):
     from crf.crf_module import ijrgbGuide
     mine = ijrgbGuide(trainable=False)(torch.from_numpy(g["img"]).to(dev))
     assert float((mine - refs).abs().max()) <= 1e-6 * float(refs.abs().max())
+
+
+def test_mean_field_gradient_through_the_lattice_operator():
+    """A LatticeGaussian whose ``ref`` requires grad makes W@Q carry a graph even when E_0 and Mu do not: the
+    fused raw-pointer kernels must step aside (they would drop the graph and overwrite a tensor LatticeFilter
+    saved for backward).  d(sum of expected disparity)/d(ref) through mean_field_infer == the plain torch loop."""
+    import torch.nn.functional as F
+    from crf.crf_module import charbonneir, compatibility_matrix, mean_field_infer
+    from crf.gaussian_matrix import LatticeGaussian
+
+    g = torch.Generator().manual_seed(11)
+    n, d, L = 600, 3, 32
+    ref0 = (torch.rand(n, d, generator=g) * 2).cuda()
+    E0 = (torch.rand(n, L, generator=g) * 5).cuda()
+    labels = torch.arange(L, dtype=torch.float32, device="cuda")
+    Mu = compatibility_matrix(lambda a, b: charbonneir(a, b, 3.0), labels) * 0.05
+
+    def run(fn):
+        ref = ref0.clone().requires_grad_(True)
+        Q = fn(E0, LatticeGaussian(ref), Mu, 2)
+        assert Q.requires_grad
+        (Q @ labels).sum().backward()
+        return Q.detach(), ref.grad
+
+    def plain(E_0, W, Mu_, niters):
+        Q = F.softmax(-E_0, dim=1)
+        for _ in range(niters):
+            Q = F.softmax(-(E_0 + (W @ Q) @ Mu_), dim=1)
+        return Q
+
+    Qa, ga = run(mean_field_infer)
+    Qb, gb = run(plain)
+    assert torch.isfinite(ga).all() and float(ga.abs().max()) > 0
+    assert float((Qa - Qb).abs().max()) <= 1e-6
+    assert float((ga - gb).abs().max()) <= 1e-4 * float(gb.abs().max())
+    # without any gradient the fused path is taken and agrees with the plain loop
+    with torch.no_grad():
+        Qc = mean_field_infer(E0, LatticeGaussian(ref0), Mu, 2)
+    assert not Qc.requires_grad and float((Qc - Qb).abs().max()) <= 1e-5
