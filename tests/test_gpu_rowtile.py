@@ -208,3 +208,31 @@ def test_preallocated_rccl_shaped_path_in_process(world, groups):
     want = phl.Lattice(torch.from_numpy(feat.reshape(-1, 5)).to(dev)).filter(torch.from_numpy(src).to(dev)).cpu().numpy()
     got = np.concatenate([outs[r] for r in range(world)], 0)
     assert rel(got, want) <= RTOL
+
+
+@pytest.mark.parametrize("world", [8, 4])
+def test_full_size_c3_in_row_bands(world):
+    """BASELINE configs[3] at its real size: the 2048x1536x256 volume cut into 8 (and 4) row bands, all bands played
+    on this one GPU (loopback exchange of exactly the rows RCCL would carry), against the single-lattice filter."""
+    import os
+    import sys
+
+    import phl
+    from phl import rowtile
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+
+    H, W, L, _ = bench.WORKLOADS["c3"]
+    feat = bench.synthetic_features(H, W)
+    dev = torch.device("cuda")
+    src = bench.synthetic_values(torch, H, W, L, 0, dev)
+    want = phl.Lattice(torch.from_numpy(feat.reshape(-1, 5)).to(dev)).filter(src)
+    got, bands = rowtile.simulate(feat, src, world, phl.Lattice, dev)
+    err = float(((got - want).abs() / want.abs().clamp_min(1e-3 * float(want.abs().max()))).max())
+    rows = [b.recv_rows(p) for b in bands for p in b.sides]
+    print(f"[measured] c3 in {world} bands: max rel err vs single lattice {err:.2e}; boundary rows per side "
+          f"{min(rows)}..{max(rows)} = {max(rows) * L * 4 / 1e6:.1f} MB; ghosts per band "
+          f"{max(b.M - b.eng.M_local for b in bands)} of {max(b.M for b in bands)} vertices")
+    assert err <= RTOL
+    assert all(b.own_rows == H // world for b in bands)
