@@ -168,9 +168,11 @@ void ws_free_buffers(phl_workspace *w)
     w->buf_elems = w->partial_elems = w->stage_elems = 0;
 }
 
+// (no fence needed: the launches it stands behind finished before it started -- stream order -- and the store
+//  itself is released to the host at the kernel's end; tools/mark_probe.hip: 2.7 us in-stream, against 3.5 us with
+//  a system fence and 4.4 us for hipStreamWriteValue64)
 __global__ void k_mark_done(unsigned long long *word, unsigned long long ticket)
 {
-    __threadfence_system();
     *reinterpret_cast<volatile unsigned long long *>(word) = ticket;
 }
 
