@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256) void k_minmax(const float *__restrict__ ref, i
 
 __global__ __launch_bounds__(256) void k_cell_ids(const float *__restrict__ ref, int64_t rs, int64_t cs, int64_t n, int da,
                                                   int db, float lo_a, float lo_b, float inv_t, int nca, int ncb,
-                                                  int *__restrict__ cell, int blk)
+                                                  int *__restrict__ cell)
 {
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool active = p < n;
@@ -79,11 +79,7 @@ __global__ __launch_bounds__(256) void k_cell_ids(const float *__restrict__ ref,
         cb = (int)((ref[pc * rs + db * cs] - lo_b) * inv_t);
         cb = min(max(cb, 0), ncb - 1);
     }
-    int c = cb * nca + ca;   // the wider dimension runs fastest inside a row of cells
-    if (blk > 1) {           // experiment: blk x blk blocks of cells stay together (cluster candidates)
-        const int nba = (nca + blk - 1) / blk;
-        c = (((cb / blk) * nba + ca / blk) * blk + cb % blk) * blk + ca % blk;
-    }
+    const int c = cb * nca + ca;   // the wider dimension runs fastest inside a row of cells
     if (active) cell[p] = c;
 }
 
@@ -934,13 +930,11 @@ int phl_tiles_build(phl_lattice *lat, const float *ref, int64_t rs, int64_t cs, 
     PHL_HIP(tmp.get(&cell, (size_t)n));
     PHL_HIP(tmp.get(&tile_sums, (size_t)n / SCAN_TILE + 2));
     const unsigned gn = (unsigned)((n + 255) / 256);
-    static const int cell_blk = getenv("PHL_CELL_BLOCK") ? atoi(getenv("PHL_CELL_BLOCK")) : 1;
-    const int64_t ncell_keys = cell_blk > 1 ? (int64_t)((nca + cell_blk - 1) / cell_blk) * ((ncb + cell_blk - 1) / cell_blk) * cell_blk * cell_blk : ncell;
     hipLaunchKernelGGL(k_cell_ids, dim3(gn), dim3(256), 0, st, ref, rs, cs, (int64_t)n, da, db, lo[da],
-                       db >= 0 ? lo[db] : 0.f, inv_t, nca, ncb, cell, cell_blk);
+                       db >= 0 ? lo[db] : 0.f, inv_t, nca, ncb, cell);
     PHL_HIP(hipGetLastError());
     PHL_HIP(phl_dev_malloc((void **)&lat->pix_order, sizeof(int) * (size_t)n));
-    rc = stable_sort_perm(cell, n, (int64_t)ncell_keys, lat->pix_order, tmp, st);
+    rc = stable_sort_perm(cell, n, ncell, lat->pix_order, tmp, st);
     if (rc) return rc;
 
     // 3. per-chunk local vertex lists, segments and local indices
