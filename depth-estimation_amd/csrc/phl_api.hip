@@ -429,7 +429,7 @@ int phl_destroy(phl_lattice *lat)
     device_guard g(lat->device);
     (void)hipDeviceSynchronize();      // what hipFree would do: nothing may still be using the arrays (they are cached, not freed)
     phl_tiles_free(lat);
-    void *ptrs[] = {lat->vkeys, lat->replay, lat->csr_ptr, lat->csr, lat->nbr, lat->nbr2, lat->table};
+    void *ptrs[] = {lat->vkeys, lat->replay, lat->csr_ptr, lat->csr, lat->nbr, lat->nbr2, lat->table, lat->ft_of_int, lat->int_of_ft, lat->vfirst};
     for (void *p : ptrs)
         if (p) (void)phl_dev_free(p);
     if (lat->shared) {
@@ -688,13 +688,47 @@ int phl_filter_once(const float *src, int vd, int64_t src_rs, int64_t src_cs, co
     return rc;
 }
 
+// first-touch <-> internal maps on the host (empty vectors: the numberings coincide)
+static int fetch_maps(phl_lattice *lat, std::vector<int32_t> &ft_of_int, std::vector<int32_t> &int_of_ft)
+{
+    ft_of_int.clear();
+    int_of_ft.clear();
+    if (!lat->int_of_ft || lat->M == 0) return PHL_OK;
+    ft_of_int.resize((size_t)lat->M);
+    int_of_ft.resize((size_t)lat->M);
+    PHL_HIP(hipMemcpy(ft_of_int.data(), lat->ft_of_int, sizeof(int32_t) * (size_t)lat->M, hipMemcpyDeviceToHost));
+    PHL_HIP(hipMemcpy(int_of_ft.data(), lat->int_of_ft, sizeof(int32_t) * (size_t)lat->M, hipMemcpyDeviceToHost));
+    return PHL_OK;
+}
+
+int phl_get_vertex_order(phl_lattice *lat, int32_t *row_of_vertex)
+{
+    if (!lat || !row_of_vertex) { phl_set_error("phl_get_vertex_order: bad arguments"); return PHL_ERR_INVALID; }
+    device_guard g(lat->device);
+    PHL_HIP(hipDeviceSynchronize());
+    if (lat->int_of_ft) PHL_HIP(hipMemcpy(row_of_vertex, lat->int_of_ft, sizeof(int32_t) * (size_t)lat->M, hipMemcpyDeviceToHost));
+    else
+        for (int64_t v = 0; v < lat->M; v++) row_of_vertex[v] = (int32_t)v;
+    return PHL_OK;
+}
+
 int phl_get_keys(phl_lattice *lat, int16_t *keys)
 {
     if (!lat || !keys) { phl_set_error("phl_get_keys: bad arguments"); return PHL_ERR_INVALID; }
     if (lat->M == 0) return PHL_OK;
     device_guard g(lat->device);
     PHL_HIP(hipDeviceSynchronize());
-    PHL_HIP(hipMemcpy(keys, lat->vkeys, sizeof(int16_t) * (size_t)lat->M * lat->d, hipMemcpyDeviceToHost));
+    std::vector<int32_t> f, r;
+    int rc = fetch_maps(lat, f, r);
+    if (rc) return rc;
+    const int d = lat->d;
+    if (r.empty()) {
+        PHL_HIP(hipMemcpy(keys, lat->vkeys, sizeof(int16_t) * (size_t)lat->M * d, hipMemcpyDeviceToHost));
+        return PHL_OK;
+    }
+    std::vector<int16_t> h((size_t)lat->M * d);
+    PHL_HIP(hipMemcpy(h.data(), lat->vkeys, sizeof(int16_t) * h.size(), hipMemcpyDeviceToHost));
+    for (int64_t v = 0; v < lat->M; v++) memcpy(keys + v * d, h.data() + (size_t)r[v] * d, sizeof(int16_t) * d);
     return PHL_OK;
 }
 
@@ -706,7 +740,10 @@ int phl_get_replay(phl_lattice *lat, int32_t *vid, float *w)
     std::vector<phl_replay_t> h((size_t)lat->N);
     PHL_HIP(hipDeviceSynchronize());
     PHL_HIP(hipMemcpy(h.data(), lat->replay, sizeof(phl_replay_t) * h.size(), hipMemcpyDeviceToHost));
-    for (size_t i = 0; i < h.size(); i++) { vid[i] = h[i].vid; w[i] = h[i].w; }
+    std::vector<int32_t> f, r;
+    int rc = fetch_maps(lat, f, r);
+    if (rc) return rc;
+    for (size_t i = 0; i < h.size(); i++) { vid[i] = f.empty() ? h[i].vid : f[h[i].vid]; w[i] = h[i].w; }
     return PHL_OK;
 }
 
@@ -716,7 +753,23 @@ int phl_get_neighbors(phl_lattice *lat, int32_t *nbr)
     if (lat->M == 0) return PHL_OK;
     device_guard g(lat->device);
     PHL_HIP(hipDeviceSynchronize());
-    PHL_HIP(hipMemcpy(nbr, lat->nbr, sizeof(int32_t) * (size_t)lat->M * (lat->d + 1) * 2, hipMemcpyDeviceToHost));
+    std::vector<int32_t> f, r;
+    int rc = fetch_maps(lat, f, r);
+    if (rc) return rc;
+    const size_t M = (size_t)lat->M;
+    const int axes = lat->d + 1;
+    if (r.empty()) {
+        PHL_HIP(hipMemcpy(nbr, lat->nbr, sizeof(int32_t) * M * axes * 2, hipMemcpyDeviceToHost));
+        return PHL_OK;
+    }
+    std::vector<int32_t> h(M * axes * 2);
+    PHL_HIP(hipMemcpy(h.data(), lat->nbr, sizeof(int32_t) * h.size(), hipMemcpyDeviceToHost));
+    for (int a = 0; a < axes; a++)
+        for (size_t v = 0; v < M; v++)
+            for (int s2 = 0; s2 < 2; s2++) {
+                const int32_t x = h[((size_t)a * M + r[v]) * 2 + s2];
+                nbr[((size_t)a * M + v) * 2 + s2] = x < 0 ? x : f[x];
+            }
     return PHL_OK;
 }
 
@@ -725,13 +778,23 @@ int phl_get_splat_lists(phl_lattice *lat, int32_t *ptr, int32_t *pixel, float *w
     if (!lat || !ptr || !pixel || !w) { phl_set_error("phl_get_splat_lists: bad arguments"); return PHL_ERR_INVALID; }
     if (lat->N == 0) { ptr[0] = 0; return PHL_OK; }
     device_guard g(lat->device);
-    const int rc = phl_ensure_csr(lat, nullptr);
-    if (rc) return rc;
+    const int rc0 = phl_ensure_csr(lat, nullptr);
+    if (rc0) return rc0;
     std::vector<phl_contrib_t> h((size_t)lat->N);
+    std::vector<int32_t> p((size_t)lat->M + 1);
     PHL_HIP(hipDeviceSynchronize());
-    PHL_HIP(hipMemcpy(ptr, lat->csr_ptr, sizeof(int32_t) * ((size_t)lat->M + 1), hipMemcpyDeviceToHost));
+    PHL_HIP(hipMemcpy(p.data(), lat->csr_ptr, sizeof(int32_t) * p.size(), hipMemcpyDeviceToHost));
     PHL_HIP(hipMemcpy(h.data(), lat->csr, sizeof(phl_contrib_t) * h.size(), hipMemcpyDeviceToHost));
-    for (size_t i = 0; i < h.size(); i++) { pixel[i] = h[i].pixel; w[i] = h[i].w; }
+    std::vector<int32_t> f, r;
+    int rc = fetch_maps(lat, f, r);
+    if (rc) return rc;
+    int64_t o = 0;
+    for (int64_t v = 0; v < lat->M; v++) {          // lists in first-touch vertex order
+        const int64_t row = r.empty() ? v : r[v];
+        ptr[v] = (int32_t)o;
+        for (int32_t e = p[row]; e < p[row + 1]; e++, o++) { pixel[o] = h[e].pixel; w[o] = h[e].w; }
+    }
+    ptr[lat->M] = (int32_t)o;
     return PHL_OK;
 }
 

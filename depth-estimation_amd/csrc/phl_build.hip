@@ -213,6 +213,14 @@ __global__ __launch_bounds__(256) void k_assign(const int *__restrict__ flag, co
     table[slot_of[e]] = -(vid + 1);
 }
 
+// first-touch candidate of every vertex (its pixel tells the renumbering where the vertex lives)
+__global__ __launch_bounds__(256) void k_first_candidate(const int *__restrict__ flag, const int *__restrict__ rankv, int N,
+                                                         int *__restrict__ vfirst)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < N && flag[e]) vfirst[rankv[e]] = e;
+}
+
 __global__ __launch_bounds__(256) void k_set_vid(const int *__restrict__ table, const int *__restrict__ slot_of, int N,
                                                  phl_replay_t *__restrict__ replay)
 {
@@ -314,12 +322,12 @@ struct hidden_t {
 // (re)build the persistent key -> vertex table from the distinct vertex keys (reference-table mode: the
 // duplicates the reference's own table cannot reach stay out)
 __global__ __launch_bounds__(256) void k_table_insert(const int16_t *__restrict__ vkeys, int d, int M, int *table,
-                                                      uint32_t mask, hidden_t hidden)
+                                                      uint32_t mask, hidden_t hidden, const int *__restrict__ int_of_ft)
 {
     const int v = blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= M) return;
-    for (int i = 0; i < hidden.n; i++)
-        if (hidden.id[i] == v) return;
+    for (int i = 0; i < hidden.n; i++)          // hidden ids are first-touch ids
+        if ((int_of_ft ? int_of_ft[hidden.id[i]] : hidden.id[i]) == v) return;
     const int16_t *key = vkeys + (int64_t)v * d;
     uint32_t h = mix_begin();
     for (int i = 0; i < d; i++) h = mix_step(h, key[i]);
@@ -371,10 +379,24 @@ void launch_elevate(const float *ref, int64_t rs, int64_t cs, int64_t n, const s
     hipLaunchKernelGGL(k_elevate<D>, dim3(blocks), dim3(256), 0, st, ref, rs, cs, n, sf, ckeys, replay, err);
 }
 
+__global__ __launch_bounds__(256) void k_iota_from(int *p, int n, int first)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = first + i;
+}
+
+// nbr[axis 0][first-touch vertex 0][side 0] = value (first-touch id or -1): the one neighbour a table doubling
+// inside the reference's blur() decides (phl_reftable.hip)
+__global__ void k_override_nbr00(int *nbr, const int *__restrict__ int_of_ft, int value)
+{
+    const int row = int_of_ft ? int_of_ft[0] : 0;
+    nbr[(int64_t)row * 2] = (value >= 0 && int_of_ft) ? int_of_ft[value] : value;
+}
+
 }  // namespace
 
 // Persistent compact table (capacity >= 2M) + blur neighbour ids for ALL current vertices.
-static int phl_rebuild_table_and_neighbors(phl_lattice *lat, hipStream_t st)
+int phl_rebuild_table_and_neighbors(phl_lattice *lat, hipStream_t st)
 {
     const int d = lat->d;
     const int M = (int)lat->M;
@@ -395,12 +417,12 @@ static int phl_rebuild_table_and_neighbors(phl_lattice *lat, hipStream_t st)
         hidden.n = lat->n_hidden;
         for (int i = 0; i < lat->n_hidden; i++) hidden.id[i] = lat->hidden[i];
         hipLaunchKernelGGL(k_table_insert, dim3((M + 255) / 256), dim3(256), 0, st, lat->vkeys, d, M, lat->table,
-                           lat->table_mask, hidden);
+                           lat->table_mask, hidden, lat->int_of_ft);
         const int64_t tot = (int64_t)M * (d + 1);
         hipLaunchKernelGGL(k_neighbors, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, lat->vkeys, d, M,
                            lat->table, lat->table_mask, lat->nbr);
         if (lat->nbr00_override != -2)    // a table doubling inside the reference's blur(): phl_reftable.hip
-            PHL_HIP(hipMemcpyAsync(lat->nbr, &lat->nbr00_override, sizeof(int32_t), hipMemcpyHostToDevice, st));
+            hipLaunchKernelGGL(k_override_nbr00, dim3(1), dim3(1), 0, st, lat->nbr, lat->int_of_ft, lat->nbr00_override);
         const int npairs = (d + 1) / 2;
         PHL_HIP(phl_dev_malloc((void **)&lat->nbr2, sizeof(int32_t) * (size_t)M * npairs * 8));
         const int64_t totp = (int64_t)M * npairs;
@@ -421,7 +443,7 @@ int phl_build_device(phl_lattice *lat, const float *ref, int64_t rs, int64_t cs,
     lat->M_local = 0;
     lat->n_hidden = 0;
     lat->nbr00_override = -2;
-    if (n == 0) return phl_rebuild_table_and_neighbors(lat, st);
+    if (n == 0) return PHL_OK;            // (tables: phl_tiles_build)
     const int N = (int)N64;
 
     // scaleFactor exactly as the reference computes it on the host (permutohedral.h:354-371)
@@ -483,18 +505,21 @@ int phl_build_device(phl_lattice *lat, const float *ref, int64_t rs, int64_t cs,
     hipLaunchKernelGGL(k_assign, dim3(gN), dim3(256), 0, st, flag, rankv, slot_of, ckeys, d, N, table, lat->vkeys);
     hipLaunchKernelGGL(k_set_vid, dim3(gN), dim3(256), 0, st, table, slot_of, N, lat->replay);
     PHL_HIP(hipGetLastError());
+    if (lat->vfirst) PHL_HIP(phl_dev_free(lat->vfirst));
+    lat->vfirst = nullptr;
     if (lat->build_flags & PHL_BUILD_REFERENCE_TABLE) {
         rc = phl_apply_reference_table(lat, flag, rankv, st);
         if (rc) return rc;
     }
+    if (lat->M == M && M > 0) {     // (the reference-table mode may have inserted duplicate vertices: no list then)
+        PHL_HIP(phl_dev_malloc((void **)&lat->vfirst, sizeof(int) * (size_t)M));
+        hipLaunchKernelGGL(k_first_candidate, dim3(gN), dim3(256), 0, st, flag, rankv, N, lat->vfirst);
+        PHL_HIP(hipGetLastError());
+    }
     lat->M_local = lat->M;
-    rc = phl_rebuild_table_and_neighbors(lat, st);
-    if (rc) return rc;
+    // (locality renumbering, key -> vertex table and blur neighbours follow in phl_tiles_build)
     PHL_HIP(hipGetLastError());
     PHL_HIP(hipStreamSynchronize(st));  // temporaries are freed on return
-    lat->table_bytes = (int64_t)(sizeof(int16_t) * (size_t)M * d + sizeof(phl_replay_t) * (size_t)N +
-                                 sizeof(int32_t) * (size_t)M * (d + 1) * 2 + sizeof(int32_t) * (size_t)M * ((d + 1) / 2) * 8 +
-                                 sizeof(int) * ((size_t)lat->table_mask + 1));
     return PHL_OK;
 }
 
@@ -577,6 +602,21 @@ int phl_add_vertices_device(phl_lattice *lat, const int16_t *keys_host, int64_t 
                            vid);
         PHL_HIP(hipGetLastError());
         PHL_HIP(hipStreamSynchronize(st));
+        if (lat->int_of_ft) {        // ghosts are appended at the end in both numberings
+            int32_t *a, *b;
+            PHL_HIP(phl_dev_malloc((void **)&a, sizeof(int32_t) * (size_t)M_new));
+            PHL_HIP(phl_dev_malloc((void **)&b, sizeof(int32_t) * (size_t)M_new));
+            PHL_HIP(hipMemcpyAsync(a, lat->ft_of_int, sizeof(int32_t) * (size_t)M_old, hipMemcpyDeviceToDevice, st));
+            PHL_HIP(hipMemcpyAsync(b, lat->int_of_ft, sizeof(int32_t) * (size_t)M_old, hipMemcpyDeviceToDevice, st));
+            hipLaunchKernelGGL(k_iota_from, dim3((n_new + 255) / 256), dim3(256), 0, st, a + M_old, n_new, M_old);
+            hipLaunchKernelGGL(k_iota_from, dim3((n_new + 255) / 256), dim3(256), 0, st, b + M_old, n_new, M_old);
+            PHL_HIP(hipGetLastError());
+            PHL_HIP(hipStreamSynchronize(st));
+            PHL_HIP(phl_dev_free(lat->ft_of_int));
+            PHL_HIP(phl_dev_free(lat->int_of_ft));
+            lat->ft_of_int = a;
+            lat->int_of_ft = b;
+        }
         if (lat->vkeys) PHL_HIP(phl_dev_free(lat->vkeys));
         // the per-vertex contribution lists are indexed by M: drop them, they are rebuilt on demand
         // (ghosts get empty lists)

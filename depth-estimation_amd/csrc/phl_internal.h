@@ -40,6 +40,11 @@ struct phl_lattice {
     int *table;             // open-addressing key -> -(vid+1), PHL_EMPTY = free; kept for phl_add_vertices
     uint32_t table_mask;
     int64_t M_local;        // vertices created by this lattice's own pixels (ghosts come after)
+    // Internal vertex numbering (phl_renumber_vertices): rows of every [M][..] array are in LOCALITY order, not in
+    // first-touch order.  Both maps are null when the two coincide.  The public introspection calls translate.
+    int32_t *vfirst;        // [M] first-touch candidate (pixel*(d+1)+remainder) per vertex: build-time only, may be null
+    int32_t *ft_of_int;     // [M] first-touch id of internal vertex i
+    int32_t *int_of_ft;     // [M] internal id (row) of first-touch vertex v
 
     // pixel chunks ("tiles") for the LDS-staged splat / slice (phl_tiles.hip)
     int P;                  // pixels per chunk
@@ -140,9 +145,10 @@ int phl_ensure_csr(phl_lattice *lat, hipStream_t st);  // pixel-sorted lists, bu
 namespace std { class mutex; }
 std::mutex *phl_csr_mutex(phl_lattice *lat);
 int phl_add_vertices_device(phl_lattice *lat, const int16_t *keys_host, int64_t count, int32_t *vid_host, hipStream_t st);
+int phl_rebuild_table_and_neighbors(phl_lattice *lat, hipStream_t st);
 
 // ---- implemented in phl_tiles.hip ----
-int phl_tiles_build(phl_lattice *lat, const float *ref, int64_t rs, int64_t cs, hipStream_t st);
+int phl_tiles_build(phl_lattice *lat, const float *ref, int64_t rs, int64_t cs, hipStream_t st);   // + renumbering, tables
 int phl_tiles_link_vertices(phl_lattice *lat, hipStream_t st);
 int phl_tiles_free(phl_lattice *lat);
 int phl_tiles_lprs(const phl_lattice *lat, int vd, int for_slice);  // -1: LDS-staged path unavailable

@@ -83,6 +83,67 @@ __global__ __launch_bounds__(256) void k_cell_ids(const float *__restrict__ ref,
     if (active) cell[p] = c;
 }
 
+// ---- locality renumbering of the vertices ----------------------------------------------------------------
+// First-touch ids follow the pixel order: for an image, raster order, so a vertex and the blur neighbours a few
+// pixels above / below it are a few image ROWS apart in every [M][vd] array (2 MB at 2048 pixels per row) and
+// the 9-row stencil of a blur pass outruns the 4 MiB L2 of an XCD (58 % hits).  Internally the vertices are
+// therefore numbered strip by strip: the grid of the two widest feature dimensions is cut into 8 strips along
+// the wider one, a vertex's home cell is the cell of its first-touch pixel, and vertices are
+// ordered by (strip, cell row, cell inside the strip), first-touch order inside a cell (stable sort).  A blur
+// launch gives every XCD a contiguous eighth of the ids = about one strip, walked row by row, so that both the
+// own-row stream and the stencil stay local.  Public introspection keeps the reference's first-touch numbering
+// (phl_get_keys & co translate); rows of caller-visible vertex buffers are in internal order
+// (phl_get_vertex_order).
+__global__ __launch_bounds__(256) void k_vertex_home(const phl_replay_t *__restrict__ replay, int N, int dp1,
+                                                     const int *__restrict__ cell, int *vhome)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= N) return;
+    const int v = replay[e].vid, c = cell[e / dp1];
+    // the value only ever decreases, so a stale read can at worst cause a redundant atomic; in pixel order the
+    // first toucher usually already holds the minimum and most candidates skip the atomic
+    if (c < *reinterpret_cast<volatile int *>(&vhome[v])) atomicMin(&vhome[v], c);
+}
+
+// home cell from the first-touch candidate (the common case: one thread per vertex, no atomics)
+__global__ __launch_bounds__(256) void k_vertex_home_first(const int *__restrict__ vfirst, int M, int dp1,
+                                                           const int *__restrict__ cell, int *__restrict__ vhome)
+{
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v < M) vhome[v] = cell[vfirst[v] / dp1];
+}
+
+__global__ __launch_bounds__(256) void k_strip_key(const int *__restrict__ vhome, int M, int nca, int ncb, int stripw,
+                                                   int *__restrict__ key)
+{
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= M) return;
+    const int c = vhome[v];
+    const int ca = c % nca, cb = c / nca;
+    key[v] = ((ca / stripw) * ncb + cb) * stripw + ca % stripw;
+}
+
+__global__ __launch_bounds__(256) void k_invert_perm(const int *__restrict__ perm, int M, int *__restrict__ inv)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < M) inv[perm[i]] = i;
+}
+
+__global__ __launch_bounds__(256) void k_permute_keys(const int16_t *__restrict__ in, const int *__restrict__ ft_of_int, int M,
+                                                      int d, int16_t *__restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)M * d) return;
+    const int v = (int)(i / d), c = (int)(i - (int64_t)v * d);
+    out[i] = in[(int64_t)ft_of_int[v] * d + c];
+}
+
+__global__ __launch_bounds__(256) void k_relabel_replay(phl_replay_t *__restrict__ replay, int N, const int *__restrict__ int_of_ft)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < N) replay[e].vid = int_of_ft[replay[e].vid];
+}
+
 // vertex of every slot without the sole mark: the sort key of the vertex -> slots lists
 __global__ __launch_bounds__(256) void k_slot_keys(const int *__restrict__ slot_vert, int S, int *__restrict__ key)
 {
@@ -873,7 +934,10 @@ int phl_tiles_build(phl_lattice *lat, const float *ref, int64_t rs, int64_t cs, 
         if (v >= 16 && v <= P) P = v;
     }
     lat->P = P;
-    if (n == 0) return phl_tiles_link_vertices(lat, st);
+    if (n == 0) {
+        const int rc0 = phl_rebuild_table_and_neighbors(lat, st);
+        return rc0 ? rc0 : phl_tiles_link_vertices(lat, st);
+    }
     int sortn = 512;
     while (sortn < P * dp1) sortn <<= 1;
 
@@ -937,6 +1001,47 @@ int phl_tiles_build(phl_lattice *lat, const float *ref, int64_t rs, int64_t cs, 
     rc = stable_sort_perm(cell, n, ncell, lat->pix_order, tmp, st);
     if (rc) return rc;
 
+    // 2b. internal vertex numbering (see k_vertex_home), then the key -> vertex table and the blur neighbours
+    {
+        static const bool renumber = !(getenv("PHL_RENUMBER") && atoi(getenv("PHL_RENUMBER")) == 0);
+        const int M = (int)lat->M;
+        if (renumber && ncell > 8 && M > 1) {
+            int *vhome, *vkey;
+            PHL_HIP(tmp.get(&vhome, (size_t)M));
+            PHL_HIP(tmp.get(&vkey, (size_t)M));
+            if (lat->vfirst) {
+                hipLaunchKernelGGL(k_vertex_home_first, dim3((M + 255) / 256), dim3(256), 0, st, lat->vfirst, M, dp1, cell, vhome);
+            } else {        // reference-table mode with duplicates: smallest cell among the touching pixels
+                hipLaunchKernelGGL(k_fill_i32, dim3(256), dim3(256), 0, st, vhome, (int64_t)M, 0x7FFFFFFF);
+                hipLaunchKernelGGL(k_vertex_home, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, lat->replay, (int)N, dp1, cell, vhome);
+            }
+            static const int nstrips = getenv("PHL_STRIPS") ? atoi(getenv("PHL_STRIPS")) : 8;
+            const int stripw = (nca + nstrips - 1) / nstrips;
+            hipLaunchKernelGGL(k_strip_key, dim3((M + 255) / 256), dim3(256), 0, st, vhome, M, nca, ncb, stripw, vkey);
+            PHL_HIP(hipGetLastError());
+            PHL_HIP(phl_dev_malloc((void **)&lat->ft_of_int, sizeof(int) * (size_t)M));
+            PHL_HIP(phl_dev_malloc((void **)&lat->int_of_ft, sizeof(int) * (size_t)M));
+            rc = stable_sort_perm(vkey, M, (int64_t)(nstrips + 1) * ncb * stripw, lat->ft_of_int, tmp, st);
+            if (rc) return rc;
+            hipLaunchKernelGGL(k_invert_perm, dim3((M + 255) / 256), dim3(256), 0, st, lat->ft_of_int, M, lat->int_of_ft);
+            int16_t *vkeys_new;
+            PHL_HIP(phl_dev_malloc((void **)&vkeys_new, sizeof(int16_t) * (size_t)M * d));
+            hipLaunchKernelGGL(k_permute_keys, dim3((unsigned)(((int64_t)M * d + 255) / 256)), dim3(256), 0, st, lat->vkeys,
+                               lat->ft_of_int, M, d, vkeys_new);
+            hipLaunchKernelGGL(k_relabel_replay, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, lat->replay, (int)N,
+                               lat->int_of_ft);
+            PHL_HIP(hipGetLastError());
+            PHL_HIP(phl_dev_free(lat->vkeys));       // (same stream: the gather above is ordered before any reuse)
+            lat->vkeys = vkeys_new;
+        }
+        if (lat->vfirst) {
+            PHL_HIP(phl_dev_free(lat->vfirst));      // build-time only (same stream: ordered behind its reader)
+            lat->vfirst = nullptr;
+        }
+        rc = phl_rebuild_table_and_neighbors(lat, st);
+        if (rc) return rc;
+    }
+
     // 3. per-chunk local vertex lists, segments and local indices
     nchunks = (n + P - 1) / P;
     lat->nchunks = nchunks;
@@ -995,6 +1100,9 @@ int phl_tiles_build(phl_lattice *lat, const float *ref, int64_t rs, int64_t cs, 
     }
     rc = phl_tiles_link_vertices(lat, st);
     if (rc) return rc;
+    lat->table_bytes = (int64_t)(sizeof(int16_t) * (size_t)lat->M * d + sizeof(phl_replay_t) * (size_t)N +
+                                 sizeof(int32_t) * (size_t)lat->M * (d + 1) * 2 + sizeof(int32_t) * (size_t)lat->M * ((d + 1) / 2) * 8 +
+                                 sizeof(int) * ((size_t)lat->table_mask + 1) + (lat->int_of_ft ? 2 * sizeof(int) * (size_t)lat->M : 0));
     lat->tile_bytes = (int64_t)(sizeof(int) * ((size_t)n + nchunks + 1 + 3 * ((size_t)S + 1) + (size_t)lat->M + 1) +
                                 sizeof(phl_contrib_t) * ((size_t)N + S + 1) + sizeof(unsigned short) * (size_t)N);
     return PHL_OK;

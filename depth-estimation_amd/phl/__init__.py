@@ -86,6 +86,7 @@ def load_library():
         lib.phl_stream_copy.argtypes = [vp, vp, i64, vp]
         lib.phl_cost_volume.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, vp, i64, vp]
         lib.phl_get_keys.argtypes = [vp, vp]
+        lib.phl_get_vertex_order.argtypes = [vp, vp]
         lib.phl_get_replay.argtypes = [vp, vp, vp]
         lib.phl_get_neighbors.argtypes = [vp, vp]
         lib.phl_get_splat_lists.argtypes = [vp, vp, vp, vp]
@@ -272,18 +273,41 @@ class Lattice:
 
     def add_vertices(self, keys):
         """Row-band support: append neighbouring-band vertices (distinct int16 keys [K, d]) as
-        ghosts; returns the local vertex id of every key (int32 [K]).  Updates ``M``."""
+        ghosts; returns, for every key, its ROW in the vertex buffers (int32 [K]).  Updates ``M``."""
         keys = np.ascontiguousarray(keys, np.int16).reshape(-1, self.d)
         vid = np.empty(len(keys), np.int32)
         with torch.cuda.device(self.device):
             _check(load_library().phl_add_vertices(self._h, keys.ctypes.data_as(C.c_void_p), len(keys),
                                                    vid.ctypes.data_as(C.c_void_p), _stream(self.device)))
         self.M = int(load_library().phl_num_vertices(self._h))
+        self._rows = None
         return vid
 
     @property
     def M_local(self):
         return int(load_library().phl_num_local_vertices(self._h))
+
+    # ---- vertex numbering ---------------------------------------------------------------------
+    # keys() / replay() / neighbors() / splat_lists() speak the reference's first-touch vertex ids.  The ROWS of
+    # the [M, vd] buffers splat / blur / slice exchange are in the library's internal (locality) order.
+    def vertex_rows(self):
+        """int64 device tensor [M]: row of first-touch vertex v in the vertex buffers (cached)."""
+        hit = getattr(self, "_rows", None)
+        if hit is None or hit.numel() != self.M:
+            out = np.empty(self.M, np.int32)
+            _check(load_library().phl_get_vertex_order(self._h, out.ctypes.data_as(C.c_void_p)))
+            hit = self._rows = torch.from_numpy(out.astype(np.int64)).to(self.device)
+        return hit
+
+    def to_first_touch(self, vert):
+        """Vertex buffer with its rows re-ordered to first-touch vertex order (parity checks against the CPU path)."""
+        return vert.index_select(0, self.vertex_rows())
+
+    def from_first_touch(self, vert_ft):
+        """Inverse of to_first_touch: rows in first-touch order -> a buffer in internal row order."""
+        out = torch.empty_like(vert_ft)
+        out.index_copy_(0, self.vertex_rows(), vert_ft)
+        return out
 
     # ---- introspection (host copies) --------------------------------------------------------
     def keys(self):

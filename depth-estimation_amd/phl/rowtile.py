@@ -139,7 +139,9 @@ class RowBand:
         for peer in (rank - 1, rank + 1):
             if 0 <= peer < world:
                 v = np.nonzero((ypos >= span[peer][0] - reach) & (ypos <= span[peer][1] + reach))[0]
-                self.sides[peer] = dict(send_idx=torch.from_numpy(v.astype(np.int64)).to(device))
+                # keys() numbers vertices in first-touch order; the vertex buffers' rows may be ordered differently
+                rows = self.eng.vertex_rows().cpu().numpy()[v] if hasattr(self.eng, "vertex_rows") else v
+                self.sides[peer] = dict(send_idx=torch.from_numpy(np.asarray(rows).astype(np.int64)).to(device))
                 self._send_keys[peer] = torch.from_numpy(np.ascontiguousarray(keys[v]))
         self._t_build = time.time() - t0
 

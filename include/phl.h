@@ -123,7 +123,7 @@ int phl_trim_scratch(void);
  * local vertex id of key i (an existing vertex when this band already has it, else a new id
  * >= phl_num_local_vertices()).  No reference counterpart: the reference is single-process. */
 int phl_add_vertices(phl_lattice *lat, const int16_t *keys_host, int64_t count, int32_t *vid_host,
-                     phl_stream stream);
+                     phl_stream stream);   /* vid_host: ROW of each key in the [M][vd] vertex buffers */
 int64_t phl_num_local_vertices(const phl_lattice *lat); /* vertices created by this lattice's own pixels */
 
 /* Pre-size everything phl_filter(vd) needs (the [M][vd] ping-pong buffers, the partial-row buffer
@@ -226,7 +226,12 @@ int phl_stream_copy(const float *src_dev, float *dst_dev, int64_t n_floats, phl_
  * several chunks, [5]=1 if the staged splat / [6]=slice would be chosen for this vd. */
 int phl_tile_stats(const phl_lattice *lat, int vd, int64_t out[7]);
 
-/* ---- introspection for parity tests (synchronous device->host copies) --------------------- */
+/* ---- introspection for parity tests (synchronous device->host copies) ---------------------
+ * Vertex ids in these calls are the reference's: first-touch (insertion) order, the numbering its hash table
+ * produces.  ROWS of the [M][vd] vertex buffers the stage-level calls take are in the library's internal
+ * (locality) order instead: row_of_vertex[v] = row that holds first-touch vertex v; phl_add_vertices returns rows.
+ * Ghost vertices come last in both numberings. */
+int phl_get_vertex_order(phl_lattice *lat, int32_t *row_of_vertex_host /* [M] */);
 int phl_get_keys(phl_lattice *lat, int16_t *keys_host /* [M][d] */);
 int phl_get_replay(phl_lattice *lat, int32_t *vid_host /* [n][d+1] */, float *w_host /* [n][d+1] */);
 int phl_get_neighbors(phl_lattice *lat, int32_t *nbr_host /* [d+1][M][2], -1 = absent */);

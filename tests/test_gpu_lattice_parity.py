@@ -84,14 +84,15 @@ def test_filter_stages_match_oracle(phl, n, d, vd, scale):
     L = phl.Lattice(torch.from_numpy(ref).cuda())
     s = torch.from_numpy(src).cuda()
     # pixel-ordered gather splat: the reference's summation order, bit for bit
+    ft = lambda v: L.to_first_touch(v).cpu().numpy()     # vertex buffers are in internal row order; the oracle's in first-touch order
     vs = L.splat(s, exact=True)
-    assert np.array_equal(vs.cpu().numpy().view(np.uint32), splat_o.view(np.uint32)), "splat bitwise"
+    assert np.array_equal(ft(vs).view(np.uint32), splat_o.view(np.uint32)), "splat bitwise"
     # default LDS-staged chunk splat: per-chunk partial sums -> fp32 rounding only
     vt = L.splat(s)
-    assert scaled_err(vt.cpu().numpy(), splat_o) <= 1e-5
-    assert rel_err(L.splat(s, no_tiles=True).cpu().numpy(), splat_o) == 0.0
+    assert scaled_err(ft(vt), splat_o) <= 1e-5
+    assert rel_err(ft(L.splat(s, no_tiles=True)), splat_o) == 0.0
     vb = L.blur(vs)
-    assert np.array_equal(vb.cpu().numpy().view(np.uint32), blur_o.view(np.uint32)), "blur bitwise"
+    assert np.array_equal(ft(vb).view(np.uint32), blur_o.view(np.uint32)), "blur bitwise"
     for no_tiles in (False, True):                  # LDS-staged and plain gather slice: both bit-exact
         out = L.slice(vb, exact=True, no_tiles=no_tiles).cpu().numpy()
         assert np.array_equal(out.view(np.uint32), out_o.view(np.uint32)), f"slice bitwise (no_tiles={no_tiles})"
@@ -129,10 +130,11 @@ def test_golden_lattice_vectors(phl, golden_dir):
         assert np.array_equal(w.view(np.uint32), g["replay_w"].view(np.uint32)), f
         s = torch.from_numpy(g["src"]).cuda()
         vs = L.splat(s, exact=True)
-        assert np.array_equal(vs.cpu().numpy()[order].view(np.uint32), g["splat_sorted"].view(np.uint32)), f
-        assert scaled_err(L.splat(s).cpu().numpy()[order], g["splat_sorted"]) <= 1e-5, f
+        ft = lambda v: L.to_first_touch(v).cpu().numpy()
+        assert np.array_equal(ft(vs)[order].view(np.uint32), g["splat_sorted"].view(np.uint32)), f
+        assert scaled_err(ft(L.splat(s))[order], g["splat_sorted"]) <= 1e-5, f
         vb = L.blur(vs)
-        assert np.array_equal(vb.cpu().numpy()[order].view(np.uint32), g["blur_sorted"].view(np.uint32)), f
+        assert np.array_equal(ft(vb)[order].view(np.uint32), g["blur_sorted"].view(np.uint32)), f
         out = phl.filter(s, torch.from_numpy(g["ref"]).cuda()).cpu().numpy()
         assert scaled_err(out, g["out"]) <= 1e-5, f
         out = L.filter(s, exact=True).cpu().numpy()
@@ -409,9 +411,9 @@ def test_reference_table_mode_equals_the_reference_engine(phl, n, d, vd, scale, 
     assert np.array_equal(L.neighbors(), O.neighbors())
     s = torch.from_numpy(src).cuda()
     vs = L.splat(s, exact=True)
-    assert np.array_equal(vs.cpu().numpy().view(np.uint32), splat_o.view(np.uint32))
+    assert np.array_equal(L.to_first_touch(vs).cpu().numpy().view(np.uint32), splat_o.view(np.uint32))
     vb = L.blur(vs)
-    assert np.array_equal(vb.cpu().numpy().view(np.uint32), blur_o.view(np.uint32))
+    assert np.array_equal(L.to_first_touch(vb).cpu().numpy().view(np.uint32), blur_o.view(np.uint32))
     assert np.array_equal(L.filter(s, exact=True).cpu().numpy().view(np.uint32), out_o.view(np.uint32))
     assert scaled_err(L.filter(s).cpu().numpy(), out_o) <= 1e-5
     if po.reference_available():          # the reference engine itself, when its binary travelled with the tree
@@ -500,8 +502,9 @@ def test_fused_blur_equals_axis_by_axis(phl, d):
         a, b = b, a
     fused = L.blur(v0.clone())
     assert torch.equal(fused, a)
-    want = po.Oracle(ref).blur(v0.cpu().numpy())
-    assert np.array_equal(fused.cpu().numpy().view(np.uint32), want.view(np.uint32))
+    want = po.Oracle(ref).blur(L.to_first_touch(v0).cpu().numpy())     # the oracle numbers vertices in first-touch order
+    assert np.array_equal(L.to_first_touch(fused).cpu().numpy().view(np.uint32), want.view(np.uint32))
+    assert torch.equal(L.from_first_touch(L.to_first_touch(v0)), v0)
 
 
 def test_more_than_two_million_vertices(phl):

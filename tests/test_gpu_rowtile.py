@@ -58,10 +58,11 @@ def test_add_vertices_semantics():
     keys = L.keys()
     M0 = L.M
     q = np.concatenate([keys[10:20], keys[:3] + np.int16(100), keys[50:52]])       # existing, new, existing
-    ids = L.add_vertices(q)
-    oids = O.add_vertices(q)
-    assert np.array_equal(ids, oids) and L.M == O.M == M0 + 3 and L.M_local == M0
-    assert np.array_equal(ids[:10], np.arange(10, 20)) and np.array_equal(ids[10:13], np.arange(M0, M0 + 3))
+    ids = L.add_vertices(q)                   # ROWS of the vertex buffers
+    oids = O.add_vertices(q)                  # first-touch vertex ids
+    rows = L.vertex_rows().cpu().numpy()
+    assert np.array_equal(ids, rows[oids]) and L.M == O.M == M0 + 3 and L.M_local == M0
+    assert np.array_equal(oids[:10], np.arange(10, 20)) and np.array_equal(ids[10:13], np.arange(M0, M0 + 3))
     assert np.array_equal(L.keys(), O.keys()) and np.array_equal(L.neighbors(), O.neighbors())
     src = rng.standard_normal((3000, 8)).astype(np.float32)
     a = L.filter(torch.from_numpy(src).cuda(), exact=True).cpu().numpy()
