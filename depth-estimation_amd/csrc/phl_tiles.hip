@@ -945,6 +945,12 @@ int phl_tiles_build(phl_lattice *lat, const float *ref, int64_t rs, int64_t cs, 
     int nchunks = 0;
     int64_t S = 0;
     const int64_t N = lat->N;
+    // arrays replaced while launches that read them may still be in flight: released only behind the stream
+    // synchronisation at the end of this phase (the block cache may hand a freed block to another thread's build)
+    struct deferred_t {
+        void *p[2] = {nullptr, nullptr};
+        ~deferred_t() { for (void *q : p) if (q) (void)phl_dev_free(q); }
+    } deferred;
     {   // temporaries of the chunk build go back to the scratch cache before the vertex lists are linked
     temp_pool tmp;
     // 1. feature ranges -> the two widest dimensions -> uniform grid with ~P pixels per cell
@@ -1031,13 +1037,11 @@ int phl_tiles_build(phl_lattice *lat, const float *ref, int64_t rs, int64_t cs, 
             hipLaunchKernelGGL(k_relabel_replay, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, lat->replay, (int)N,
                                lat->int_of_ft);
             PHL_HIP(hipGetLastError());
-            PHL_HIP(phl_dev_free(lat->vkeys));       // (same stream: the gather above is ordered before any reuse)
+            deferred.p[0] = lat->vkeys;              // still being read by the gather above
             lat->vkeys = vkeys_new;
         }
-        if (lat->vfirst) {
-            PHL_HIP(phl_dev_free(lat->vfirst));      // build-time only (same stream: ordered behind its reader)
-            lat->vfirst = nullptr;
-        }
+        deferred.p[1] = lat->vfirst;                 // build-time only
+        lat->vfirst = nullptr;
         rc = phl_rebuild_table_and_neighbors(lat, st);
         if (rc) return rc;
     }

@@ -111,6 +111,23 @@ int main()
         hipEventElapsedTime(&ms, a, b);
         printf("copy of %5ld MiB (nt, %d blocks): %7.1f GB/s (R+W)\n", mb, blocks, 2.0 * m4 * 16 * 20 / (ms * 1e-3) / 1e9);
     }
+    // relative placement of source and destination: both on 2 MiB boundaries vs the destination shifted
+    {
+        vf4 *big;
+        hipMalloc(&big, n4 * 16 + (64 << 20));
+        for (long off : {0L, 256L, 1024L, 4096L, 16384L, 65536L, 1L << 20, (1L << 20) + 4096}) {
+            vf4 *dd = (vf4 *)((char *)big + off);
+            float ms;
+            k_copy<3, 4><<<65536, 256>>>(s, dd, n4);
+            hipDeviceSynchronize();
+            hipEventRecord(a);
+            for (int r = 0; r < 5; r++) k_copy<3, 4><<<65536, 256>>>(s, dd, n4);
+            hipEventRecord(b); hipEventSynchronize(b);
+            hipEventElapsedTime(&ms, a, b);
+            printf("copy, dst shifted by %8ld B from a 2 MiB boundary: %7.1f GB/s (R+W)   (src %p dst %p)\n", off, 2.0 * n4 * 16 * 5 / (ms * 1e-3) / 1e9, (void *)s, (void *)dd);
+        }
+        hipFree(big);
+    }
     hipEventRecord(a);
     for (int r = 0; r < 5; r++) hipMemcpyAsync(d, s, n4 * 16, hipMemcpyDeviceToDevice, 0);
     hipEventRecord(b); hipEventSynchronize(b);
