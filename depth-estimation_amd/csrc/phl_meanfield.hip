@@ -169,21 +169,7 @@ __global__ __launch_bounds__(256, 2) void k_compat_softmax(const float *__restri
     extern __shared__ __attribute__((aligned(16))) float lds[];   // 2 x [L labels][32 k], 16-byte slots XOR-swizzled
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 31, h = lane >> 5;
-    const int64_t row0 = (int64_t)blockIdx.x * 128 + wave * 32;
-    const int64_t arow = min(row0 + i, n - 1);          // clamped: loads stay in bounds, stores are predicated
-    const float *xrow = X + arow * x_rs + 4 * h;
-
-    // The accumulators START as the E0 tile (the MFMA's C input), so E = E0 + X @ Mu comes out of the matrix
-    // pipe itself and the epilogue has no loads left to wait for.  C/D map: column = lane&31,
-    // row = (reg&3) + 8*(reg>>2) + 4*(lane>>5): for one register the 32 lanes of a half-wave hold 32
-    // consecutive labels of one pixel (128 B per access).
-    f32x16 acc[NT];
-#pragma unroll
-    for (int r = 0; r < 16; r++) {
-        const int64_t pr = min(row0 + (r & 3) + 8 * (r >> 2) + 4 * h, n - 1);
-#pragma unroll
-        for (int t = 0; t < NT; t++) acc[t][r] = E0[pr * e_rs + 32 * t + i];
-    }
+    const int64_t ntiles = (n + 127) / 128;
 
     // Chunk loader (LDS-DMA, no staging registers): a chunk is L labels x 8 slots of 16 B; one wave-instruction
     // fills 64 consecutive slots = 8 labels.  LDS stays linear (that is all the DMA can write); the bank
@@ -199,92 +185,138 @@ __global__ __launch_bounds__(256, 2) void k_compat_softmax(const float *__restri
             glds16(MuT + (int64_t)lab * L + 32 * kc + 4 * part, lds + buf * (L * 32) + g0 * 4);
         }
     };
-    float4 a_cur[4], a_nxt[4];
+    auto x_row = [&](int64_t tile) {             // this lane's X row of a tile (clamped: loads stay in bounds)
+        return X + min(tile * 128 + wave * 32 + i, n - 1) * x_rs + 4 * h;
+    };
+    auto e0_at = [&](int64_t tile, int r, int t) {
+        const int64_t pr = min(tile * 128 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, n - 1);
+        return E0[pr * e_rs + 32 * t + i];
+    };
+
+    // PERSISTENT workgroups (two per CU) walk the 128-pixel tiles; everything the NEXT tile needs before its first
+    // MFMA is requested while the current tile is in its epilogue: Mu's chunk 0 (both LDS buffers are idle then),
+    // the X fragments of chunk 0, and -- register by register, as soon as a row has been stored -- the E0 tile,
+    // which goes straight into the accumulators (the MFMA's C input: E = E0 + X @ Mu comes out of the matrix pipe
+    // itself and the epilogue has no loads to wait for).  C/D map: column = lane&31,
+    // row = (reg&3) + 8*(reg>>2) + 4*(lane>>5): for one register the 32 lanes of a half-wave hold 32 consecutive
+    // labels of one pixel (128 B per access).
+    int64_t tile = blockIdx.x;
+    if (tile >= ntiles) return;
+    f32x16 acc[NT];
 #pragma unroll
-    for (int q = 0; q < 4; q++) a_nxt[q] = *reinterpret_cast<const float4 *>(xrow + 8 * q);
+    for (int r = 0; r < 16; r++)
+#pragma unroll
+        for (int t = 0; t < NT; t++) acc[t][r] = e0_at(tile, r, t);
+    float4 a_cur[4], a_nxt[4];
+    {
+        const float *xrow = x_row(tile);
+#pragma unroll
+        for (int q = 0; q < 4; q++) a_nxt[q] = *reinterpret_cast<const float4 *>(xrow + 8 * q);
+    }
     load_mu(0, 0);
     __syncthreads();
     const int sw = (i >> 1) & 7;            // the swizzle of the labels this lane reads (32t + i)
-    for (int kc = 0; kc < NT; kc++) {
+    for (; tile < ntiles; tile += gridDim.x) {
+        const float *xrow = x_row(tile);
+        const int64_t row0 = tile * 128 + wave * 32;
+        for (int kc = 0; kc < NT; kc++) {
 #pragma unroll
-        for (int q = 0; q < 4; q++) a_cur[q] = a_nxt[q];
-        const bool more = kc + 1 < NT;       // uniform
-        if (more) {
-            // next chunk: the other buffer was last read in chunk kc-1, behind the previous barrier
-            load_mu(kc + 1, (kc + 1) & 1);
+            for (int q = 0; q < 4; q++) a_cur[q] = a_nxt[q];
+            const bool more = kc + 1 < NT;       // uniform
+            if (more) {
+                // next chunk: the other buffer was last read in chunk kc-1, behind the previous barrier
+                load_mu(kc + 1, (kc + 1) & 1);
 #pragma unroll
-            for (int q = 0; q < 4; q++) a_nxt[q] = *reinterpret_cast<const float4 *>(xrow + 32 * (kc + 1) + 8 * q);
+                for (int q = 0; q < 4; q++) a_nxt[q] = *reinterpret_cast<const float4 *>(xrow + 32 * (kc + 1) + 8 * q);
+            }
+            // keep the prefetch HERE: left alone, the scheduler sinks these loads to the end of the chunk (their
+            // results are not needed before the next one) and the wave then waits out a full HBM miss per chunk
+            __builtin_amdgcn_sched_barrier(0);
+            const float *bbase = lds + (kc & 1) * (L * 32) + i * 32;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                float4 b[NT];
+                const int slot = ((2 * q + h) ^ sw) * 4;
+#pragma unroll
+                for (int t = 0; t < NT; t++) b[t] = *reinterpret_cast<const float4 *>(bbase + t * 32 * 32 + slot);
+#pragma unroll
+                for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[q].x, b[t].x, acc[t], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[q].y, b[t].y, acc[t], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[q].z, b[t].z, acc[t], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[q].w, b[t].w, acc[t], 0, 0, 0);
+            }
+            __syncthreads();                     // (drains the DMA of the next chunk: issued 8k MFMA cycles ago)
         }
-        // keep the prefetch HERE: left alone, the scheduler sinks these loads to the end of the chunk (their
-        // results are not needed before the next one) and the wave then waits out a full HBM miss per chunk
-        __builtin_amdgcn_sched_barrier(0);
-        const float *bbase = lds + (kc & 1) * (L * 32) + i * 32;
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            float4 b[NT];
-            const int slot = ((2 * q + h) ^ sw) * 4;
-#pragma unroll
-            for (int t = 0; t < NT; t++) b[t] = *reinterpret_cast<const float4 *>(bbase + t * 32 * 32 + slot);
-#pragma unroll
-            for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[q].x, b[t].x, acc[t], 0, 0, 0);
-#pragma unroll
-            for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[q].y, b[t].y, acc[t], 0, 0, 0);
-#pragma unroll
-            for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[q].z, b[t].z, acc[t], 0, 0, 0);
-#pragma unroll
-            for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[q].w, b[t].w, acc[t], 0, 0, 0);
-        }
-        __syncthreads();                     // (drains the DMA of the next chunk: issued 8k MFMA cycles ago)
-    }
 
-    // epilogue on the accumulators (acc = E now).  The 16 pixel rows a lane holds are reduced TOGETHER: sixteen
-    // independent butterfly chains per step, so the cross-lane latency is paid once per step, not per row.
-    if (LOGITS) {              // CRFasRNN returns -E of the last iteration, not Q (crf_module.py:103)
+        // ---- next tile's inputs, requested before this tile's epilogue -------------------------------------
+        const int64_t nxt = tile + gridDim.x;
+        const bool has_next = nxt < ntiles;      // uniform
+        if (has_next) {
+            load_mu(0, 0);                       // every wave is past the last barrier: both buffers are idle
+            const float *xn = x_row(nxt);
 #pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const int64_t prow = row0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            if (prow < n) {
+            for (int q = 0; q < 4; q++) a_nxt[q] = *reinterpret_cast<const float4 *>(xn + 8 * q);
+        }
+
+        // ---- epilogue on the accumulators (acc = E now) ------------------------------------------------------
+        // The 16 pixel rows a lane holds are reduced TOGETHER: sixteen independent butterfly chains per step, so the
+        // cross-lane latency is paid once per step, not per row.
+        if (LOGITS) {              // CRFasRNN returns -E of the last iteration, not Q (crf_module.py:103)
 #pragma unroll
-                for (int t = 0; t < NT; t++) out[prow * o_rs + 32 * t + i] = -acc[t][r];
+            for (int r = 0; r < 16; r++) {
+                const int64_t prow = row0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (prow < n) {
+#pragma unroll
+                    for (int t = 0; t < NT; t++) out[prow * o_rs + 32 * t + i] = -acc[t][r];
+                }
+                if (has_next) {
+#pragma unroll
+                    for (int t = 0; t < NT; t++) acc[t][r] = e0_at(nxt, r, t);
+                }
+            }
+        } else {
+            float m[16], sum[16];
+#pragma unroll
+            for (int r = 0; r < 16; r++) {       // softmax(-E): shift by the row MINIMUM of E
+                m[r] = INFINITY;
+#pragma unroll
+                for (int t = 0; t < NT; t++) m[r] = fminf(m[r], acc[t][r]);
+            }
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1)     // the 32 lanes of this half-wave
+#pragma unroll
+                for (int r = 0; r < 16; r++) m[r] = fminf(m[r], __shfl_xor(m[r], o));
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                sum[r] = 0.f;
+#pragma unroll
+                for (int t = 0; t < NT; t++) {   // exp(-(E - min)) = exp2((min - E) * log2 e)
+                    acc[t][r] = __builtin_amdgcn_exp2f((m[r] - acc[t][r]) * 1.4426950408889634f);
+                    sum[r] += acc[t][r];
+                }
+            }
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1)
+#pragma unroll
+                for (int r = 0; r < 16; r++) sum[r] += __shfl_xor(sum[r], o);
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int64_t prow = row0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const float inv = 1.0f / sum[r];
+                if (prow < n) {
+#pragma unroll
+                    for (int t = 0; t < NT; t++) out[prow * o_rs + 32 * t + i] = acc[t][r] * inv;
+                }
+                if (has_next) {                  // this row's registers are free: the next tile's E0 goes in
+#pragma unroll
+                    for (int t = 0; t < NT; t++) acc[t][r] = e0_at(nxt, r, t);
+                }
             }
         }
-        return;
-    }
-    float m[16], sum[16];
-#pragma unroll
-    for (int r = 0; r < 16; r++) {
-        m[r] = -INFINITY;
-#pragma unroll
-        for (int t = 0; t < NT; t++) {
-            acc[t][r] = -acc[t][r];
-            m[r] = fmaxf(m[r], acc[t][r]);
-        }
-    }
-#pragma unroll
-    for (int o = 16; o > 0; o >>= 1)                     // the 32 lanes of this half-wave
-#pragma unroll
-        for (int r = 0; r < 16; r++) m[r] = fmaxf(m[r], __shfl_xor(m[r], o));
-#pragma unroll
-    for (int r = 0; r < 16; r++) {
-        sum[r] = 0.f;
-#pragma unroll
-        for (int t = 0; t < NT; t++) {
-            acc[t][r] = __builtin_amdgcn_exp2f((acc[t][r] - m[r]) * 1.4426950408889634f);
-            sum[r] += acc[t][r];
-        }
-    }
-#pragma unroll
-    for (int o = 16; o > 0; o >>= 1)
-#pragma unroll
-        for (int r = 0; r < 16; r++) sum[r] += __shfl_xor(sum[r], o);
-#pragma unroll
-    for (int r = 0; r < 16; r++) {
-        const int64_t prow = row0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        const float inv = 1.0f / sum[r];
-        if (prow < n) {
-#pragma unroll
-            for (int t = 0; t < NT; t++) out[prow * o_rs + 32 * t + i] = acc[t][r] * inv;
-        }
+        __syncthreads();                         // next tile's chunk 0 has landed in LDS (and its E0 / X in registers)
     }
 }
 
@@ -326,7 +358,9 @@ int phl_compat_softmax(const float *E0, int64_t e_rs, const float *X, int64_t x_
         return PHL_ERR_UNSUPPORTED;
     }
     hipStream_t st = (hipStream_t)stream;
-    const unsigned grid = (unsigned)((n + 127) / 128);
+    // persistent workgroups: two per CU (256 CUs), each walking tiles blockIdx.x, blockIdx.x + grid, ...
+    const int64_t ntiles = (n + 127) / 128;
+    const unsigned grid = (unsigned)(ntiles < 512 ? ntiles : 512);
     const size_t lds = (size_t)2 * L * 32 * sizeof(float);
     const bool logits = (flags & PHL_COMPAT_LOGITS) != 0;     // LDS is 2*L*128 B <= 64 KiB: no attribute needed
 #define PHL_CS(NT_)                                                                                                       \
