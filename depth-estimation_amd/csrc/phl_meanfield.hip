@@ -158,12 +158,14 @@ __device__ __forceinline__ void glds16(const float *g, float *l)
                                      (__attribute__((address_space(3))) void *)l, 16, 0, 0);
 }
 
-template <int NT, bool LOGITS>
+template <int NT, bool LOGITS, bool PAD>
 __global__ __launch_bounds__(256, 2) void k_compat_softmax(const float *__restrict__ E0, int64_t e_rs,
                                                            const float *__restrict__ X, int64_t x_rs,
                                                            const float *__restrict__ MuT, float *__restrict__ out,
-                                                           int64_t o_rs, int64_t n)
+                                                           int64_t o_rs, int64_t n, int Lr)
 {
+    // Lr = the real label count (a multiple of 4, <= L): columns Lr..L-1 are padding -- MuT is zero there, E0 reads
+    // as +inf (so exp gives 0 and the row minimum ignores them), X reads as 0, nothing is stored.
     typedef float f32x16 __attribute__((ext_vector_type(16)));
     constexpr int L = 32 * NT;
     extern __shared__ __attribute__((aligned(16))) float lds[];   // 2 x [L labels][32 k], 16-byte slots XOR-swizzled
@@ -190,7 +192,15 @@ __global__ __launch_bounds__(256, 2) void k_compat_softmax(const float *__restri
     };
     auto e0_at = [&](int64_t tile, int r, int t) {
         const int64_t pr = min(tile * 128 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, n - 1);
-        return E0[pr * e_rs + 32 * t + i];
+        const int col = 32 * t + i;
+        if (!PAD) return E0[pr * e_rs + col];
+        const float e = E0[pr * e_rs + min(col, Lr - 1)];
+        return col < Lr ? e : INFINITY;
+    };
+    auto x_at = [&](const float *xrow, int k0) {      // 4 contraction values from column k0 + 4h (0 beyond Lr)
+        if (!PAD) return *reinterpret_cast<const float4 *>(xrow + k0);
+        const float4 v = *reinterpret_cast<const float4 *>(xrow + min(k0, Lr - 4 - 4 * h));
+        return (k0 + 4 * h) < Lr ? v : make_float4(0.f, 0.f, 0.f, 0.f);
     };
 
     // PERSISTENT workgroups (two per CU) walk the 128-pixel tiles; everything the NEXT tile needs before its first
@@ -211,7 +221,7 @@ __global__ __launch_bounds__(256, 2) void k_compat_softmax(const float *__restri
     {
         const float *xrow = x_row(tile);
 #pragma unroll
-        for (int q = 0; q < 4; q++) a_nxt[q] = *reinterpret_cast<const float4 *>(xrow + 8 * q);
+        for (int q = 0; q < 4; q++) a_nxt[q] = x_at(xrow, 8 * q);
     }
     load_mu(0, 0);
     __syncthreads();
@@ -227,7 +237,7 @@ __global__ __launch_bounds__(256, 2) void k_compat_softmax(const float *__restri
                 // next chunk: the other buffer was last read in chunk kc-1, behind the previous barrier
                 load_mu(kc + 1, (kc + 1) & 1);
 #pragma unroll
-                for (int q = 0; q < 4; q++) a_nxt[q] = *reinterpret_cast<const float4 *>(xrow + 32 * (kc + 1) + 8 * q);
+                for (int q = 0; q < 4; q++) a_nxt[q] = x_at(xrow, 32 * (kc + 1) + 8 * q);
             }
             // keep the prefetch HERE: left alone, the scheduler sinks these loads to the end of the chunk (their
             // results are not needed before the next one) and the wave then waits out a full HBM miss per chunk
@@ -258,7 +268,7 @@ __global__ __launch_bounds__(256, 2) void k_compat_softmax(const float *__restri
             load_mu(0, 0);                       // every wave is past the last barrier: both buffers are idle
             const float *xn = x_row(nxt);
 #pragma unroll
-            for (int q = 0; q < 4; q++) a_nxt[q] = *reinterpret_cast<const float4 *>(xn + 8 * q);
+            for (int q = 0; q < 4; q++) a_nxt[q] = x_at(xn, 8 * q);
         }
 
         // ---- epilogue on the accumulators (acc = E now) ------------------------------------------------------
@@ -270,7 +280,8 @@ __global__ __launch_bounds__(256, 2) void k_compat_softmax(const float *__restri
                 const int64_t prow = row0 + (r & 3) + 8 * (r >> 2) + 4 * h;
                 if (prow < n) {
 #pragma unroll
-                    for (int t = 0; t < NT; t++) out[prow * o_rs + 32 * t + i] = -acc[t][r];
+                    for (int t = 0; t < NT; t++)
+                        if (!PAD || 32 * t + i < Lr) out[prow * o_rs + 32 * t + i] = -acc[t][r];
                 }
                 if (has_next) {
 #pragma unroll
@@ -308,7 +319,8 @@ __global__ __launch_bounds__(256, 2) void k_compat_softmax(const float *__restri
                 const float inv = 1.0f / sum[r];
                 if (prow < n) {
 #pragma unroll
-                    for (int t = 0; t < NT; t++) out[prow * o_rs + 32 * t + i] = acc[t][r] * inv;
+                    for (int t = 0; t < NT; t++)
+                        if (!PAD || 32 * t + i < Lr) out[prow * o_rs + 32 * t + i] = acc[t][r] * inv;
                 }
                 if (has_next) {                  // this row's registers are free: the next tile's E0 goes in
 #pragma unroll
@@ -353,22 +365,26 @@ int phl_compat_softmax(const float *E0, int64_t e_rs, const float *X, int64_t x_
 {
     if (n < 0 || L < 1 || (n > 0 && (!E0 || !X || !MuT || !out))) { phl_set_error("phl_compat_softmax: bad arguments"); return PHL_ERR_INVALID; }
     if (n == 0) return PHL_OK;
-    if (L % 32 || L > 256 || x_rs % 4 || (reinterpret_cast<uintptr_t>(X) & 15) || (reinterpret_cast<uintptr_t>(MuT) & 15)) {
-        phl_set_error("phl_compat_softmax: needs L %% 32 == 0, L <= 256 and 16-byte aligned X rows (L=%d)", L);
+    if (L % 4 || L > 256 || x_rs % 4 || (reinterpret_cast<uintptr_t>(X) & 15) || (reinterpret_cast<uintptr_t>(MuT) & 15)) {
+        phl_set_error("phl_compat_softmax: needs L %% 4 == 0, L <= 256 and 16-byte aligned X rows (L=%d)", L);
         return PHL_ERR_UNSUPPORTED;
     }
+    const int Lp = (L + 31) / 32 * 32;       // the tile width: mu_t is [Lp][Lp], zero beyond L
+    const bool pad = Lp != L;
     hipStream_t st = (hipStream_t)stream;
     // persistent workgroups: two per CU (256 CUs), each walking tiles blockIdx.x, blockIdx.x + grid, ...
     const int64_t ntiles = (n + 127) / 128;
     const unsigned grid = (unsigned)(ntiles < 512 ? ntiles : 512);
-    const size_t lds = (size_t)2 * L * 32 * sizeof(float);
+    const size_t lds = (size_t)2 * Lp * 32 * sizeof(float);
     const bool logits = (flags & PHL_COMPAT_LOGITS) != 0;     // LDS is 2*L*128 B <= 64 KiB: no attribute needed
 #define PHL_CS(NT_)                                                                                                       \
     case NT_:                                                                                                             \
-        if (logits) k_compat_softmax<NT_, true><<<dim3(grid), dim3(256), lds, st>>>(E0, e_rs, X, x_rs, MuT, out, o_rs, n); \
-        else k_compat_softmax<NT_, false><<<dim3(grid), dim3(256), lds, st>>>(E0, e_rs, X, x_rs, MuT, out, o_rs, n);      \
+        if (logits && pad) k_compat_softmax<NT_, true, true><<<dim3(grid), dim3(256), lds, st>>>(E0, e_rs, X, x_rs, MuT, out, o_rs, n, L);        \
+        else if (logits) k_compat_softmax<NT_, true, false><<<dim3(grid), dim3(256), lds, st>>>(E0, e_rs, X, x_rs, MuT, out, o_rs, n, L);         \
+        else if (pad) k_compat_softmax<NT_, false, true><<<dim3(grid), dim3(256), lds, st>>>(E0, e_rs, X, x_rs, MuT, out, o_rs, n, L);            \
+        else k_compat_softmax<NT_, false, false><<<dim3(grid), dim3(256), lds, st>>>(E0, e_rs, X, x_rs, MuT, out, o_rs, n, L);                    \
         break;
-    switch (L / 32) {
+    switch (Lp / 32) {
         PHL_CS(1) PHL_CS(2) PHL_CS(3) PHL_CS(4) PHL_CS(5) PHL_CS(6) PHL_CS(7) PHL_CS(8)
     }
 #undef PHL_CS

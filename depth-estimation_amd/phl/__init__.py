@@ -359,25 +359,30 @@ _mu_t_cache = {}
 
 
 def _mu_transposed(Mu, device):
-    """Mu^T as a dense fp32 device tensor, cached per (storage, version): Mu is fixed during inference."""
+    """Mu^T as a dense fp32 device tensor padded to the MFMA tile width, cached per (storage, version): Mu is
+    fixed during inference."""
     key = (Mu.data_ptr(), Mu._version, tuple(Mu.shape), tuple(Mu.stride()), str(device))
     hit = _mu_t_cache.get(key)
     if hit is None:
         if len(_mu_t_cache) > 8:
             _mu_t_cache.clear()
-        hit = _mu_t_cache[key] = (Mu.detach().to(device, torch.float32).t().contiguous(), Mu)    # keeps Mu alive
+        L = Mu.shape[0]
+        Lp = (L + 31) // 32 * 32                 # the kernel's tile width: zero padding beyond L
+        mt = torch.zeros((Lp, Lp), dtype=torch.float32, device=device)
+        mt[:L, :L] = Mu.detach().to(device, torch.float32).t()
+        hit = _mu_t_cache[key] = (mt, Mu)        # keeps Mu alive
     return hit[0]
 
 
 def compat_softmax(E0, X, Mu, out=None, logits=False):
     """softmax(-(E0 + X @ Mu), dim=1): the whole non-lattice half of a mean-field iteration
     (crf/crf_module.py:51-52) for fp32 CUDA E0, X [n, L] and Mu [L, L], in one fused MFMA kernel
-    (phl_compat_softmax) when L % 32 == 0 and L <= 256; other label counts take a library GEMM followed by the
-    fused add + softmax pass.  logits=True returns -(E0 + X @ Mu) instead (CRFasRNN's output)."""
+    (phl_compat_softmax) when L % 4 == 0 and L <= 256 (label counts that are not a multiple of 32 run on a padded
+    tile); other label counts take a library GEMM followed by the fused add + softmax pass.  logits=True returns -(E0 + X @ Mu) instead (CRFasRNN's output)."""
     if not (_rowmajor(E0) and _rowmajor(X) and X.shape == E0.shape and Mu.shape == (E0.shape[1], E0.shape[1])):
         raise TypeError("compat_softmax: expects fp32 CUDA E0, X [n, L] with unit channel stride and Mu [L, L]")
     n, L = E0.shape
-    if L % 32 == 0 and L <= 256 and X.stride(0) % 4 == 0 and X.data_ptr() % 16 == 0:
+    if L % 4 == 0 and L <= 256 and X.stride(0) % 4 == 0 and X.data_ptr() % 16 == 0:
         if out is None:
             out = torch.empty((n, L), dtype=torch.float32, device=E0.device)
         mu_t = _mu_transposed(Mu, E0.device)

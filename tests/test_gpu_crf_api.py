@@ -200,7 +200,8 @@ def test_batched_filter_spreads_items_over_devices():
     assert torch.equal(phl.batched_filter(srcs.cuda(), refs.cuda(), devices=two), want)
 
 
-@pytest.mark.parametrize("n,L", [(4097, 256), (128, 32), (1000, 64), (333, 96), (5000, 160), (129, 224), (1, 32)])
+@pytest.mark.parametrize("n,L", [(4097, 256), (128, 32), (1000, 64), (333, 96), (5000, 160), (129, 224), (1, 32),
+                                 (110592, 16), (700, 4), (900, 48), (3000, 100), (513, 252)])
 def test_fused_compat_softmax_kernel(n, L):
     """phl_compat_softmax: softmax(-(E0 + X @ Mu)) on the fp32-input matrix cores with the softmax as epilogue,
     against an fp64 reference and torch's fp32 GEMM + softmax.  Mu is deliberately ASYMMETRIC (the kernel takes
@@ -236,7 +237,7 @@ def test_compat_softmax_falls_back_for_other_label_counts():
     import phl
 
     g = torch.Generator(device="cuda").manual_seed(3)
-    for L in (16, 48 + 2, 288):
+    for L in (18, 48 + 2, 288):
         E0 = torch.rand((500, L), device="cuda", generator=g) * 10
         X = torch.rand((500, L), device="cuda", generator=g)
         Mu = torch.rand((L, L), device="cuda", generator=g)
