@@ -732,16 +732,16 @@ def test_block_cache_is_invisible(phl):
         L.close()                                           # its arrays go to the cache; the next build takes them
     assert phl.load_library().phl_trim_scratch() == 0
     code = (
-        "import os, sys, numpy as np, torch\\n"
-        "root = sys.argv[1]\\n"
-        "sys.path[:0] = [os.path.join(root, 'depth-estimation_amd'), root]\\n"
-        "import phl\\n"
-        "rng = np.random.default_rng(41)\\n"
-        "ref = np.cumsum(rng.random((30000, 5), dtype=np.float32) * 0.02, axis=0).astype(np.float32)\\n"
-        "src = rng.random((30000, 16), dtype=np.float32)\\n"
-        "for _ in range(3):\\n"
-        "    L = phl.Lattice(torch.from_numpy(ref).cuda()); out = L.filter(torch.from_numpy(src).cuda(), exact=True).cpu().numpy(); L.close()\\n"
-        "np.save(sys.argv[2], out)\\n")
+        "import os, sys, numpy as np, torch\n"
+        "root = sys.argv[1]\n"
+        "sys.path[:0] = [os.path.join(root, 'depth-estimation_amd'), root]\n"
+        "import phl\n"
+        "rng = np.random.default_rng(41)\n"
+        "ref = np.cumsum(rng.random((30000, 5), dtype=np.float32) * 0.02, axis=0).astype(np.float32)\n"
+        "src = rng.random((30000, 16), dtype=np.float32)\n"
+        "for _ in range(3):\n"
+        "    L = phl.Lattice(torch.from_numpy(ref).cuda()); out = L.filter(torch.from_numpy(src).cuda(), exact=True).cpu().numpy(); L.close()\n"
+        "np.save(sys.argv[2], out)\n")
     import tempfile
 
     with tempfile.TemporaryDirectory() as tmp:
