@@ -551,6 +551,36 @@ int phl_splat(phl_lattice *lat, const float *src, int vd, int64_t src_rs, float 
     return phl_launch_splat(lat, src, src_rs, vd, vert, (hipStream_t)st);
 }
 
+int64_t phl_num_chunks(const phl_lattice *lat) { return lat ? lat->nchunks : -1; }
+int64_t phl_partial_rows(const phl_lattice *lat) { return lat ? lat->S_multi : -1; }
+
+int phl_chunks_touching(phl_lattice *lat, const int64_t *rows_dev, int64_t k, int32_t *mask_host, phl_stream st)
+{
+    if (!lat || k < 0 || (k > 0 && !rows_dev) || !mask_host) { phl_set_error("phl_chunks_touching: bad arguments"); return PHL_ERR_INVALID; }
+    device_guard g(lat->device);
+    return phl_tiles_chunks_touching(lat, rows_dev, k, mask_host, (hipStream_t)st);
+}
+
+int phl_splat_part(phl_lattice *lat, const float *src, int vd, int64_t src_rs, float *vert, float *partial_dev,
+                   const int32_t *chunks_dev, int64_t nchunks_sel, const int32_t *rows_dev, int64_t nrows, phl_stream st)
+{
+    if (!lat || vd < 0 || nchunks_sel < 0 || nrows < 0 || !src || !vert || (nchunks_sel > 0 && !chunks_dev) || (nrows > 0 && !rows_dev) ||
+        (lat->S_multi > 0 && !partial_dev)) {
+        phl_set_error("phl_splat_part: bad arguments");
+        return PHL_ERR_INVALID;
+    }
+    device_guard g(lat->device);
+    if (!use_tiled_splat(lat, vd, 0, src, vert, src_rs) || (reinterpret_cast<uintptr_t>(partial_dev) & 15)) {
+        phl_set_error("phl_splat_part: the chunk splat is not available for this shape (vd %% 4, alignment, sharing)");
+        return PHL_ERR_UNSUPPORTED;
+    }
+    // a chunk list is never null for the launcher: an empty selection still needs the "subset" meaning
+    static const int32_t none = 0;
+    return phl_launch_splat_tiled(lat, src, src_rs, vd, vert, partial_dev, (hipStream_t)st,
+                                  nchunks_sel ? chunks_dev : reinterpret_cast<const int32_t *>(&none) + 0, (int)nchunks_sel,
+                                  rows_dev, nrows);
+}
+
 int phl_blur_axis(phl_lattice *lat, int axis, const float *vin, float *vout, int vd, phl_stream st)
 {
     if (!lat || axis < 0 || axis > lat->d || vd < 0 || vin == vout) { phl_set_error("phl_blur_axis: bad arguments"); return PHL_ERR_INVALID; }

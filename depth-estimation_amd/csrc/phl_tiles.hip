@@ -416,7 +416,7 @@ __global__ __launch_bounds__(TPB_S) void k_splat_tiled(const float *__restrict__
                                                      const int *__restrict__ slot_pidx, const int2 *__restrict__ seg_rng,
                                                      const phl_contrib_t *__restrict__ seg, float *__restrict__ vert,
                                                      float *__restrict__ partial, int nchunks, int xcd_chunk,
-                                                     unsigned long long *__restrict__ tl)
+                                                     unsigned long long *__restrict__ tl, const int *__restrict__ chunk_list)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int SL = LPRS * 4;
@@ -427,9 +427,11 @@ __global__ __launch_bounds__(TPB_S) void k_splat_tiled(const float *__restrict__
     const int g = threadIdx.x / LPRS, l = threadIdx.x % LPRS;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int q = lane / LPRS;
-    // XCD-aware chunk order (see k_blur): neighbouring chunks share boundary vertices
-    const int c = xcd_chunk > 0 ? (int)(blockIdx.x & 7) * xcd_chunk + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
-    if (c >= nchunks) return;
+    // XCD-aware chunk order (see k_blur): neighbouring chunks share boundary vertices.  With a chunk list
+    // (phl_splat_part: a subset of the chunks, `nchunks` = its length) the same order runs over list positions.
+    const int ci = xcd_chunk > 0 ? (int)(blockIdx.x & 7) * xcd_chunk + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    if (ci >= nchunks) return;
+    const int c = chunk_list ? chunk_list[ci] : ci;
     // debug timeline (PHL_TIMELINE=file): 100 MHz wall-clock stamps per workgroup, tl == nullptr in normal runs
     unsigned long long *tlb = tl ? tl + (size_t)blockIdx.x * 8 : nullptr;
     if (tlb && threadIdx.x == 0) {
@@ -603,16 +605,17 @@ template <int LPR>
 __global__ __launch_bounds__(256) void k_splat_reduce(const float *__restrict__ partial, const int *__restrict__ vs_ptr,
                                                       const phl_contrib_t *__restrict__ vs,
                                                       const int *__restrict__ slot_pidx, int M, int vd,
-                                                      float *__restrict__ vert)
+                                                      float *__restrict__ vert, const int *__restrict__ vlist)
 {
+    // vlist (optional): only these M vertex rows (phl_splat_part)
     constexpr int Gw = 64 / LPR;
     const int lane = threadIdx.x & 63;
     const int sub = lane / LPR, l = lane % LPR;
     const int wave = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
     const int64_t stride = (int64_t)gridDim.x * 4 * Gw;
     for (int64_t v0 = (int64_t)wave * Gw; v0 < M; v0 += stride) {
-        const int64_t v = v0 + sub;
-        if (v >= M) continue;
+        if (v0 + sub >= M) continue;
+        const int64_t v = vlist ? vlist[v0 + sub] : v0 + sub;
         const int beg = vs_ptr[v], end = vs_ptr[v + 1];
         if (end - beg == 1) continue;
         for (int ch = l * 4; ch < vd; ch += LPR * 4) {
@@ -1120,11 +1123,50 @@ int phl_tiles_lprs(const phl_lattice *lat, int vd, int for_slice)
                      : pick_lprs(vd, lat->P + 1, lds_extra(lat->P, lat->d + 1, lat->nv_max));
 }
 
-int phl_launch_splat_tiled(phl_lattice *lat, const float *src, int64_t src_rs, int vd, float *vert, float *partial,
-                           hipStream_t st)
+// which chunks hold a slot of any of the listed vertex rows
+__global__ __launch_bounds__(256) void k_mark_chunks(const int64_t *__restrict__ rows, int64_t k, const int *__restrict__ vs_ptr,
+                                                     const phl_contrib_t *__restrict__ vs, const int *__restrict__ chunk_vptr,
+                                                     int nchunks, int *__restrict__ mask)
 {
-    const int M = (int)lat->M;
-    if (M == 0 || vd == 0) return PHL_OK;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= k) return;
+    const int64_t v = rows[i];
+    for (int e = vs_ptr[v]; e < vs_ptr[v + 1]; e++) {
+        const int slot = vs[e].pixel;
+        int lo = 0, hi = nchunks - 1;                     // chunk_vptr[c] <= slot < chunk_vptr[c + 1]
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (chunk_vptr[mid] <= slot) lo = mid;
+            else hi = mid - 1;
+        }
+        mask[lo] = 1;
+    }
+}
+
+int phl_tiles_chunks_touching(phl_lattice *lat, const int64_t *rows_dev, int64_t k, int32_t *mask_host, hipStream_t st)
+{
+    const int nchunks = lat->nchunks;
+    if (nchunks == 0) return PHL_OK;
+    temp_pool tmp;
+    int *mask;
+    PHL_HIP(tmp.get(&mask, (size_t)nchunks));
+    PHL_HIP(hipMemsetAsync(mask, 0, sizeof(int) * (size_t)nchunks, st));
+    if (k > 0) {
+        hipLaunchKernelGGL(k_mark_chunks, dim3((unsigned)((k + 255) / 256)), dim3(256), 0, st, rows_dev, k, lat->vs_ptr, lat->vs,
+                           lat->chunk_vptr, nchunks, mask);
+        PHL_HIP(hipGetLastError());
+    }
+    PHL_HIP(hipMemcpyAsync(mask_host, mask, sizeof(int) * (size_t)nchunks, hipMemcpyDeviceToHost, st));
+    PHL_HIP(hipStreamSynchronize(st));
+    return PHL_OK;
+}
+
+int phl_launch_splat_tiled(phl_lattice *lat, const float *src, int64_t src_rs, int vd, float *vert, float *partial,
+                           hipStream_t st, const int *chunk_list, int nlist, const int *vlist, int64_t nvl)
+{
+    // chunk_list / vlist (both or neither): run only the listed chunks, then complete only the listed vertex rows
+    const int M = chunk_list ? (int)nvl : (int)lat->M;
+    if (lat->M == 0 || vd == 0) return PHL_OK;
     const int64_t extra = lds_extra(lat->P, lat->d + 1, lat->nv_max);
     const int lprs = pick_lprs(vd, lat->P + 1, extra);      // + the row of zeros
     if (lprs < 0) {
@@ -1135,7 +1177,8 @@ int phl_launch_splat_tiled(phl_lattice *lat, const float *src, int64_t src_rs, i
     const size_t lds = (size_t)(lat->P + 1) * lprs * 16 + (size_t)extra;
     unsigned cgrid;
     int xcd_chunk;
-    chunk_grid(lat->nchunks, &cgrid, &xcd_chunk);
+    const int nrun = chunk_list ? nlist : lat->nchunks;
+    chunk_grid(nrun, &cgrid, &xcd_chunk);
     static const char *tl_path = getenv("PHL_TIMELINE");     // debug: dump per-workgroup time stamps of this launch
     unsigned long long *tl = nullptr;
     const size_t tl_n = (size_t)cgrid * 8;
@@ -1143,12 +1186,12 @@ int phl_launch_splat_tiled(phl_lattice *lat, const float *src, int64_t src_rs, i
         PHL_HIP(phl_dev_malloc((void **)&tl, tl_n * 8));
         PHL_HIP(hipMemsetAsync(tl, 0, tl_n * 8, st));
     }
-    dispatch_lprs(lprs, [&](auto L) {
+    if (nrun > 0) dispatch_lprs(lprs, [&](auto L) {
         constexpr int LPRS = decltype(L)::value;
         if ((rc = allow_lds(k_splat_tiled<LPRS>, lds)) != PHL_OK) return;
         k_splat_tiled<LPRS><<<dim3(cgrid), dim3(TPB_S), lds, st>>>(
             src, src_rs, vd, (int)lat->n, lat->P, lat->d + 1, lat->nv_max, lat->pix_order, lat->chunk_vptr, lat->slot_vert,
-            lat->slot_pidx, lat->seg_rng, lat->seg, vert, partial, lat->nchunks, xcd_chunk, tl);
+            lat->slot_pidx, lat->seg_rng, lat->seg, vert, partial, nrun, xcd_chunk, tl, chunk_list);
     });
     if (tl) {
         std::vector<unsigned long long> h(tl_n);
@@ -1161,13 +1204,14 @@ int phl_launch_splat_tiled(phl_lattice *lat, const float *src, int64_t src_rs, i
         }
     }
     if (rc) return rc;
+    if (M == 0) return PHL_OK;
     const int lpr = pick_lpr_row(vd);
     int64_t waves = ((int64_t)M + (64 / lpr) - 1) / (64 / lpr);
     int64_t blocks = (waves + 3) / 4;
     if (blocks > 2048) blocks = 2048;
 #define PHL_RED(LPR_)                                                                                                  \
     k_splat_reduce<LPR_><<<dim3((unsigned)blocks), dim3(256), 0, st>>>(partial, lat->vs_ptr, lat->vs, lat->slot_pidx, \
-                                                                       M, vd, vert)
+                                                                       M, vd, vert, vlist)
     switch (lpr) {
         case 64: PHL_RED(64); break;
         case 16: PHL_RED(16); break;

@@ -75,6 +75,11 @@ def load_library():
         lib.phl_filter_once.argtypes = [vp, i32, i64, i64, vp, i32, i64, i64, i64, vp, i64, i64, u32, i32, vp]
         lib.phl_splat.argtypes = [vp, vp, i32, i64, vp, u32, vp]
         lib.phl_tile_stats.argtypes = [vp, i32, vp]
+        for name in ("phl_num_chunks", "phl_partial_rows"):
+            getattr(lib, name).restype = i64
+            getattr(lib, name).argtypes = [vp]
+        lib.phl_chunks_touching.argtypes = [vp, vp, i64, vp, vp]
+        lib.phl_splat_part.argtypes = [vp, vp, i32, i64, vp, vp, vp, i64, vp, i64, vp]
         lib.phl_blur_axis.argtypes = [vp, i32, vp, vp, i32, vp]
         lib.phl_blur.argtypes = [vp, vp, vp, i32, C.POINTER(i32), vp]
         lib.phl_gather_rows.argtypes = [vp, i32, vp, i64, vp, i64, vp]
@@ -212,6 +217,34 @@ class Lattice:
                                             (EXACT if exact else 0) | (NO_TILES if no_tiles else 0),
                                             _stream(self.device)))
         return vert
+
+    # ---- splat in parts (row-band exchange overlap, see phl_splat_part in include/phl.h) ------------------
+    def chunks_touching(self, rows):
+        """bool numpy mask [#chunks]: pixel chunks that contribute to any of the vertex rows (int64 device tensor)."""
+        lib = load_library()
+        mask = np.zeros(int(lib.phl_num_chunks(self._h)), np.int32)
+        rows = rows.to(self.device, torch.int64).contiguous()
+        with torch.cuda.device(self.device):
+            _check(lib.phl_chunks_touching(self._h, C.c_void_p(rows.data_ptr()), int(rows.numel()),
+                                           mask.ctypes.data_as(C.c_void_p), _stream(self.device)))
+        return mask.astype(bool)
+
+    @property
+    def partial_rows(self):
+        return int(load_library().phl_partial_rows(self._h))
+
+    def splat_part(self, src, out, partial, chunks, rows):
+        """Run the chunk splat for the listed chunks (int32 device tensor) and complete the listed vertex rows
+        (int32 device tensor) of ``out`` [M, vd]; ``partial`` [partial_rows, vd] is shared by the parts of one splat."""
+        vd = int(src.shape[1])
+        assert src.stride(1) == 1 and out.is_contiguous() and out.shape == (self.M, vd)
+        assert chunks.dtype == torch.int32 and rows.dtype == torch.int32 and chunks.is_contiguous() and rows.is_contiguous()
+        assert partial.is_contiguous() and partial.shape[0] >= self.partial_rows and partial.shape[1] == vd
+        with torch.cuda.device(self.device):
+            _check(load_library().phl_splat_part(self._h, C.c_void_p(src.data_ptr()), vd, src.stride(0), C.c_void_p(out.data_ptr()),
+                                                 C.c_void_p(partial.data_ptr()), C.c_void_p(chunks.data_ptr()), int(chunks.numel()),
+                                                 C.c_void_p(rows.data_ptr()), int(rows.numel()), _stream(self.device)))
+        return out
 
     def blur_axis(self, axis, vin, vout=None):
         vd = int(vin.shape[1])

@@ -238,7 +238,13 @@ class RowTileFilter:
         self.build_ms = (time.time() - t0) * 1e3
         self.row0, self.own_rows, self.n_local = self.band.row0, self.band.own_rows, self.band.n_local
         if groups is None:
-            groups = int(os.environ.get("PHL_ROWTILE_GROUPS", "0")) or (2 if (world > 1 and L % 8 == 0 and L >= 64) else 1)
+            groups = int(os.environ.get("PHL_ROWTILE_GROUPS", "0"))
+            if not groups:
+                # device-resident payloads (RCCL): one group with the edge-first schedule (_make_edge_plan); payloads
+                # staged through host memory (gloo): two channel groups pipelined
+                edge_first = (self.comm_device == device and os.environ.get("PHL_ROWTILE_EDGE_FIRST", "1") != "0"
+                              and hasattr(engine_factory, "splat_part"))
+                groups = 1 if (edge_first or not (world > 1 and L % 8 == 0 and L >= 64)) else 2
         self.groups = [(g * L // groups, (g + 1) * L // groups) for g in range(groups)]
         total = sum(self.band.recv_rows(p) for p in self.band.sides)
         self._rpack = [torch.empty((total, c1 - c0), dtype=torch.float32, device=self.comm_device) for c0, c1 in self.groups]
@@ -248,6 +254,7 @@ class RowTileFilter:
         # not be on the critical path).
         self._fused = hasattr(self.band.eng, "gather_rows") and self.comm_device == self.band.device
         self._vert = self._scratch = self._sbuf = self._ops = None
+        self._plan, self._edge_first = None, False
         if self._fused:
             M = self.band.M
             self._vert = [torch.empty((M, c1 - c0), dtype=torch.float32, device=device) for c0, c1 in self.groups]
@@ -265,6 +272,32 @@ class RowTileFilter:
                 self._ops.append(ops)
         if hasattr(self.band.eng, "reserve"):
             self.band.eng.reserve(max(c1 - c0 for c0, c1 in self.groups))
+        self._make_edge_plan()
+
+    def _make_edge_plan(self):
+        """Edge-first schedule (one channel group): the chunks that feed this rank's boundary vertices are
+        splatted first and those rows completed, so that they travel while the interior chunks are splatted --
+        the exchange hides behind ~3/4 of the splat instead of behind a second channel group (splitting the
+        channels costs 10 % of the step in small-launch overhead)."""
+        eng, band = self.band.eng, self.band
+        want = os.environ.get("PHL_ROWTILE_EDGE_FIRST", "1") != "0"
+        if not (want and self._fused and len(self.groups) == 1 and band.sides and hasattr(eng, "splat_part")
+                and self.L % 4 == 0 and eng.tile_stats(self.L)["staged_splat"]):
+            return
+        send = band._send_all
+        mask = eng.chunks_touching(send)
+        if mask.all() or not mask.any():
+            return
+        dev = band.device
+        is_send = torch.zeros(band.M, dtype=torch.bool, device=dev)
+        is_send[send] = True
+        self._plan = dict(
+            edge=torch.from_numpy(np.nonzero(mask)[0].astype(np.int32)).to(dev),
+            interior=torch.from_numpy(np.nonzero(~mask)[0].astype(np.int32)).to(dev),
+            send_rows=torch.nonzero(is_send).flatten().to(torch.int32),
+            other_rows=torch.nonzero(~is_send).flatten().to(torch.int32),
+            partial=torch.empty((max(eng.partial_rows, 1), self.L), dtype=torch.float32, device=dev))
+        self._edge_first = True
 
     @property
     def M(self):
@@ -316,8 +349,22 @@ class RowTileFilter:
             self.band.finish(vert, inbox, out=out[:, c0:c1], packed=pack)
         return out
 
+    def _filter_edge_first(self, src, out):
+        dist, band, eng, pl = self.dist, self.band, self.band.eng, self._plan
+        vert, sbuf = self._vert[0], self._sbuf[0]
+        eng.splat_part(src, vert, pl["partial"], pl["edge"], pl["send_rows"])        # boundary rows complete
+        eng.gather_rows(vert, band._send_all, out=sbuf)
+        reqs = dist.batch_isend_irecv(self._ops[0]) if self._ops[0] else []          # ... and on their way
+        eng.splat_part(src, vert, pl["partial"], pl["interior"], pl["other_rows"])   # the rest, under the exchange
+        for req in reqs:
+            req.wait()
+        band.finish(vert, self._rbuf[0], out=out, packed=self._rpack[0], scratch=self._scratch[0])
+        return out
+
     def _filter_fused(self, src, out):
         """Same schedule on preallocated buffers and persistent op lists (RCCL: payloads stay in HBM)."""
+        if self._edge_first:
+            return self._filter_edge_first(src, out)
         dist, band = self.dist, self.band
         reqs = []
         for gi, (c0, c1) in enumerate(self.groups):
@@ -335,6 +382,9 @@ class RowTileFilter:
         return {"rowtile": {"rows_per_rank": b.own_rows, "strip_rows": b.S, "M_local_plus_ghosts": int(b.M),
                             "boundary_vertices_recv": rows,
                             "channel_groups": len(self.groups),
+                            "schedule": ("edge chunks first, exchange under the interior splat" if getattr(self, "_edge_first", False)
+                                         else "channel groups pipelined"),
+                            "edge_chunks": int(self._plan["edge"].numel()) if getattr(self, "_plan", None) else None,
                             "exchange_bytes_per_step_per_rank": int(sum(rows.values()) * self.L * 4 * 2)}}
 
 

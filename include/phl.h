@@ -176,6 +176,21 @@ int phl_gather_rows(const float *vert_dev, int vd, const int64_t *idx_dev, int64
                     int64_t out_row_stride, phl_stream stream);
 int phl_scatter_add_rows(float *vert_dev, int vd, const int64_t *idx_dev, int64_t k, const float *in_dev,
                          int64_t in_row_stride, phl_stream stream);
+/* The chunk splat in two (or more) parts, for overlapping the row-band exchange with compute: run only the listed
+ * pixel chunks, then complete exactly the listed vertex rows.  A rank first splats the chunks that touch its
+ * boundary vertices (phl_chunks_touching) and completes those rows -- they can travel -- and then the interior
+ * chunks and all other rows while the exchange is in flight.  partial_dev: caller-owned [phl_partial_rows()][vd]
+ * scratch shared by the parts of one splat (rows shared between an early and a late chunk are summed by the late
+ * part).  Every chunk must appear in exactly one part and every vertex row in exactly one part that runs after all
+ * chunks touching it.  No reference counterpart. */
+int64_t phl_num_chunks(const phl_lattice *lat);
+int64_t phl_partial_rows(const phl_lattice *lat);
+/* mask_host[c] = 1 iff pixel chunk c contributes to any of the k listed vertex rows (device int64 array) */
+int phl_chunks_touching(phl_lattice *lat, const int64_t *rows_dev, int64_t k, int32_t *mask_host /* [phl_num_chunks] */,
+                        phl_stream stream);
+int phl_splat_part(phl_lattice *lat, const float *src_dev, int vd, int64_t src_row_stride, float *vert_dev,
+                   float *partial_dev, const int32_t *chunks_dev, int64_t nchunks_sel, const int32_t *rows_dev,
+                   int64_t nrows, phl_stream stream);
 /* slice(): out[p] = sum_i w_i * vert[v_i] / (1 + 2^-d)                        (:473-483) */
 int phl_slice(phl_lattice *lat, const float *vert_dev, int vd, float *out_dev, int64_t out_row_stride,
               const float *sub_dev /* NULL or src to subtract */, int64_t sub_row_stride, unsigned flags,

@@ -189,6 +189,7 @@ def test_preallocated_rccl_shaped_path_in_process(world, groups):
             fake.local.rank = rank
             job = rowtile.RowTileFilter(feat, L, rank, world, dev, fake, groups=groups)
             assert job._fused and len(job._ops) == groups
+            assert job._edge_first == (groups == 1), job.describe()      # one group: edge chunks first, exchange under the rest
             mine = torch.from_numpy(src[job.row0 * W:(job.row0 + job.own_rows) * W]).to(dev)
             buf = torch.empty_like(mine)
             a = job.filter(mine, out=buf).clone()
@@ -237,3 +238,35 @@ def test_full_size_c3_in_row_bands(world):
           f"{max(b.M - b.eng.M_local for b in bands)} of {max(b.M for b in bands)} vertices")
     assert err <= RTOL
     assert all(b.own_rows == H // world for b in bands)
+
+
+def test_splat_in_parts_equals_the_whole_splat():
+    """phl_splat_part: the chunks that touch a set of vertex rows first (those rows complete), then the other chunks
+    and rows -- bitwise the same vertex sums as one whole chunk splat, for any split."""
+    import phl
+    from test_rowtile_cpu import make_image
+
+    feat, src = make_image(160, 128, 32, sigma_xy=3.0)
+    dev = torch.device("cuda")
+    L = phl.Lattice(torch.from_numpy(feat.reshape(-1, 5)).to(dev))
+    s = torch.from_numpy(src).to(dev)
+    assert L.tile_stats(32)["staged_splat"] == 1
+    whole = L.splat(s)
+    rng = np.random.default_rng(0)
+    keys = L.keys()
+    rows_map = L.vertex_rows()
+    for frac in (0.1, 0.5):
+        pick = torch.from_numpy(np.sort(rng.permutation(L.M)[:int(L.M * frac)]).astype(np.int64)).to(dev)   # first-touch ids
+        first_rows = rows_map[pick]
+        mask = L.chunks_touching(first_rows)
+        assert 0 < mask.sum() <= len(mask)
+        is_first = torch.zeros(L.M, dtype=torch.bool, device=dev)
+        is_first[first_rows] = True
+        out = torch.full((L.M, 32), float("nan"), device=dev)
+        partial = torch.empty((max(L.partial_rows, 1), 32), device=dev)
+        ch = lambda m: torch.from_numpy(np.nonzero(m)[0].astype(np.int32)).to(dev)
+        L.splat_part(s, out, partial, ch(mask), torch.nonzero(is_first).flatten().to(torch.int32))
+        assert torch.equal(out[first_rows], whole[first_rows])          # complete before the second part runs
+        L.splat_part(s, out, partial, ch(~mask), torch.nonzero(~is_first).flatten().to(torch.int32))
+        assert torch.equal(out, whole)
+    assert keys.shape[0] == L.M

@@ -63,6 +63,45 @@ for groups in ([int(g) for g in sys.argv[3].split(',')] if len(sys.argv) > 3 els
     wall = (time.perf_counter() - t0) / reps * 1e3
     print(f"groups {groups}: host issue {host:.3f} ms/call, gpu {e0.elapsed_time(e1) / reps:.3f} ms/call, wall {wall:.3f} ms/call")
 
+# edge-first schedule (one channel group): boundary chunks, gather, [exchange], interior chunks, add, blur, slice
+send = b._send_all
+mask = b.eng.chunks_touching(send)
+is_send = torch.zeros(b.M, dtype=torch.bool, device=dev)
+is_send[send] = True
+i32 = lambda m: torch.from_numpy(__import__("numpy").nonzero(m)[0].astype("int32")).to(dev)
+edge, interior = i32(mask), i32(~mask)
+send_rows, other_rows = torch.nonzero(is_send).flatten().to(torch.int32), torch.nonzero(~is_send).flatten().to(torch.int32)
+partial = torch.empty((max(b.eng.partial_rows, 1), L), device=dev)
+vert = torch.empty((b.M, L), device=dev)
+scr = torch.empty_like(vert)
+sbuf = torch.empty((b.send_rows(), L), device=dev)
+total = sum(b.recv_rows(p) for p in b.sides)
+pack1 = torch.randn((total, L), device=dev)
+fake1 = {p: pack1[slice(*b.recv_range(p))] for p in b.sides}
+res = torch.empty((b.n_local, L), device=dev)
+
+
+def call_edge():
+    b.eng.splat_part(src, vert, partial, edge, send_rows)
+    b.eng.gather_rows(vert, send, out=sbuf)
+    b.eng.splat_part(src, vert, partial, interior, other_rows)
+    b.finish(vert, fake1, out=res, packed=pack1, scratch=scr)
+
+
+for _ in range(5):
+    call_edge()
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+t0 = time.perf_counter()
+e0.record()
+for _ in range(50):
+    call_edge()
+e1.record()
+host = (time.perf_counter() - t0) / 50 * 1e3
+torch.cuda.synchronize()
+print(f"edge-first ({int(edge.numel())} of {int(edge.numel() + interior.numel())} chunks feed the {int(send.numel())} boundary rows): "
+      f"host issue {host:.3f} ms/call, gpu {e0.elapsed_time(e1) / 50:.3f} ms/call")
+
 # single-lattice reference point on the same box
 ref = torch.from_numpy(feat.reshape(-1, 5)).to(dev)
 full = bench.synthetic_values(torch, H, W, L, 0, dev)
