@@ -574,11 +574,8 @@ int phl_splat_part(phl_lattice *lat, const float *src, int vd, int64_t src_rs, f
         phl_set_error("phl_splat_part: the chunk splat is not available for this shape (vd %% 4, alignment, sharing)");
         return PHL_ERR_UNSUPPORTED;
     }
-    // a chunk list is never null for the launcher: an empty selection still needs the "subset" meaning
-    static const int32_t none = 0;
-    return phl_launch_splat_tiled(lat, src, src_rs, vd, vert, partial_dev, (hipStream_t)st,
-                                  nchunks_sel ? chunks_dev : reinterpret_cast<const int32_t *>(&none) + 0, (int)nchunks_sel,
-                                  rows_dev, nrows);
+    return phl_launch_splat_tiled(lat, src, src_rs, vd, vert, partial_dev, (hipStream_t)st, /*subset=*/true, chunks_dev,
+                                  (int)nchunks_sel, rows_dev, nrows);
 }
 
 int phl_blur_axis(phl_lattice *lat, int axis, const float *vin, float *vout, int vd, phl_stream st)

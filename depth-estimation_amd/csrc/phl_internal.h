@@ -153,8 +153,8 @@ int phl_tiles_link_vertices(phl_lattice *lat, hipStream_t st);
 int phl_tiles_free(phl_lattice *lat);
 int phl_tiles_lprs(const phl_lattice *lat, int vd, int for_slice);  // -1: LDS-staged path unavailable
 int phl_launch_splat_tiled(phl_lattice *lat, const float *src, int64_t src_rs, int vd, float *vert, float *partial,
-                           hipStream_t st, const int *chunk_list = nullptr, int nlist = 0, const int *vlist = nullptr,
-                           int64_t nvl = 0);
+                           hipStream_t st, bool subset = false, const int *chunk_list = nullptr, int nlist = 0,
+                           const int *vlist = nullptr, int64_t nvl = 0);
 int phl_tiles_chunks_touching(phl_lattice *lat, const int64_t *rows_dev, int64_t k, int32_t *mask_host, hipStream_t st);
 int phl_launch_slice_tiled(const phl_lattice *lat, const float *vert, int vd, float *out, int64_t out_rs, const float *sub,
                            int64_t sub_rs, unsigned flags, hipStream_t st);

@@ -1162,10 +1162,10 @@ int phl_tiles_chunks_touching(phl_lattice *lat, const int64_t *rows_dev, int64_t
 }
 
 int phl_launch_splat_tiled(phl_lattice *lat, const float *src, int64_t src_rs, int vd, float *vert, float *partial,
-                           hipStream_t st, const int *chunk_list, int nlist, const int *vlist, int64_t nvl)
+                           hipStream_t st, bool subset, const int *chunk_list, int nlist, const int *vlist, int64_t nvl)
 {
-    // chunk_list / vlist (both or neither): run only the listed chunks, then complete only the listed vertex rows
-    const int M = chunk_list ? (int)nvl : (int)lat->M;
+    // subset: run only the listed chunks, then complete only the listed vertex rows (either list may be empty)
+    const int M = subset ? (int)nvl : (int)lat->M;
     if (lat->M == 0 || vd == 0) return PHL_OK;
     const int64_t extra = lds_extra(lat->P, lat->d + 1, lat->nv_max);
     const int lprs = pick_lprs(vd, lat->P + 1, extra);      // + the row of zeros
@@ -1177,7 +1177,7 @@ int phl_launch_splat_tiled(phl_lattice *lat, const float *src, int64_t src_rs, i
     const size_t lds = (size_t)(lat->P + 1) * lprs * 16 + (size_t)extra;
     unsigned cgrid;
     int xcd_chunk;
-    const int nrun = chunk_list ? nlist : lat->nchunks;
+    const int nrun = subset ? nlist : lat->nchunks;
     chunk_grid(nrun, &cgrid, &xcd_chunk);
     static const char *tl_path = getenv("PHL_TIMELINE");     // debug: dump per-workgroup time stamps of this launch
     unsigned long long *tl = nullptr;
