@@ -193,8 +193,11 @@ __global__ __launch_bounds__(256) void k_blur(const float *__restrict__ vin, flo
             for (int u = 0; u < U; u++) {
                 const int64_t vc = v[u] < M ? v[u] : (int64_t)M - 1;
                 s[u] = vload(vin + vc * vd + c, V());
-                a[u] = vload(vin + (int64_t)max(nb[u].x, 0) * vd + c, V());
-                b[u] = vload(vin + (int64_t)max(nb[u].y, 0) * vd + c, V());
+                // absent neighbours (-1) issue no load when no vertex of the wave has one (wave-uniform test, see
+                // k_blur2); otherwise the vertex's own row is loaded and discarded
+                a[u] = b[u] = vzero<VEC>();
+                if (__ballot(nb[u].x >= 0) != 0ull) a[u] = vload(vin + (nb[u].x >= 0 ? (int64_t)nb[u].x : vc) * vd + c, V());
+                if (__ballot(nb[u].y >= 0) != 0ull) b[u] = vload(vin + (nb[u].y >= 0 ? (int64_t)nb[u].y : vc) * vd + c, V());
             }
 #pragma unroll
             for (int u = 0; u < U; u++) {
@@ -241,7 +244,26 @@ __global__ __launch_bounds__(256) void k_blur2(const float *__restrict__ vin, fl
             const int64_t vc = v[u] < M ? v[u] : (int64_t)M - 1;
             s[u] = vload(vin + vc * vd + c, V());
 #pragma unroll
-            for (int k = 0; k < 8; k++) x[u][k] = vload(vin + (int64_t)max(id[u][k], 0) * vd + c, V());
+            // Absent neighbours (id < 0) are more than half of the stencil on a sparse lattice: 2.7 / 4.2 / 5.1 of
+            // the 8 at C3 for the three axis pairs.  Loading a dummy row for them (round 1) kept the code
+            // branch-free but made the pass issue-bound on loads whose results it throws away: skipping them took the
+            // three passes from 0.459 to 0.385 ms.  The test must be WAVE-UNIFORM (a load under a divergent `if`
+            // makes hipcc drain vmcnt per load).
+            for (int k = 0; k < 8; k++) {
+                if constexpr (LPR == 64) {
+                    // one vertex per wave: the ids are wave-uniform, so an absent neighbour is skipped by a SCALAR
+                    // branch (no divergence, the loads that are issued still go out back to back)
+                    const int idk = __builtin_amdgcn_readfirstlane(id[u][k]);
+                    x[u][k] = vzero<VEC>();
+                    if (idk >= 0) x[u][k] = vload(vin + (int64_t)idk * vd + c, V());
+                } else {
+                    // several vertices per wave: skip the load when NONE of them has this neighbour (still a
+                    // wave-uniform test); lanes of a vertex without it load its own row and discard it
+                    x[u][k] = vzero<VEC>();
+                    if (__ballot(id[u][k] >= 0) != 0ull)
+                        x[u][k] = vload(vin + (id[u][k] >= 0 ? (int64_t)id[u][k] : vc) * vd + c, V());
+                }
+            }
         }
 #pragma unroll
         for (int u = 0; u < U; u++) {
