@@ -175,10 +175,13 @@ class RowBand:
         """src [n_local, C] (any channel subset, unit column stride) -> (vertex sums, {peer: rows to send}).
         vert / sendbuf: optional preallocated [M, C] / [rows to send, C] buffers (engines with the phl.Lattice
         stage surface write into them, so a steady-state call allocates nothing)."""
-        fused = hasattr(self.eng, "gather_rows")
-        vert = self.eng.splat(src, out=vert) if (vert is not None and fused) else self.eng.splat(src)
-        if self.sides and fused:
-            buf = self.eng.gather_rows(vert, self._send_all, out=sendbuf)        # one launch for both neighbours
+        engine_rows = hasattr(self.eng, "gather_rows")
+        vert = self.eng.splat(src, out=vert) if (vert is not None and engine_rows) else self.eng.splat(src)
+        if self.sides and engine_rows:
+            if vert.shape[1] % 4 == 0:       # the engine's row kernels move 16-byte pieces
+                buf = self.eng.gather_rows(vert, self._send_all, out=sendbuf)        # one launch for both neighbours
+            else:
+                buf = torch.index_select(vert, 0, self._send_all, out=sendbuf) if sendbuf is not None else vert.index_select(0, self._send_all)
             return vert, {p: buf[a:b] for p, (a, b) in self._send_rng.items()}
         return vert, {peer: vert.index_select(0, s["send_idx"]) for peer, s in self.sides.items()}
 
@@ -192,7 +195,7 @@ class RowBand:
     def finish(self, vert, inbox, out=None, packed=None, scratch=None):
         """inbox: {peer: rows}; packed: the same rows as ONE [sum of rows, C] tensor in ascending peer order
         (lets the engine add them in a single launch); scratch: optional second [M, C] buffer for the blur."""
-        fused = hasattr(self.eng, "scatter_add_rows")
+        fused = hasattr(self.eng, "scatter_add_rows") and vert.shape[1] % 4 == 0
         if fused and packed is not None and self.sides and self._map_disjoint:
             self.eng.scatter_add_rows(vert, self._map_all, packed)
         else:

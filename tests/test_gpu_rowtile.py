@@ -270,3 +270,50 @@ def test_splat_in_parts_equals_the_whole_splat():
         L.splat_part(s, out, partial, ch(~mask), torch.nonzero(~is_first).flatten().to(torch.int32))
         assert torch.equal(out, whole)
     assert keys.shape[0] == L.M
+
+
+def test_rccl_shaped_path_random_shapes():
+    """Randomised images / rank counts / label counts through the device-payload driver (threads as ranks): the
+    edge-first schedule where it applies (one group, chunk splat available), channel groups or the plain path
+    elsewhere (L % 4 != 0, tiny bands) -- always equal to the single lattice."""
+    import threading
+
+    import phl
+    from phl import rowtile
+    from test_rowtile_cpu import make_image
+
+    rng = np.random.default_rng(20261004)
+    dev = torch.device("cuda")
+    seen = set()
+    for trial in range(6):
+        world = int(rng.integers(2, 6))
+        rows = int(rng.choice([48, 64, 96]))
+        H, W = rows * world, int(rng.choice([40, 64, 100]))
+        L = int(rng.choice([4, 6, 20, 64]))
+        groups = int(rng.choice([1, 1, 2])) if L % 2 == 0 and L >= 4 else 1
+        feat, src = make_image(H, W, L, sigma_xy=float(rng.choice([2.0, 3.0])))
+        fake = _LoopbackDist(world)
+        outs, errs = {}, []
+
+        def run(rank):
+            try:
+                fake.local.rank = rank
+                job = rowtile.RowTileFilter(feat, L, rank, world, dev, fake, groups=groups)
+                mine = torch.from_numpy(src[job.row0 * W:(job.row0 + job.own_rows) * W]).to(dev)
+                outs[rank] = (job.filter(mine).cpu().numpy(), job._edge_first)
+            except Exception:      # noqa: BLE001
+                import traceback
+
+                errs.append((rank, traceback.format_exc()))
+
+        ts = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join(timeout=300)
+        assert not errs, (trial, world, H, W, L, groups, errs)
+        want = phl.Lattice(torch.from_numpy(feat.reshape(-1, 5)).to(dev)).filter(torch.from_numpy(src).to(dev)).cpu().numpy()
+        got = np.concatenate([outs[r][0] for r in range(world)], 0)
+        assert rel(got, want) <= RTOL, (trial, world, H, W, L, groups)
+        seen.add(any(outs[r][1] for r in range(world)))
+    assert seen == {True, False}, seen          # both schedules were exercised
