@@ -751,3 +751,44 @@ def test_block_cache_is_invisible(phl):
                            capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stderr[-2000:]
         assert np.array_equal(np.load(path).view(np.uint32), outs[0].view(np.uint32))
+
+
+def test_threads_with_different_channel_counts_share_one_lattice(phl):
+    """Workspace pool under stress: three host threads, each on its own stream, filter values of DIFFERENT widths
+    (so workspaces are grown and recycled while others are in flight), with and without the fused subtraction,
+    through one lattice; every result equals the single-threaded one bit for bit."""
+    import threading
+
+    rng = np.random.default_rng(77)
+    n, d = 60000, 5
+    ref_np = np.cumsum(rng.random((n, d), dtype=np.float32) * 0.015, axis=0).astype(np.float32)
+    Lat = phl.Lattice(torch.from_numpy(ref_np).cuda())
+    widths = [4, 16, 64, 100, 256, 3]
+    xs = {vd: torch.rand((n, vd), device="cuda") for vd in widths}
+    want = {(vd, sub): Lat.filter(xs[vd], subtract_input=sub) for vd in widths for sub in (False, True)}
+    torch.cuda.synchronize()
+    errors = []
+
+    def worker(tid):
+        try:
+            r = np.random.default_rng(100 + tid)
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st):
+                for it in range(40):
+                    vd = int(r.choice(widths))
+                    sub = bool(r.integers(0, 2))
+                    got = Lat.filter(xs[vd], subtract_input=sub)
+                    if it % 4 == 3:
+                        st.synchronize()
+                        if not torch.equal(got, want[(vd, sub)]):
+                            errors.append((tid, it, vd, sub, float((got - want[(vd, sub)]).abs().max())))
+                st.synchronize()
+        except Exception as e:      # noqa: BLE001
+            errors.append((tid, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(3)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors[:5]
