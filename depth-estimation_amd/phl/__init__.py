@@ -415,9 +415,9 @@ def compat_softmax(E0, X, Mu, out=None, logits=False):
     if not (_rowmajor(E0) and _rowmajor(X) and X.shape == E0.shape and Mu.shape == (E0.shape[1], E0.shape[1])):
         raise TypeError("compat_softmax: expects fp32 CUDA E0, X [n, L] with unit channel stride and Mu [L, L]")
     n, L = E0.shape
-    if L % 4 == 0 and L <= 256 and X.stride(0) % 4 == 0 and X.data_ptr() % 16 == 0:
-        if out is None:
-            out = torch.empty((n, L), dtype=torch.float32, device=E0.device)
+    if out is None:
+        out = torch.empty((n, L), dtype=torch.float32, device=E0.device)
+    if L % 4 == 0 and L <= 256 and all(t.stride(0) % 4 == 0 and t.data_ptr() % 16 == 0 for t in (X, E0, out)):
         mu_t = _mu_transposed(Mu, E0.device)
         with torch.cuda.device(E0.device):
             _check(load_library().phl_compat_softmax(
@@ -426,8 +426,7 @@ def compat_softmax(E0, X, Mu, out=None, logits=False):
         return out
     G = X @ Mu.to(E0.device, torch.float32)
     if logits:
-        res = -(E0 + G)
-        return res if out is None else out.copy_(res)
+        return out.copy_(-(E0 + G))
     return softmax_neg_add(E0, G, out=out)
 
 

@@ -208,8 +208,8 @@ int phl_softmax_neg_add(const float *E0_dev, int64_t e0_row_stride, const float 
  * softmax applied to the accumulators, so G and E never exist in memory.
  * mu_t_dev is Mu TRANSPOSED and zero-padded to the tile width Lp = 32*ceil(L/32): a dense [Lp][Lp] array with
  * mu_t[c*Lp + k] = Mu[k][c] for c, k < L and 0 elsewhere (Charbonnier / Potts compatibilities are symmetric: their
- * own transpose).  Needs L % 4 == 0, L <= 256, x_row_stride % 4 == 0 and 16-byte aligned X / mu_t (else
- * PHL_ERR_UNSUPPORTED: the caller keeps its GEMM + phl_softmax_neg_add).  Rows have unit channel stride.
+ * own transpose).  Needs L % 4 == 0, L <= 256, all three row strides % 4 == 0 and 16-byte aligned E0 / X / out /
+ * mu_t (else PHL_ERR_UNSUPPORTED: the caller keeps its GEMM + phl_softmax_neg_add).  Rows have unit channel stride.
  * flags: PHL_COMPAT_LOGITS writes -(E0 + X @ Mu) instead of its softmax (CRFasRNN returns the logits of the last
  * iteration, crf_module.py:103). */
 enum phl_compat_flags { PHL_COMPAT_SOFTMAX = 0, PHL_COMPAT_LOGITS = 1 };

@@ -36,8 +36,121 @@ void run(int blocks, int iters)
            NACC, blocks, blocks * 4 / 1024.0, ms, mfmas * 4096 / ms / 1e9, ms * 1e6 / per_simd, 64 / 2.4);
     hipFree(d);
 }
-int main()
+// Same-wave interleave: KV independent v_fma behind every MFMA of a single wave per SIMD
+template <int KV>
+__global__ __launch_bounds__(256) void k_mix(float *out, int iters)
 {
+    f32x16 acc[8];
+    for (int t = 0; t < 8; t++) for (int r = 0; r < 16; r++) acc[t][r] = (float)(threadIdx.x + t);
+    float v[16];
+    for (int r = 0; r < 16; r++) v[r] = (float)(threadIdx.x + r);
+    float a = 1.f + threadIdx.x, b = 2.f;
+    for (int it = 0; it < iters; it++) {
+#pragma unroll
+        for (int t = 0; t < 8; t++) {
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < KV; r++) v[r] = __builtin_fmaf(v[r], 1.0001f, 0.5f);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    float s = 0;
+    for (int t = 0; t < 8; t++) for (int r = 0; r < 16; r++) s += acc[t][r];
+    for (int r = 0; r < 16; r++) s += v[r];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+template <int KV>
+void mix()
+{
+    float *d; hipMalloc(&d, 256 * 256 * 4);
+    hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+    const int iters = 8192;
+    k_mix<KV><<<256, 256>>>(d, iters); hipDeviceSynchronize();
+    hipEventRecord(a); k_mix<KV><<<256, 256>>>(d, iters); hipEventRecord(b); hipEventSynchronize(b);
+    float ms; hipEventElapsedTime(&ms, a, b);
+    printf("same wave, %2d v_fma per MFMA: %.1f cycles per MFMA (at 2.4 GHz)\n", KV, ms * 1e-3 * 2.4e9 / (iters * 8.0));
+    hipFree(d);
+}
+
+// Co-execution: one 512-thread workgroup per CU = 2 waves per SIMD.  Waves 0-3 issue MFMAs, waves 4-7 run `mode`:
+// 1 = independent v_fma chains, 2 = streaming global loads + stores (dword per lane, 128-byte segments).
+// Each group's duration comes from its own 100 MHz stamps (max over the grid).
+__global__ __launch_bounds__(512) void k_coexec(float *out, float *mem, unsigned long long *stamps, int mfma_iters, int other_iters, int mode)
+{
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const unsigned long long t0 = wall_clock64();
+    float s = 0;
+    if (mode >= 16 && wave >= 4) __builtin_amdgcn_s_setprio(3);     // mode + 16: the non-MFMA waves run at high priority
+    mode &= 15;
+    if (wave < 4) {
+        f32x16 acc[8];
+        for (int t = 0; t < 8; t++) for (int r = 0; r < 16; r++) acc[t][r] = (float)(threadIdx.x + t);
+        float a = 1.f + threadIdx.x, b = 2.f;
+        for (int it = 0; it < mfma_iters; it++) {
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+#pragma unroll
+                for (int t = 0; t < 8; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
+        }
+        for (int t = 0; t < 8; t++) for (int r = 0; r < 16; r++) s += acc[t][r];
+    } else if (mode == 1) {
+        float v[16];
+        for (int r = 0; r < 16; r++) v[r] = (float)(lane + r);
+        for (int it = 0; it < other_iters; it++) {
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) v[r] = __builtin_fmaf(v[r], 1.0001f, 0.5f);
+        }
+        for (int r = 0; r < 16; r++) s += v[r];
+    } else if (mode == 2) {
+        // rows of 1 KiB; a wave walks its own region: 8 loads + 8 stores of 256 B per step
+        float *base = mem + ((size_t)blockIdx.x * 4 + (wave - 4)) * ((size_t)other_iters * 2048) + lane;
+        for (int it = 0; it < other_iters; it++) {
+            float x[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) x[u] = base[(size_t)it * 2048 + u * 64];
+#pragma unroll
+            for (int u = 0; u < 8; u++) base[(size_t)it * 2048 + 1024 + u * 64] = x[u] + 1.f;
+        }
+    }
+    const unsigned long long t1 = wall_clock64();
+    if (lane == 0) { stamps[(blockIdx.x * 8 + wave) * 2] = t0; stamps[(blockIdx.x * 8 + wave) * 2 + 1] = t1; }
+    out[blockIdx.x * 512 + threadIdx.x] = s;
+}
+void coexec(int mfma_iters, int other_iters, int mode, float *mem)
+{
+    const int blocks = 256;
+    float *d; hipMalloc(&d, blocks * 512 * 4);
+    unsigned long long *st; hipMalloc(&st, blocks * 16 * 8);
+    for (int rep = 0; rep < 2; rep++) { k_coexec<<<blocks, 512>>>(d, mem, st, mfma_iters, other_iters, mode); hipDeviceSynchronize(); }
+    unsigned long long h[256 * 16];
+    hipMemcpy(h, st, sizeof(h), hipMemcpyDeviceToHost);
+    double dm = 0, dother = 0;
+    for (int b = 0; b < blocks; b++) for (int w = 0; w < 8; w++) {
+        const double us = (h[(b * 8 + w) * 2 + 1] - h[(b * 8 + w) * 2]) / 100.0;
+        if (w < 4) dm += us / (blocks * 4); else dother += us / (blocks * 4);
+    }
+    printf("mfma_iters=%5d other(mode %d)_iters=%6d : MFMA waves %8.1f us (%.1f cycles/MFMA at 2.4 GHz), other waves %8.1f us",
+           mfma_iters, mode & 15, other_iters, dm, mfma_iters ? dm * 2400 / (mfma_iters * 32.0) : 0.0, dother);
+    if (mode >= 16) printf(" [prio]");
+    mode &= 15;
+    if (mode == 1 && other_iters) printf(" (%.2f cycles per v_fma)", dother * 2400 / (other_iters * 128.0));
+    if (mode == 2 && other_iters) printf(" (%.1f GB/s per CU, %.2f TB/s)", other_iters * 4 * 4096.0 / dother / 1e3, other_iters * 4 * 4096.0 / dother / 1e6 * 256);
+    printf("\n");
+    hipFree(d); hipFree(st);
+}
+int main(int argc, char **argv)
+{
+    if (argc > 1) {
+        float *mem; const size_t bytes = (size_t)256 * 4 * 1024 * 8192;    // other_iters <= 1024
+        hipMalloc(&mem, bytes); hipMemset(mem, 0, bytes);
+        mix<0>(); mix<2>(); mix<4>(); mix<8>(); mix<12>(); mix<16>();
+        coexec(2048, 0, 1, mem); coexec(0, 4096, 1, mem); coexec(2048, 4096, 1, mem); coexec(2048, 1024, 1, mem);
+        coexec(0, 1024, 2, mem); coexec(2048, 1024, 2, mem); coexec(2048, 256, 2, mem);
+        coexec(2048, 4096, 17, mem); coexec(2048, 1024, 17, mem); coexec(2048, 1024, 18, mem); coexec(2048, 256, 18, mem);
+        return 0;
+    }
     for (int blocks : {256, 512, 1024}) { run<8>(blocks, 4096); run<4>(blocks, 8192); run<2>(blocks, 16384); run<1>(blocks, 32768); }
     return 0;
 }
