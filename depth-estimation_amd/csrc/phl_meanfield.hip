@@ -8,6 +8,7 @@
 //   k_softmax_neg_add   Q[p,:] = softmax(-(E0[p,:] + G[p,:]))          (G optional)
 //   k_expected_value    out[p] = sum_c Q[p,c] * labels[c]                (Experiments/DenseCrf.ipynb cell 11)
 #include <math.h>
+#include <type_traits>
 
 #include "phl_internal.h"
 
@@ -163,7 +164,7 @@ __global__ __launch_bounds__(256) void k_stream_copy(const vf4 *__restrict__ src
 __device__ __forceinline__ void glds16(const float *sbase, unsigned voff, unsigned lds_addr)
 {
     unsigned keep;                              // m0 is the compiler's: hand it back as found
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_addr));
 }
 __device__ __forceinline__ void dma_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
@@ -228,13 +229,14 @@ __device__ __forceinline__ void half_wave_sum16(float (&x)[16])
 #ifdef PHL_COMPAT_TIMELINE
 // debug build only (make EXTRA=-DPHL_COMPAT_TIMELINE): per wave group, 100 MHz stamps of the first 16 phase starts
 __device__ unsigned long long *g_cs_timeline;
-__device__ int g_cs_exp;
-#define CS_EXP(bit) (g_cs_exp & (bit))
-#define CS_STAMP(p) do { if (g_cs_timeline && lane == 0 && w4 == 0 && (p) < 16) g_cs_timeline[((size_t)blockIdx.x * 2 + grp) * 40 + (p)] = wall_clock64(); } while (0)
-#define CS_ARRIVE(k) do { if (g_cs_timeline && lane == 0 && w4 == 0 && it == 2) g_cs_timeline[((size_t)blockIdx.x * 2 + grp) * 40 + 16 + (k)] = wall_clock64(); } while (0)
+#define CS_STAMP(p) do { if (g_cs_timeline && lane == 0 && w4 == 0 && (p) < 16) g_cs_timeline[((size_t)blockIdx.x * 2 + grp) * 64 + (p)] = wall_clock64(); } while (0)
+#ifdef PHL_CS_FINE
+#define CS_ARRIVE(k) do { if (g_cs_timeline && lane == 0 && w4 == 0 && tile / G2 == 2) g_cs_timeline[((size_t)blockIdx.x * 2 + grp) * 64 + 16 + (k)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define CS_ARRIVE(k) do { } while (0)
+#endif
 #else
 #define CS_STAMP(p) do { } while (0)
-#define CS_EXP(bit) 0
 #define CS_ARRIVE(k) do { } while (0)
 #endif
 
@@ -253,8 +255,13 @@ __global__ __launch_bounds__(512) void k_compat_softmax(const float *__restrict_
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int grp = wave >> 2, w4 = wave & 3;     // wave group (0/1) and wave within it
     const int i = lane & 31, h = lane >> 5;
-    const int64_t ntiles = (n + 127) / 128;
+    const int64_t ntiles = n / 128;               // WHOLE tiles only: the launcher hands the last n % 128 pixels to k_compat_tail
     const int64_t G2 = 2 * (int64_t)gridDim.x;
+
+    // RULE OF THIS KERNEL: no vector-ALU instruction inside the MFMA stream.  On gfx950 a VALU instruction between two
+    // v_mfma_f32_32x32x2_f32 does not overlap with them (tools/mfma_probe.hip: 16 register copies per 128 MFMAs cost
+    // 3 cycles per MFMA), so every address below is "scalar base + per-lane offset fixed for the whole kernel +
+    // immediate": the scalar unit does the arithmetic.
 
     // Chunk loader (LDS-DMA, no staging registers): a chunk is L labels x 8 slots of 16 B; one wave-instruction
     // fills 64 consecutive slots = 8 labels.  LDS stays linear (that is all the DMA can write); the bank
@@ -262,42 +269,56 @@ __global__ __launch_bounds__(512) void k_compat_softmax(const float *__restrict_
     // reads below apply the same XOR (the 16 lanes a ds_read_b128 serves at a time then hit 16 different
     // 16-byte bank groups).  The per-lane part of the address only depends on the parity of the
     // wave-instruction's index gi = w4*NT + r (label = 8 gi + lane/8, so (label >> 1) & 7 = (4 (gi & 1) + lane/16) & 7):
-    // two byte offsets serve all of them.
+    // two byte offsets serve all of them, picked once per wave (even r / odd r).
     const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float *)lds;
     const unsigned voff0 = ((lane >> 3) * L + 4 * ((lane & 7) ^ (lane >> 4))) * 4;
     const unsigned voff1 = ((lane >> 3) * L + 4 * ((lane & 7) ^ (4 + (lane >> 4)))) * 4;
+    const bool odd0 = (w4 * NT) & 1;
+    const unsigned voff_even = odd0 ? voff1 : voff0, voff_odd = odd0 ? voff0 : voff1;    // for even / odd r
+    auto load_mu_piece = [&](int kc, int buf, int r) {       // piece r of NT: 64 slots = 8 labels
+        const int gi = w4 * NT + r;              // wave-instruction index within the chunk (the group's four waves share it)
+        glds16(MuT + (int64_t)gi * 8 * L + 32 * kc, (r & 1) ? voff_odd : voff_even, lds_base + (buf * (L * 32) + gi * 256) * 4);
+    };
     auto load_mu = [&](int kc, int buf) {        // issued by the four waves of ONE group
 #pragma unroll
-        for (int r = 0; r < NT; r++) {
-            const int gi = w4 * NT + r;          // wave-instruction index: 64 slots = 8 labels
-            glds16(MuT + (int64_t)gi * 8 * L + 32 * kc, (gi & 1) ? voff1 : voff0, lds_base + (buf * (L * 32) + gi * 256) * 4);
-        }
+        for (int r = 0; r < NT; r++) load_mu_piece(kc, buf, r);
     };
-    auto x_row = [&](int64_t tile) {             // this lane's X row of a tile (clamped: loads stay in bounds)
-        return X + min(tile * 128 + w4 * 32 + i, n - 1) * x_rs + 4 * h;
-    };
-    // E0 / out addressing: a register r of the C/D map is pixel row rr(r) + 4h of the wave's 32, label 32t + lane&31:
-    // wave-uniform row pointer (scalar registers) + one per-lane byte offset for the whole kernel + 128 t -- no
-    // vector address arithmetic.  Rows beyond n (last tile only) are masked per lane, never clamped.
+    // B-operand reads: lane (i, h) takes k-part 2q + h of label 32t + i -> slot ((2q + h) ^ sw) of LDS row 32t + i
+    const int sw = (i >> 1) & 7;
+    const float *brow[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) brow[q] = lds + i * 32 + ((2 * q + h) ^ sw) * 4;
+
+    // E0 / out / X addressing: a register r of the C/D map is pixel row rr(r) + 4h of the wave's 32, label
+    // 32t + lane&31; the A operand of lane (i, h) is X[row i][8q + 4h ..].  Wave-uniform row pointer (scalar
+    // registers) + one per-lane byte offset for the whole kernel + an immediate.  Every tile is whole, so there is
+    // no row masking or clamping anywhere (a lane-dependent branch around a load would also make the compiler treat
+    // the whole 16-register accumulator as that load's destination and wait for it at every later touch).
     // Padding is applied where a value is CONSUMED, not where it is loaded (a select on a fresh load would make the
-    // wave wait for it): the last label tile's loads are clamped into the row, pad_e0() / pad_x() overwrite the
-    // padding afterwards.
+    // wave wait for it): loads of padded columns are clamped into the row, pad_e0() / pad_x() overwrite them later.
     const int h4 = 4 * h;
     const unsigned lo_e = (unsigned)(h4 * e_rs + i) * 4u, lo_o = (unsigned)(h4 * o_rs + i) * 4u;
     const unsigned lo_e_last = PAD ? (unsigned)(h4 * e_rs + min(32 * (NT - 1) + i, Lr - 1) - 32 * (NT - 1)) * 4u : lo_e;
+    const unsigned lo_x = (unsigned)(i * x_rs + h4) * 4u;
     const bool lane_stores_last = !PAD || 32 * (NT - 1) + i < Lr;
     auto rr = [](int r) { return (r & 3) + 8 * (r >> 2); };
-    auto rows_left = [&](int64_t tile) { return (int)min((int64_t)32, n - (tile * 128 + w4 * 32)); };   // of this wave (<= 0: none)
-    auto e0_load_row = [&](f32x16 *acc, int r, const float *wave_rows, int left) {       // wave_rows: E0 row of the wave's first pixel
-        if (rr(r) + h4 < left) {
-            const char *p = reinterpret_cast<const char *>(wave_rows + rr(r) * e_rs);
-#pragma unroll
-            for (int t = 0; t < NT; t++)
-                acc[t][r] = *reinterpret_cast<const float *>(p + 128 * t + ((PAD && t == NT - 1) ? lo_e_last : lo_e));
-        }
+#define PHL_E0_LOAD_ROW(r, wave_rows)  /* wave_rows: E0 row of the wave's first pixel */                                    \
+    do {                                                                                                                  \
+        const char *p_ = reinterpret_cast<const char *>((wave_rows) + rr(r) * e_rs);                                      \
+        _Pragma("unroll") for (int t = 0; t < NT; t++)                                                                    \
+            acc[t][r] = *reinterpret_cast<const float *>(p_ + 128 * t + ((PAD && t == NT - 1) ? lo_e_last : lo_e));       \
+    } while (0)
+    // A fragment q of chunk kc: columns 32 kc + 8q + 4h .. +3 of this lane's X row
+    auto x_load_q = [&](float4 &a, const float *wave_rows, int kc, int q) {
+        if (PAD && kc == NT - 1)                 // padded columns: clamp into the row (per-lane offsets, last chunk only)
+            a = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(wave_rows) +
+                                                  (unsigned)(i * x_rs + min(32 * kc + 8 * q + h4, Lr - 4)) * 4u);
+        else
+            a = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(wave_rows + 32 * kc) + 32 * q + lo_x);
     };
-    auto x_at = [&](const float *xrow, int k0) {      // 4 contraction values from column k0 + 4h (clamped under PAD)
-        return *reinterpret_cast<const float4 *>(xrow + (PAD ? min(k0, Lr - 4 - 4 * h) : k0));
+    auto x_load = [&](float4 (&a)[4], const float *wave_rows, int kc) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) x_load_q(a[q], wave_rows, kc, q);
     };
     auto pad_e0 = [&](f32x16 &last) {                 // only the last label tile holds padding (L - Lr < 32)
         if (PAD && 32 * (NT - 1) + i >= Lr) {
@@ -306,7 +327,7 @@ __global__ __launch_bounds__(512) void k_compat_softmax(const float *__restrict_
         }
     };
     auto pad_x = [&](float4 &v, int k0) {
-        if (PAD && k0 + 4 * h >= Lr) v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (PAD && k0 + h4 >= Lr) v = make_float4(0.f, 0.f, 0.f, 0.f);
     };
 
     // Tiles of this group: 2 (b + k gridDim) + grp, k = 0, 1, ...  Every wave alternates the MFMA half of a tile (NT
@@ -318,15 +339,11 @@ __global__ __launch_bounds__(512) void k_compat_softmax(const float *__restrict_
     int64_t tile = 2 * (int64_t)blockIdx.x + grp;
     bool valid = tile < ntiles;                  // wave-uniform
     f32x16 acc[NT];
-    float4 a_cur[4], a_nxt[4];
+    float4 a[2][4];                              // A fragments: chunk kc lives in a[kc & 1] (no copies between chunks)
     if (valid) {
-        const float *erows = E0 + (tile * 128 + w4 * 32) * e_rs;
-        const int left = rows_left(tile);
 #pragma unroll
-        for (int r = 0; r < 16; r++) e0_load_row(acc, r, erows, left);
-        const float *xrow = x_row(tile);
-#pragma unroll
-        for (int q = 0; q < 4; q++) a_nxt[q] = x_at(xrow, 8 * q);
+        for (int r = 0; r < 16; r++) PHL_E0_LOAD_ROW(r, E0 + (tile * 128 + w4 * 32) * e_rs);
+        x_load(a[0], X + (tile * 128 + w4 * 32) * x_rs, 0);
     }
     int slot = 0;                                // chunks since the start: chunk `slot` sits in LDS buffer slot & 1
     if (grp == 0) {
@@ -337,51 +354,84 @@ __global__ __launch_bounds__(512) void k_compat_softmax(const float *__restrict_
     if (grp == 1) {
         for (int s = 0; s < NT; s++, slot++) __builtin_amdgcn_s_barrier();
     }
-    const int sw = (i >> 1) & 7;                 // the swizzle of the labels this lane reads (32t + i)
+
+    // One K chunk of the MFMA half.  PAR = kc & 1 picks the A registers; for even NT it is also the LDS buffer (a
+    // half is NT slots, so `slot` is even whenever a half starts) and every LDS offset is an immediate.
+    auto chunk = [&](auto par, int kc, const float *xrows) {
+        constexpr int PAR = decltype(par)::value;
+        const int buf = (NT % 2 == 0) ? PAR : (slot & 1);
+        // The prefetch for the NEXT slot -- Mu's chunk (of this tile, or chunk 0 for the other group's tile; its buffer
+        // was last read in the previous slot, behind the barrier) and this tile's next A fragments -- is issued in
+        // pieces BETWEEN the MFMA steps: an LDS-DMA instruction takes 100-200 cycles to issue, and the 8 of them + 4
+        // loads in one block ahead of the MFMAs kept the matrix pipe idle for a quarter of the chunk (in-kernel
+        // stamps: 2.7k of 10.9k cycles).
+        const int kc_next = kc + 1 < NT ? kc + 1 : 0;
+        CS_ARRIVE(kc * 4 + 0);
+        if (valid) {
+            if (PAD && kc == NT - 1) {
+#pragma unroll
+                for (int q = 0; q < 4; q++) pad_x(a[PAR][q], 32 * kc + 8 * q);
+            }
+            // B operands in half-groups of NT/2 label tiles, software-pipelined by hand: the LDS reads of step s+1 are
+            // issued BEFORE the MFMAs of step s (only one wave per SIMD is on the matrix cores at a time, so an LDS round
+            // trip left exposed is matrix-pipe time lost).
+            constexpr int HT = (NT + 1) / 2, STEPS = NT > 1 ? 8 : 4;     // NT == 1: whole groups
+            float4 b[2][HT];
+            auto read_b = [&](int st, float4 (&dst)[HT]) {
+                const int q = NT > 1 ? st >> 1 : st, t0 = NT > 1 ? (st & 1) * HT : 0;
+#pragma unroll
+                for (int t = 0; t < HT; t++)
+                    if (t0 + t < NT) dst[t] = *reinterpret_cast<const float4 *>(brow[q] + buf * (L * 32) + (t0 + t) * 32 * 32);
+            };
+            read_b(0, b[0]);
+#pragma unroll
+            for (int st = 0; st < STEPS; st++) {
+                const int q = NT > 1 ? st >> 1 : st, t0 = NT > 1 ? (st & 1) * HT : 0;
+                if (st + 1 < STEPS) read_b(st + 1, b[(st + 1) & 1]);
+#pragma unroll
+                for (int r = 0; r < NT; r++)
+                    if (r * STEPS / NT == st) load_mu_piece(kc_next, buf ^ 1, r);
+                if (kc + 1 < NT) {
+                    if (STEPS == 8 && (st & 1)) x_load_q(a[PAR ^ 1][st >> 1], xrows, kc + 1, st >> 1);
+                    if (STEPS == 4) x_load_q(a[PAR ^ 1][st], xrows, kc + 1, st);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                float4(&bc)[HT] = b[st & 1];
+                const float4 av = a[PAR][q];
+#pragma unroll
+                for (int t = 0; t < HT; t++) if (t0 + t < NT) acc[t0 + t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bc[t].x, acc[t0 + t], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < HT; t++) if (t0 + t < NT) acc[t0 + t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bc[t].y, acc[t0 + t], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < HT; t++) if (t0 + t < NT) acc[t0 + t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bc[t].z, acc[t0 + t], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < HT; t++) if (t0 + t < NT) acc[t0 + t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bc[t].w, acc[t0 + t], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+            load_mu(kc_next, buf ^ 1);           // (a group out of tiles only keeps the LDS ring fed)
+        }
+        CS_ARRIVE(kc * 4 + 2);
+        dma_drain();                             // the next chunk's DMA
+        CS_ARRIVE(kc * 4 + 3);
+        __builtin_amdgcn_s_barrier();
+        slot++;
+    };
 
     for (int64_t it = 0; it < iters; it++) {
         CS_STAMP(2 * it);
         // =========== MFMA half: E = E0 + X @ Mu on `tile`; the group in this half feeds the LDS ring ===========
         {
-            const float *xrow = x_row(valid ? tile : 0);
+            const float *xrows = X + ((valid ? tile : 0) * 128 + w4 * 32) * x_rs;
+            // every E0 load has landed by now (they were issued at least a slot ago); saying so HERE, with a use of
+            // the accumulator that was loaded last, keeps the compiler from guarding single registers later
+#ifdef __HIP_DEVICE_COMPILE__                    /* (the host pass has no "v" registers) */
+            asm volatile("" ::"v"(acc[NT - 1]));
+#endif
             pad_e0(acc[NT - 1]);
-            for (int kc = 0; kc < NT; kc++, slot++) {
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    a_cur[q] = a_nxt[q];
-                    if (kc == NT - 1) pad_x(a_cur[q], 32 * kc + 8 * q);
-                }
-                // next chunk (of this tile, or chunk 0 for the other group's tile): its buffer was last read in the
-                // previous slot, behind the barrier
-                load_mu(kc + 1 < NT ? kc + 1 : 0, (slot + 1) & 1);
-                if (valid && kc + 1 < NT && !CS_EXP(8)) {
-#pragma unroll
-                    for (int q = 0; q < 4; q++) a_nxt[q] = x_at(xrow, 32 * (kc + 1) + 8 * q);
-                }
-                // keep the prefetch HERE: left alone, the scheduler sinks these loads to the end of the chunk
-                __builtin_amdgcn_sched_barrier(0);
-                if (valid) {
-                    const float *bbase = lds + (slot & 1) * (L * 32) + i * 32;
-#pragma unroll
-                    for (int q = 0; q < 4; q++) {
-                        float4 b[NT];
-                        const int sl = ((2 * q + h) ^ sw) * 4;
-#pragma unroll
-                        for (int t = 0; t < NT; t++) b[t] = *reinterpret_cast<const float4 *>(bbase + t * 32 * 32 + sl);
-#pragma unroll
-                        for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[q].x, b[t].x, acc[t], 0, 0, 0);
-#pragma unroll
-                        for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[q].y, b[t].y, acc[t], 0, 0, 0);
-#pragma unroll
-                        for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[q].z, b[t].z, acc[t], 0, 0, 0);
-#pragma unroll
-                        for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[q].w, b[t].w, acc[t], 0, 0, 0);
-                    }
-                }
-                CS_ARRIVE(16 + kc);              // (before the drain)
-                dma_drain();                     // the next chunk's DMA: issued a whole chunk of MFMAs ago
-                CS_ARRIVE(kc);
-                __builtin_amdgcn_s_barrier();
+            for (int kc = 0; kc < NT; kc += 2) {
+                chunk(std::integral_constant<int, 0>(), kc, xrows);
+                if (kc + 1 < NT) chunk(std::integral_constant<int, 1>(), kc + 1, xrows);
             }
         }
         CS_STAMP(2 * it + 1);
@@ -396,9 +446,12 @@ __global__ __launch_bounds__(512) void k_compat_softmax(const float *__restrict_
             const bool has_next = nxt < ntiles;  // uniform
             float *orows = out + (tile * 128 + w4 * 32) * o_rs;                        // wave-uniform
             const float *erows = E0 + ((has_next ? nxt : tile) * 128 + w4 * 32) * e_rs;
-            const int left_o = valid ? rows_left(tile) : 0, left_e = has_next ? rows_left(nxt) : 0;
             float scale[16];
-            if (valid && !LOGITS && !CS_EXP(4)) {
+#ifdef PHL_CS_NO_EPILOGUE            /* timing experiment: the MFMA halves alone */
+            if (false) {
+#else
+            if (valid && !LOGITS) {
+#endif
                 float m[16];
 #pragma unroll
                 for (int r = 0; r < 16; r++) {   // softmax(-E): shift by the row MINIMUM of E
@@ -422,8 +475,18 @@ __global__ __launch_bounds__(512) void k_compat_softmax(const float *__restrict_
                     scale[r] = s0 + s1;
                 }
                 half_wave_sum16(scale);
+                // Q = exp / sum, in place and BEFORE the first E0 load of the next tile is issued: a write to one
+                // register of a 16-register accumulator while a load into another one is in flight makes the
+                // compiler wait for that load (it tracks the accumulator as one unit)
 #pragma unroll
-                for (int r = 0; r < 16; r++) scale[r] = __builtin_amdgcn_rcpf(scale[r]);
+                for (int r = 0; r < 16; r++) {
+                    scale[r] = __builtin_amdgcn_rcpf(scale[r]);
+#pragma unroll
+                    for (int t = 0; t < NT; t++) acc[t][r] *= scale[r];
+                }
+            } else if (valid) {                  // CRFasRNN returns -E of the last iteration, not Q (crf_module.py:103)
+#pragma unroll
+                for (int t = 0; t < NT; t++) acc[t] = -acc[t];
             }
 #pragma unroll
             for (int s = 0; s < NT; s++) {
@@ -432,22 +495,19 @@ __global__ __launch_bounds__(512) void k_compat_softmax(const float *__restrict_
 #pragma unroll
                 for (int r = 0; r < 16; r++) {   // (constant trip counts: both loops unroll and the test folds)
                     if (r < r_lo || r >= r_hi) continue;
-                    if (rr(r) + h4 < left_o && !CS_EXP(1)) {
-                        const float sc = LOGITS ? -1.0f : scale[r];     // CRFasRNN returns -E (crf_module.py:103)
+#ifdef PHL_CS_NO_EPILOGUE
+                    if (n != -12345) continue;     /* (never true: keeps the accumulators alive) */
+#endif
+                    if (valid) {
                         char *p = reinterpret_cast<char *>(orows + rr(r) * o_rs);
 #pragma unroll
                         for (int t = 0; t < NT; t++)
-                            if (!PAD || t < NT - 1 || lane_stores_last) *reinterpret_cast<float *>(p + 128 * t + lo_o) = acc[t][r] * sc;
+                            if (!PAD || t < NT - 1 || lane_stores_last) *reinterpret_cast<float *>(p + 128 * t + lo_o) = acc[t][r];
                     }
                     // this row's registers are free: the next tile's E0 goes in
-                    if (!CS_EXP(2)) e0_load_row(acc, r, erows, left_e);
+                    if (has_next) PHL_E0_LOAD_ROW(r, erows);
                 }
-                if (s == NT - 1 && has_next) {
-                    const float *xn = x_row(nxt);
-#pragma unroll
-                    for (int q = 0; q < 4; q++) a_nxt[q] = x_at(xn, 8 * q);
-                }
-                CS_ARRIVE(NT + s);
+                if (s == NT - 1 && has_next) x_load(a[0], X + (nxt * 128 + w4 * 32) * x_rs, 0);
                 __builtin_amdgcn_s_barrier();
                 slot++;
             }
@@ -460,6 +520,48 @@ __global__ __launch_bounds__(512) void k_compat_softmax(const float *__restrict_
     }
 }
 
+// The last n % 128 pixels of phl_compat_softmax (the tile kernel takes whole tiles only): one workgroup per pixel,
+// thread c owns label c -- an fmaf chain over k straight from the transposed compatibility matrix, then the row
+// softmax through LDS.  At most 127 pixels: its speed does not matter, its arithmetic is the tile kernel's
+// (f32 fma chain from E0, exp2 of the log2e-scaled difference to the row minimum).
+template <bool LOGITS>
+__global__ __launch_bounds__(256) void k_compat_tail(const float *__restrict__ E0, int64_t e_rs, const float *__restrict__ X,
+                                                     int64_t x_rs, const float *__restrict__ MuT, int Lp,
+                                                     float *__restrict__ out, int64_t o_rs, int64_t p0, int L)
+{
+    __shared__ float xs[256], red[256];
+    const int64_t p = p0 + blockIdx.x;
+    const int c = threadIdx.x;
+    xs[c] = c < L ? X[p * x_rs + c] : 0.f;
+    __syncthreads();
+    float e = INFINITY;
+    if (c < L) {
+        e = E0[p * e_rs + c];
+        for (int k = 0; k < L; k++) e = __builtin_fmaf(xs[k], MuT[(int64_t)c * Lp + k], e);
+    }
+    if (LOGITS) {
+        if (c < L) out[p * o_rs + c] = -e;
+        return;
+    }
+    red[c] = e;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (c < o) red[c] = fminf(red[c], red[c + o]);
+        __syncthreads();
+    }
+    const float m = red[0] * 1.4426950408889634f;
+    __syncthreads();
+    const float v = c < L ? __builtin_amdgcn_exp2f(__builtin_fmaf(e, -1.4426950408889634f, m)) : 0.f;
+    red[c] = v;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (c < o) red[c] += red[c + o];
+        __syncthreads();
+    }
+    if (c < L) out[p * o_rs + c] = v * __builtin_amdgcn_rcpf(red[0]);
+}
+
+#undef PHL_E0_LOAD_ROW
 inline unsigned rows_grid(int64_t n)
 {
     int64_t b = (n + 3) / 4;
@@ -493,7 +595,7 @@ int phl_compat_softmax(const float *E0, int64_t e_rs, const float *X, int64_t x_
 {
     if (n < 0 || L < 1 || (n > 0 && (!E0 || !X || !MuT || !out))) { phl_set_error("phl_compat_softmax: bad arguments"); return PHL_ERR_INVALID; }
     if (n == 0) return PHL_OK;
-    if (L % 4 || L > 256 || x_rs % 4 || e_rs % 4 || o_rs % 4 ||
+    if (L % 4 || L > 256 || x_rs % 4 || e_rs % 4 || o_rs % 4 || x_rs >= (1 << 24) || e_rs >= (1 << 24) || o_rs >= (1 << 24) ||
         ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(MuT) | reinterpret_cast<uintptr_t>(E0) | reinterpret_cast<uintptr_t>(out)) & 15)) {
         phl_set_error("phl_compat_softmax: needs L %% 4 == 0, L <= 256 and 16-byte aligned E0 / X / out rows (L=%d)", L);
         return PHL_ERR_UNSUPPORTED;
@@ -501,8 +603,9 @@ int phl_compat_softmax(const float *E0, int64_t e_rs, const float *X, int64_t x_
     const int Lp = (L + 31) / 32 * 32;       // the tile width: mu_t is [Lp][Lp], zero beyond L
     const bool pad = Lp != L;
     hipStream_t st = (hipStream_t)stream;
-    // persistent workgroups, one per CU (256 CUs): each walks pairs of 128-pixel tiles (one per wave group)
-    const int64_t npairs = ((n + 127) / 128 + 1) / 2;
+    // persistent workgroups, one per CU (256 CUs): each walks pairs of whole 128-pixel tiles (one per wave group);
+    // the last n % 128 pixels go to k_compat_tail
+    const int64_t n_main = n / 128 * 128, npairs = (n / 128 + 1) / 2;
     const unsigned grid = (unsigned)(npairs < 256 ? npairs : 256);
     const size_t lds = (size_t)2 * Lp * 32 * sizeof(float);
     const bool logits = (flags & PHL_COMPAT_LOGITS) != 0;     // LDS is 2*L*128 B <= 64 KiB: no attribute needed
@@ -511,16 +614,14 @@ int phl_compat_softmax(const float *E0, int64_t e_rs, const float *X, int64_t x_
     if (const char *path = getenv("PHL_COMPAT_TIMELINE")) {
         if (tl_buf) {                            // dump the previous launch
             hipDeviceSynchronize();
-            std::vector<unsigned long long> hbuf(512 * 40);
+            std::vector<unsigned long long> hbuf(512 * 64);
             hipMemcpy(hbuf.data(), tl_buf, hbuf.size() * 8, hipMemcpyDeviceToHost);
             if (FILE *f = fopen(path, "wb")) { fwrite(hbuf.data(), 8, hbuf.size(), f); fclose(f); }
         } else {
-            hipMalloc(&tl_buf, 512 * 40 * 8);
+            hipMalloc(&tl_buf, 512 * 64 * 8);
             hipMemcpyToSymbol(HIP_SYMBOL(g_cs_timeline), &tl_buf, sizeof(tl_buf));
-            const int exp_mode = getenv("PHL_CS_EXP") ? atoi(getenv("PHL_CS_EXP")) : 0;
-            hipMemcpyToSymbol(HIP_SYMBOL(g_cs_exp), &exp_mode, sizeof(exp_mode));
         }
-        hipMemset(tl_buf, 0, 512 * 40 * 8);
+        hipMemset(tl_buf, 0, 512 * 64 * 8);
     }
 #endif
 #define PHL_CS(NT_)                                                                                                       \
@@ -530,8 +631,14 @@ int phl_compat_softmax(const float *E0, int64_t e_rs, const float *X, int64_t x_
         else if (pad) k_compat_softmax<NT_, false, true><<<dim3(grid), dim3(512), lds, st>>>(E0, e_rs, X, x_rs, MuT, out, o_rs, n, L);            \
         else k_compat_softmax<NT_, false, false><<<dim3(grid), dim3(512), lds, st>>>(E0, e_rs, X, x_rs, MuT, out, o_rs, n, L);                    \
         break;
-    switch (Lp / 32) {
-        PHL_CS(1) PHL_CS(2) PHL_CS(3) PHL_CS(4) PHL_CS(5) PHL_CS(6) PHL_CS(7) PHL_CS(8)
+    if (n_main > 0) {
+        switch (Lp / 32) {
+            PHL_CS(1) PHL_CS(2) PHL_CS(3) PHL_CS(4) PHL_CS(5) PHL_CS(6) PHL_CS(7) PHL_CS(8)
+        }
+    }
+    if (n > n_main) {
+        if (logits) k_compat_tail<true><<<dim3((unsigned)(n - n_main)), dim3(256), 0, st>>>(E0, e_rs, X, x_rs, MuT, Lp, out, o_rs, n_main, L);
+        else k_compat_tail<false><<<dim3((unsigned)(n - n_main)), dim3(256), 0, st>>>(E0, e_rs, X, x_rs, MuT, Lp, out, o_rs, n_main, L);
     }
 #undef PHL_CS
     PHL_HIP(hipGetLastError());

@@ -72,6 +72,78 @@ void mix()
     hipFree(d);
 }
 
+// The compat kernel's inner loop in isolation: per q-group 8 ds_read_b128 (B operands, swizzled like the kernel's)
+// and 32 MFMAs on 8 accumulators; MODE 0 = B from registers only, 1 = with the LDS reads, 2 = reads + a barrier
+// every 4 q-groups.
+__device__ __forceinline__ float hashf(unsigned x)      // pseudo-random float in [-1, 1)
+{
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return (float)(int)x * (1.0f / 2147483648.0f);
+}
+// LB = the launch bound: 256 lets the compiler keep the accumulators in AccVGPRs (512 registers per lane at one
+// wave per SIMD), 512 halves the budget and they end up in architectural VGPRs next to the A/B operands
+template <int MODE, int LB = 256>
+__global__ __launch_bounds__(LB) void k_loop(float *out, int iters, int random)
+{
+    __shared__ __attribute__((aligned(16))) float lds[2 * 256 * 32];
+    for (int j = threadIdx.x; j < 2 * 256 * 32; j += 256) lds[j] = random ? hashf(j * 7919u + blockIdx.x) : (float)(j & 15);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, i = lane & 31, h = lane >> 5, sw = (i >> 1) & 7;
+    f32x16 acc[8];
+    for (int t = 0; t < 8; t++) for (int r = 0; r < 16; r++) acc[t][r] = (float)(threadIdx.x + t);
+    float4 a = make_float4(1.f + lane, 2.f, 3.f, 4.f);
+    float4 aq[4], an[4];
+    for (int q = 0; q < 4; q++) { aq[q] = make_float4(1.f + lane + q, 2.f, 3.f + q, 4.f); an[q] = aq[q]; }
+    float4 b[8];
+    for (int t = 0; t < 8; t++) b[t] = make_float4(1.f + t, 2.f, 3.f, 4.f);
+    if (random) {
+        a = make_float4(hashf(threadIdx.x), hashf(threadIdx.x + 999), hashf(threadIdx.x + 77777), hashf(threadIdx.x + 31337));
+        for (int t = 0; t < 8; t++) b[t] = make_float4(hashf(lane * 8 + t), hashf(lane * 8 + t + 4096), hashf(lane * 8 + t + 9999), hashf(lane + t * 131));
+        for (int t = 0; t < 8; t++) for (int r = 0; r < 16; r++) acc[t][r] = hashf(threadIdx.x * 128 + t * 16 + r);
+    }
+    for (int it = 0; it < iters; it++) {
+        const float *bbase = lds + (it & 1) * (256 * 32) + i * 32;
+        if (MODE >= 3) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) { aq[q] = an[q]; asm volatile("" : "+v"(an[q].x), "+v"(an[q].y), "+v"(an[q].z), "+v"(an[q].w)); }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            if (MODE >= 3) a = aq[q];
+            if (MODE >= 1) {
+                const int sl = ((2 * q + h) ^ sw) * 4;
+#pragma unroll
+                for (int t = 0; t < 8; t++) b[t] = *reinterpret_cast<const float4 *>(bbase + t * 32 * 32 + sl);
+            }
+#pragma unroll
+            for (int t = 0; t < 8; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b[t].x, acc[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < 8; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b[t].y, acc[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < 8; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b[t].z, acc[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < 8; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b[t].w, acc[t], 0, 0, 0);
+        }
+        if (MODE >= 2) __builtin_amdgcn_s_barrier();
+    }
+    float s = 0;
+    for (int t = 0; t < 8; t++) for (int r = 0; r < 16; r++) s += acc[t][r];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+template <int MODE, int LB = 256>
+void loop_probe(int blocks, int random = 0)
+{
+    float *d; hipMalloc(&d, blocks * 256 * 4);
+    hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+    const int iters = 2048;
+    k_loop<MODE, LB><<<blocks, 256>>>(d, iters, random); hipDeviceSynchronize();
+    hipEventRecord(a); k_loop<MODE, LB><<<blocks, 256>>>(d, iters, random); hipEventRecord(b); hipEventSynchronize(b);
+    float ms; hipEventElapsedTime(&ms, a, b);
+    printf("inner loop mode %d%s bound %d, %d waves/SIMD: %.1f cycles per MFMA per SIMD (at 2.4 GHz), %.1f TFLOP/s\n", MODE, random ? " RANDOM data" : "", LB, blocks / 256,
+           ms * 1e-3 * 2.4e9 / (iters * 128.0 * (blocks / 256)), (double)blocks * 4 * iters * 128 * 4096 / ms / 1e9);
+    hipFree(d);
+}
+
 // Co-execution: one 512-thread workgroup per CU = 2 waves per SIMD.  Waves 0-3 issue MFMAs, waves 4-7 run `mode`:
 // 1 = independent v_fma chains, 2 = streaming global loads + stores (dword per lane, 128-byte segments).
 // Each group's duration comes from its own 100 MHz stamps (max over the grid).
@@ -145,6 +217,7 @@ int main(int argc, char **argv)
     if (argc > 1) {
         float *mem; const size_t bytes = (size_t)256 * 4 * 1024 * 8192;    // other_iters <= 1024
         hipMalloc(&mem, bytes); hipMemset(mem, 0, bytes);
+        loop_probe<3, 512>(256); loop_probe<3, 512>(512); loop_probe<3, 256>(256); loop_probe<1, 512>(256); loop_probe<0>(256, 1); loop_probe<1>(256, 1); loop_probe<1>(512, 1); loop_probe<0>(256); loop_probe<1>(256); loop_probe<2>(256); loop_probe<0>(512); loop_probe<1>(512); loop_probe<2>(512);
         mix<0>(); mix<2>(); mix<4>(); mix<8>(); mix<12>(); mix<16>();
         coexec(2048, 0, 1, mem); coexec(0, 4096, 1, mem); coexec(2048, 4096, 1, mem); coexec(2048, 1024, 1, mem);
         coexec(0, 1024, 2, mem); coexec(2048, 1024, 2, mem); coexec(2048, 256, 2, mem);
