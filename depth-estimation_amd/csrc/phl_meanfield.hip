@@ -137,29 +137,46 @@ __global__ __launch_bounds__(256) void k_stream_copy(const vf4 *__restrict__ src
 // gfx950 has no xf32/TF32 path and the reference computes in f32), with +E0, negate and the row softmax done on
 // the accumulators.  Neither G = X@Mu nor E ever exists in HBM: the iteration's non-lattice half moves 3 x [n,L]
 // (read X, read E0, write Q) instead of the 7 x [n,L] of GEMM + fused softmax, and is MFMA-bound
-// (2 n L^2 flop at ~155 TF f32: 2.7 ms for 2048x1536x256).
+// (2 n L^2 flop at ~150 TF f32: 2.75 ms for 2048x1536x256).
 //
-// Tiling.  L = 32*NT <= 256, so a pixel's whole label row fits one workgroup: 256 threads = 4 waves, a wave owns
-// 32 pixels x all L labels = NT accumulator tiles of 32x32 (16 VGPRs each, 128 at L = 256), two workgroups per CU
-// so that one wave's epilogue (exp, stores) runs under its SIMD partner's MFMAs.  K = L is walked in chunks of
-// 32: Mu's chunk (32 k x L labels, 32 KiB) is shared by the four waves through LDS, double buffered; X comes
-// straight from global memory (each value is used by one wave only).
+// Tiling.  L = 32*NT <= 256, so a pixel's whole label row fits one wave: a wave owns 32 pixels x all L labels = NT
+// accumulator tiles of 32x32 (16 VGPRs each, 128 at L = 256).  One persistent 512-thread workgroup per CU = two
+// GROUPS of four waves, one wave of each per SIMD, working in anti-phase on alternate 128-pixel tiles: while one
+// group walks K = L in NT chunks of 32 on the matrix cores ("MFMA half", NT slots), the other one is in the
+// "epilogue half" of its previous tile -- stores Q, fetches the next tile's E0 straight into the accumulators (the
+// MFMA's C input) -- and FEEDS the first: both operands of the MFMA stream come through LDS rings (Mu's chunk,
+// 32 k x L labels = 32 KiB shared by the four waves; the tile's X chunk, 16 KiB), filled by LDS-DMA two slots
+// ahead.  Every slot ends in the workgroup barrier.  The product is computed transposed (labels = MFMA rows), so
+// that a lane holds four consecutive labels of a pixel in four consecutive registers (16-byte E0 / Q accesses)
+// and a pixel's row sits in two lanes (softmax reductions: in-lane + one v_permlane32_swap).
 //
-// Operand maps (32x32x2: lane l = (i = l&31, h = l>>5) supplies A[i][k-slot h] and B[k-slot h][j = i]).  The k
-// order of a contraction is free as long as A and B agree, so a lane loads 16 B = X[row i][8q+4h .. 8q+4h+3]
-// and the four values feed MFMAs u = 0..3 of group q: MFMA (q,u) contracts k = 8q+u (lower half-wave) and
-// k = 8q+4+u (upper).  B must follow: lane (j,h) takes Mu[8q+4h+u][32t+j], u = 0..3 -- 16 contiguous bytes of
-// the TRANSPOSED compatibility matrix, which is what the caller passes (MuT[c][k]) and what the LDS image
-// holds: Bt[label][k], 128-byte rows whose 16-byte slots are XOR-swizzled (see the chunk loader).
-// 16 bytes global -> LDS without a register in between (global_load_lds_dwordx4): the LDS address is the
-// wave-uniform `l` plus lane*16, the global address is per lane
+// What shaped it (all measured on gfx950; tools/mfma_probe.hip, tools/compat_timeline.py):
+//  * v_mfma_f32_32x32x2_f32 does not overlap with anything else the SIMD issues: a VALU instruction slipped between
+//    two MFMAs costs its own time plus a bubble (SQ_VALU_MFMA_COEXEC_CYCLES = 0), and the OTHER wave of the SIMD --
+//    VALU, scalar or memory instructions alike -- only gets issue slots in the stream's gaps.  Two independent
+//    workgroups per CU therefore do not hide an epilogue behind a partner's MFMAs; they take turns anyway, and
+//    unsynchronised they also spend time with both in their epilogue and the matrix pipe idle.
+//  * a vector-memory instruction takes 100-200 cycles to ISSUE (an LDS-DMA piece as much as a load): the 8 + 4 of
+//    them a wave needed per chunk kept the pipe idle for a quarter of the chunk, wherever in the chunk they stood.
+//    Hence the loader duty of the epilogue group: the waves on the matrix cores issue MFMAs and LDS reads, nothing else.
+//  * a wave can have only 63 vector-memory operations in flight; with a dword per lane (the untransposed C/D map)
+//    that cap, at ~5 us loaded latency, paced the epilogue.  Hence 16-byte accesses.
+//  * LDS-DMA pieces issued right behind the barrier delay the LDS reads the other group's first MFMAs wait for
+//    (0.8 us per slot): the feeder sleeps 256 cycles first.
+//
+// Operand maps (32x32x2: lane l = (i = l&31, h = l>>5) supplies A[i][k-slot h] and B[k-slot h][j = i]).  A = Mu^T
+// (rows = labels 32t + i), B = X^T (columns = the wave's pixels).  The k order of a contraction is free as long as
+// A and B agree, so a lane reads 16 B = X[pixel i][8q+4h .. 8q+4h+3] and the four values feed MFMAs u = 0..3 of
+// group q: MFMA (q,u) contracts k = 8q+u (lower half-wave) and k = 8q+4+u (upper); for A the lane reads
+// Mu^T[32t+i][8q+4h .. +3] -- 16 contiguous bytes of the TRANSPOSED compatibility matrix, which is what the caller
+// passes (MuT[c][k]).  Both LDS images are [row][32 k] with 128-byte rows whose 16-byte slots are XOR-swizzled (see
+// the feeder).  16 bytes global -> LDS without a register in between (global_load_lds_dwordx4): the LDS address is
+// wave-uniform (M0) plus lane*16, the global address is per lane.
 //
 // The DMA is issued through inline assembly, NOT __builtin_amdgcn_global_load_lds: with the builtin the compiler
-// knows an LDS write is in flight, cannot tell it from the buffer the ds_reads below use, and puts
-// `s_waitcnt vmcnt(0)` in front of the first ds_read after every prefetch -- each chunk then waits out a full
-// memory round trip with its MFMAs idle (measured: 60 us per tile phase against 28 us of MFMA work).  The
-// kernel's own protocol makes the wait unnecessary (a buffer is only read behind the barrier that follows its
-// DMA), so the kernel waits itself: dma_drain() before each barrier.
+// knows an LDS write is in flight, cannot tell it from the buffer the ds_reads use, and puts `s_waitcnt vmcnt(0)`
+// in front of the first ds_read after every prefetch.  The kernel's own protocol makes that wait unnecessary (a
+// buffer is only read behind the barrier that follows the counted wait for its DMA).
 // Addressing: scalar base (SGPR pair) + 32-bit per-lane byte offset, so that a whole chunk's DMAs share two VGPRs.
 __device__ __forceinline__ void glds16(const float *sbase, unsigned voff, unsigned lds_addr)
 {
@@ -172,60 +189,19 @@ __device__ __forceinline__ void dma_drain() { asm volatile("s_waitcnt vmcnt(0)" 
 // VALU helpers of the epilogue.  v_mfma_f32_32x32x2_f32 and ordinary VALU instructions do NOT overlap on gfx950
 // (tools/mfma_probe.hip: every v_fma slipped between two MFMAs costs its own issue time plus a ~10-cycle bubble,
 // SQ_VALU_MFMA_COEXEC_CYCLES reads 0), so every epilogue instruction is paid for in matrix-pipe time: minima
-// without the compiler's NaN canonicalisation (v_max x,x before every v_min), cross-lane steps as DPP modifiers
-// of the min / add itself instead of ds_bpermute round trips.
+// three at a time and without the compiler's NaN canonicalisation (v_max x,x before every v_min), the one
+// cross-lane step as a lane-half swap instead of a ds_bpermute round trip.  (The swap is inline assembly because
+// __builtin_amdgcn_permlane16/32_swap hands back its FIRST result twice in this compiler -- ROCm 7.2, checked with
+// tools/dpp_probe.hip.)
 __device__ __forceinline__ float vmin3(float a, float b, float c)
 {
     float r;
     asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
     return r;
 }
-// (s_nop 1: a DPP source needs two wait states behind the VALU write of that register, and the compiler's hazard
-// recogniser does not look inside inline assembly)
-#define PHL_DPP_ROR(op, x, n)                                                                                             \
-    asm("s_nop 1\n\t" op " %0, %1, %1 row_ror:" #n " row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(x) : "v"(x))
-// v_permlane16_swap_b32 a, b: the odd 16-lane rows of a trade places with the even rows of b.  Inline assembly
-// because __builtin_amdgcn_permlane16_swap hands back its FIRST result twice in this compiler (ROCm 7.2; checked
-// with tools/dpp_probe.hip).
-#define PHL_ROW_SWAP(a, b) asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b))
-// all-reduce of 16 values at once over the 32 lanes of a half-wave (two DPP rows of 16): rotations inside the row,
-// then the row swap.  Step-major, so that consecutive instructions are independent (a DPP operand must not have
-// been written by the instruction just before it).
-__device__ __forceinline__ void half_wave_min16(float (&x)[16])
-{
-#pragma unroll
-    for (int r = 0; r < 16; r++) PHL_DPP_ROR("v_min_f32_dpp", x[r], 8);
-#pragma unroll
-    for (int r = 0; r < 16; r++) PHL_DPP_ROR("v_min_f32_dpp", x[r], 4);
-#pragma unroll
-    for (int r = 0; r < 16; r++) PHL_DPP_ROR("v_min_f32_dpp", x[r], 2);
-#pragma unroll
-    for (int r = 0; r < 16; r++) PHL_DPP_ROR("v_min_f32_dpp", x[r], 1);
-#pragma unroll
-    for (int r = 0; r < 16; r++) {
-        float a = x[r], b = x[r];       // -> (row0,row0,row2,row2), (row1,row1,row3,row3)
-        PHL_ROW_SWAP(a, b);
-        asm("v_min_f32 %0, %1, %2" : "=v"(x[r]) : "v"(a), "v"(b));
-    }
-}
-__device__ __forceinline__ void half_wave_sum16(float (&x)[16])
-{
-#pragma unroll
-    for (int r = 0; r < 16; r++) PHL_DPP_ROR("v_add_f32_dpp", x[r], 8);
-#pragma unroll
-    for (int r = 0; r < 16; r++) PHL_DPP_ROR("v_add_f32_dpp", x[r], 4);
-#pragma unroll
-    for (int r = 0; r < 16; r++) PHL_DPP_ROR("v_add_f32_dpp", x[r], 2);
-#pragma unroll
-    for (int r = 0; r < 16; r++) PHL_DPP_ROR("v_add_f32_dpp", x[r], 1);
-#pragma unroll
-    for (int r = 0; r < 16; r++) {
-        float a = x[r], b = x[r];
-        PHL_ROW_SWAP(a, b);
-        x[r] = a + b;
-    }
-}
-
+// v_permlane32_swap_b32 a, b: the upper 32 lanes of a trade places with the lower 32 lanes of b (checked on the GPU:
+// with a = b = x on entry, a holds x[lane & 31] and b holds x[32 + (lane & 31)] in every lane afterwards)
+#define PHL_HALF_SWAP(a, b) asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b))
 #ifdef PHL_COMPAT_TIMELINE
 // debug build only (make EXTRA=-DPHL_COMPAT_TIMELINE): per wave group, 100 MHz stamps of the first 16 phase starts
 __device__ unsigned long long *g_cs_timeline;
@@ -240,6 +216,16 @@ __device__ unsigned long long *g_cs_timeline;
 #define CS_ARRIVE(k) do { } while (0)
 #endif
 
+// compile-time loop: f(integral_constant<int, I>) for I = 0 .. N-1 (slot-dependent wait counts must be immediates)
+template <int N, int I = 0, class F>
+__device__ __forceinline__ void static_for(F &&f)
+{
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>());
+        static_for<N, I + 1>(f);
+    }
+}
+
 template <int NT, bool LOGITS, bool PAD>
 __global__ __launch_bounds__(512) void k_compat_softmax(const float *__restrict__ E0, int64_t e_rs,
                                                         const float *__restrict__ X, int64_t x_rs,
@@ -250,7 +236,12 @@ __global__ __launch_bounds__(512) void k_compat_softmax(const float *__restrict_
     // as +inf (so exp gives 0 and the row minimum ignores them), X reads as 0, nothing is stored.
     typedef float f32x16 __attribute__((ext_vector_type(16)));
     constexpr int L = 32 * NT;
-    extern __shared__ __attribute__((aligned(16))) float lds[];   // 2 x [L labels][32 k], 16-byte slots XOR-swizzled
+    constexpr int MU_FLOATS = L * 32;             // one chunk of Mu^T: [L labels][32 k]
+    constexpr int X_FLOATS = 4 * 1024;            // one chunk of the tile's X: 4 waves x [32 pixels][32 k]
+    // LDS: Mu ring [3][MU_FLOATS], then X ring [3][X_FLOATS]; slot s reads buffers s % 3, and both are requested TWO
+    // slots ahead (a request then has a whole slot beyond its own to land: with one slot the DMA's issue + latency
+    // was the critical path of every slot); rows of 128 B, 16-byte slots XOR-swizzled
+    extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int grp = wave >> 2, w4 = wave & 3;     // wave group (0/1) and wave within it
@@ -258,72 +249,105 @@ __global__ __launch_bounds__(512) void k_compat_softmax(const float *__restrict_
     const int64_t ntiles = n / 128;               // WHOLE tiles only: the launcher hands the last n % 128 pixels to k_compat_tail
     const int64_t G2 = 2 * (int64_t)gridDim.x;
 
-    // RULE OF THIS KERNEL: no vector-ALU instruction inside the MFMA stream.  On gfx950 a VALU instruction between two
-    // v_mfma_f32_32x32x2_f32 does not overlap with them (tools/mfma_probe.hip: 16 register copies per 128 MFMAs cost
-    // 3 cycles per MFMA), so every address below is "scalar base + per-lane offset fixed for the whole kernel +
-    // immediate": the scalar unit does the arithmetic.
+    // RULES OF THIS KERNEL (each one measured, tools/mfma_probe.hip and the in-kernel stamps of the debug build):
+    //  * the waves on the matrix cores issue NOTHING but MFMAs and LDS reads.  A VALU instruction between two
+    //    v_mfma_f32_32x32x2_f32 does not overlap with them on gfx950, and a vector-memory instruction takes 100-200
+    //    cycles to ISSUE (an LDS-DMA piece as much as a load): 8 + 4 of them per chunk kept the pipe idle for a
+    //    quarter of the time.  So both operands come through LDS, and the OTHER wave group -- the one in its epilogue
+    //    half, whose SIMD partner is busy with MFMAs anyway -- does all the fetching (loader duty).
+    //  * every address is "scalar base + per-lane offset fixed for the whole kernel + immediate": the scalar unit
+    //    does the arithmetic.
 
-    // Chunk loader (LDS-DMA, no staging registers): a chunk is L labels x 8 slots of 16 B; one wave-instruction
-    // fills 64 consecutive slots = 8 labels.  LDS stays linear (that is all the DMA can write); the bank
-    // swizzle lives in WHICH 16 bytes a lane fetches: slot s of label r holds k-part s ^ ((r >> 1) & 7), and the
-    // reads below apply the same XOR (the 16 lanes a ds_read_b128 serves at a time then hit 16 different
-    // 16-byte bank groups).  The per-lane part of the address only depends on the parity of the
-    // wave-instruction's index gi = w4*NT + r (label = 8 gi + lane/8, so (label >> 1) & 7 = (4 (gi & 1) + lane/16) & 7):
-    // two byte offsets serve all of them, picked once per wave (even r / odd r).
+    // Loader duty (LDS-DMA, no staging registers).  A Mu chunk is L labels x 8 slots of 16 B; one wave-instruction
+    // ("piece") fills 64 consecutive slots = 8 labels.  An X chunk is, per wave of the consuming group, 32 pixels x 8
+    // slots = 4 pieces.  LDS stays linear (that is all the DMA can write); the bank swizzle lives in WHICH 16 bytes a
+    // lane fetches: slot s of row r holds k-part s ^ ((r >> 1) & 7), and the reads apply the same XOR (the 16 lanes
+    // a ds_read_b128 serves at a time then hit 16 different 16-byte bank groups).  The per-lane part of the address
+    // only depends on the parity of the piece (row = 8 piece + lane/8, so (row >> 1) & 7 = (4 (piece & 1) + lane/16) & 7):
+    // two byte offsets per matrix serve every piece.
     const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float *)lds;
-    const unsigned voff0 = ((lane >> 3) * L + 4 * ((lane & 7) ^ (lane >> 4))) * 4;
-    const unsigned voff1 = ((lane >> 3) * L + 4 * ((lane & 7) ^ (4 + (lane >> 4)))) * 4;
-    const bool odd0 = (w4 * NT) & 1;
-    const unsigned voff_even = odd0 ? voff1 : voff0, voff_odd = odd0 ? voff0 : voff1;    // for even / odd r
-    auto load_mu_piece = [&](int kc, int buf, int r) {       // piece r of NT: 64 slots = 8 labels
-        const int gi = w4 * NT + r;              // wave-instruction index within the chunk (the group's four waves share it)
-        glds16(MuT + (int64_t)gi * 8 * L + 32 * kc, (r & 1) ? voff_odd : voff_even, lds_base + (buf * (L * 32) + gi * 256) * 4);
-    };
-    auto load_mu = [&](int kc, int buf) {        // issued by the four waves of ONE group
+    const int part0 = (lane & 7) ^ (lane >> 4), part1 = (lane & 7) ^ (4 + (lane >> 4));
+    const unsigned mvoff0 = ((lane >> 3) * L + 4 * part0) * 4, mvoff1 = ((lane >> 3) * L + 4 * part1) * 4;
+    const bool odd0 = (w4 * NT) & 1;              // piece index of Mu within the chunk: w4 * NT + r
+    const unsigned mvoff_even = odd0 ? mvoff1 : mvoff0, mvoff_odd = odd0 ? mvoff0 : mvoff1;    // for even / odd r
+    const unsigned xvoff0 = (unsigned)((lane >> 3) * x_rs + 4 * part0) * 4u, xvoff1 = (unsigned)((lane >> 3) * x_rs + 4 * part1) * 4u;
+    // feed(S), called in slot S by the group that is NOT on the matrix cores (four waves): Mu's chunk and the X chunk
+    // for slot S+2.  Who multiplies in a slot follows from its number alone: half ph = slot / NT belongs
+    // to group ph & 1, which is then on its (ph >> 1)-th tile (group 1 started one half late), chunk slot % NT.
+    // Returns the number of X pieces issued (0 if that group has run out of tiles) for the counted wait.
+    const int64_t b2 = 2 * (int64_t)blockIdx.x;
+    auto feed = [&](int S, int s3) -> bool {     // s3 = S mod 3 (S >= -2)
+        const int ph = (S + 2) / NT, kc = (S + 2) - ph * NT, xb = s3 == 0 ? 2 : s3 - 1;     // (S + 2) % 3
 #pragma unroll
-        for (int r = 0; r < NT; r++) load_mu_piece(kc, buf, r);
+        for (int r = 0; r < NT; r++) {
+            const int gi = w4 * NT + r;
+            glds16(MuT + (int64_t)gi * 8 * L + 32 * kc, (r & 1) ? mvoff_odd : mvoff_even, lds_base + (xb * MU_FLOATS + gi * 256) * 4);
+        }
+        const int64_t tile = (ph & 1) ? b2 + 1 + (int64_t)((ph - 1) >> 1) * G2 : b2 + (int64_t)(ph >> 1) * G2;
+        const bool ok = tile < ntiles;
+        if (ok) {
+            const float *xw = X + (tile * 128 + w4 * 32) * x_rs;          // the consuming wave's 32 rows (same w4)
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                unsigned vo = (j & 1) ? xvoff1 : xvoff0;
+                if (PAD && kc == NT - 1)         // padded columns: clamp into the row (pad_x() zeroes them when consumed)
+                    vo = (unsigned)((lane >> 3) * x_rs + min(4 * ((j & 1) ? part1 : part0), Lr - 4 - 32 * kc)) * 4u;
+                glds16(xw + (int64_t)8 * j * x_rs + 32 * kc, vo, lds_base + (3 * MU_FLOATS + xb * X_FLOATS + w4 * 1024 + j * 256) * 4);
+            }
+        }
+        asm volatile("" ::: "memory");           // the row traffic below stays behind the DMAs (counted wait)
+        return ok;
     };
-    // B-operand reads: lane (i, h) takes k-part 2q + h of label 32t + i -> slot ((2q + h) ^ sw) of LDS row 32t + i
+    // wait until all but this slot's own requests -- NT + 4 xp DMA pieces and `rows` accesses behind them, the wave's
+    // youngest vector-memory operations -- are done (immediates only)
+#define PHL_WAIT_BUT(xp, rows)                                                                                            \
+    do {                                                                                                                  \
+        if (xp) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((rows) + NT + 4 < 63 ? (rows) + NT + 4 : 63) : "memory");        \
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((rows) + NT < 63 ? (rows) + NT : 63) : "memory");                   \
+    } while (0)
+    // operand reads: lane (i, h) takes k-part 2q + h of row i (a pixel of X, or label 32t + i of Mu^T) -> slot
+    // ((2q + h) ^ sw) of that row
     const int sw = (i >> 1) & 7;
-    const float *brow[4];
+    const float *brow[4], *arow[4];
 #pragma unroll
-    for (int q = 0; q < 4; q++) brow[q] = lds + i * 32 + ((2 * q + h) ^ sw) * 4;
+    for (int q = 0; q < 4; q++) {
+        brow[q] = lds + i * 32 + ((2 * q + h) ^ sw) * 4;
+        arow[q] = brow[q] + 3 * MU_FLOATS + w4 * 1024;
+    }
 
-    // E0 / out / X addressing: a register r of the C/D map is pixel row rr(r) + 4h of the wave's 32, label
-    // 32t + lane&31; the A operand of lane (i, h) is X[row i][8q + 4h ..].  Wave-uniform row pointer (scalar
-    // registers) + one per-lane byte offset for the whole kernel + an immediate.  Every tile is whole, so there is
-    // no row masking or clamping anywhere (a lane-dependent branch around a load would also make the compiler treat
-    // the whole 16-register accumulator as that load's destination and wait for it at every later touch).
+    // The product is computed TRANSPOSED (D^T = Mu^T X^T: labels are the MFMA's rows, pixels its columns), so that the
+    // C/D map puts FOUR CONSECUTIVE LABELS of one pixel into four consecutive registers: lane (i, h) holds pixel i of
+    // the wave's 32, register r of tile t is label 32t + 8(r>>2) + 4h + (r&3).  E0 comes in and Q goes out as
+    // 16-byte accesses -- a quarter of the vector-memory instructions of a dword-per-lane layout, which matters
+    // because a wave can have only 63 of them in flight (at ~5 us loaded latency that cap, not bandwidth, set the pace
+    // of the epilogue half) -- and a pixel's row lives in just two lanes (l, l ^ 32): the softmax reductions are
+    // in-lane plus one exchange.
+    // E0 / out addressing: wave-uniform tile pointer (scalar registers) + one per-lane byte offset for the whole
+    // kernel + an immediate.  Every tile is whole: no row masking or clamping anywhere.
     // Padding is applied where a value is CONSUMED, not where it is loaded (a select on a fresh load would make the
     // wave wait for it): loads of padded columns are clamped into the row, pad_e0() / pad_x() overwrite them later.
     const int h4 = 4 * h;
-    const unsigned lo_e = (unsigned)(h4 * e_rs + i) * 4u, lo_o = (unsigned)(h4 * o_rs + i) * 4u;
-    const unsigned lo_e_last = PAD ? (unsigned)(h4 * e_rs + min(32 * (NT - 1) + i, Lr - 1) - 32 * (NT - 1)) * 4u : lo_e;
-    const unsigned lo_x = (unsigned)(i * x_rs + h4) * 4u;
-    const bool lane_stores_last = !PAD || 32 * (NT - 1) + i < Lr;
-    auto rr = [](int r) { return (r & 3) + 8 * (r >> 2); };
-#define PHL_E0_LOAD_ROW(r, wave_rows)  /* wave_rows: E0 row of the wave's first pixel */                                    \
+    const unsigned lo_e = (unsigned)(i * e_rs + h4) * 4u, lo_o = (unsigned)(i * o_rs + h4) * 4u;
+    // unit (t, g): labels 32t + 8g + 4h .. +3 of this lane's pixel = registers 4g .. 4g+3 of accumulator t
+#define PHL_E0_LOAD_UNIT(t, g, wave_rows)  /* wave_rows: E0 row of the wave's first pixel */                               \
     do {                                                                                                                  \
-        const char *p_ = reinterpret_cast<const char *>((wave_rows) + rr(r) * e_rs);                                      \
-        _Pragma("unroll") for (int t = 0; t < NT; t++)                                                                    \
-            acc[t][r] = *reinterpret_cast<const float *>(p_ + 128 * t + ((PAD && t == NT - 1) ? lo_e_last : lo_e));       \
+        const char *p_ = reinterpret_cast<const char *>((wave_rows) + 32 * (t) + 8 * (g));                                \
+        unsigned lo_ = lo_e;                                                                                              \
+        if (PAD && (t) == NT - 1) {              /* clamp padded columns into the row (Lr >= 32 t + 4: never negative) */ \
+            p_ = reinterpret_cast<const char *>((wave_rows) + 32 * (t));                                                  \
+            lo_ = (unsigned)(i * e_rs + min(8 * (g) + h4, Lr - 4 - 32 * (t))) * 4u;                                       \
+        }                                                                                                                 \
+        const float4 v_ = *reinterpret_cast<const float4 *>(p_ + lo_);                                                    \
+        acc[t][4 * (g)] = v_.x; acc[t][4 * (g) + 1] = v_.y; acc[t][4 * (g) + 2] = v_.z; acc[t][4 * (g) + 3] = v_.w;       \
     } while (0)
-    // A fragment q of chunk kc: columns 32 kc + 8q + 4h .. +3 of this lane's X row
-    auto x_load_q = [&](float4 &a, const float *wave_rows, int kc, int q) {
-        if (PAD && kc == NT - 1)                 // padded columns: clamp into the row (per-lane offsets, last chunk only)
-            a = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(wave_rows) +
-                                                  (unsigned)(i * x_rs + min(32 * kc + 8 * q + h4, Lr - 4)) * 4u);
-        else
-            a = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(wave_rows + 32 * kc) + 32 * q + lo_x);
-    };
-    auto x_load = [&](float4 (&a)[4], const float *wave_rows, int kc) {
-#pragma unroll
-        for (int q = 0; q < 4; q++) x_load_q(a[q], wave_rows, kc, q);
-    };
     auto pad_e0 = [&](f32x16 &last) {                 // only the last label tile holds padding (L - Lr < 32)
-        if (PAD && 32 * (NT - 1) + i >= Lr) {
+        if (PAD) {
 #pragma unroll
-            for (int r = 0; r < 16; r++) last[r] = INFINITY;
+            for (int g = 0; g < 4; g++)
+                if (32 * (NT - 1) + 8 * g + h4 >= Lr) {
+#pragma unroll
+                    for (int j = 0; j < 4; j++) last[4 * g + j] = INFINITY;
+                }
         }
     };
     auto pad_x = [&](float4 &v, int k0) {
@@ -331,46 +355,103 @@ __global__ __launch_bounds__(512) void k_compat_softmax(const float *__restrict_
     };
 
     // Tiles of this group: 2 (b + k gridDim) + grp, k = 0, 1, ...  Every wave alternates the MFMA half of a tile (NT
-    // slots, one per K chunk) with its epilogue half (NT slots as well); a slot ends in the workgroup barrier, and
-    // group 1 starts one half late (NT bare barriers), group 0 ends with them: whenever one group is on the matrix
-    // cores, the other one -- its SIMD partner -- is storing Q and fetching E0.  Both groups run the same number of
-    // iterations (group 0 never has fewer tiles); a group without a tile left still keeps the LDS ring fed.
+    // slots, one per K chunk) with its epilogue half (NT slots as well); a slot ends in the workgroup barrier.  Group 1
+    // starts one half late (it spends that half feeding group 0), group 0 ends with NT bare barriers: whenever one
+    // group is on the matrix cores, the other one -- its SIMD partner -- is storing Q, fetching E0 and feeding it.
+    // Both groups run the same number of iterations (group 0 never has fewer tiles).
     const int64_t iters = (ntiles - 2 * (int64_t)blockIdx.x + G2 - 1) / G2;          // tiles 2b, 2b + G2, ... < ntiles
     int64_t tile = 2 * (int64_t)blockIdx.x + grp;
     bool valid = tile < ntiles;                  // wave-uniform
     f32x16 acc[NT];
-    float4 a[2][4];                              // A fragments: chunk kc lives in a[kc & 1] (no copies between chunks)
     if (valid) {
 #pragma unroll
-        for (int r = 0; r < 16; r++) PHL_E0_LOAD_ROW(r, E0 + (tile * 128 + w4 * 32) * e_rs);
-        x_load(a[0], X + (tile * 128 + w4 * 32) * x_rs, 0);
+        for (int t = 0; t < NT; t++)
+#pragma unroll
+            for (int g = 0; g < 4; g++) PHL_E0_LOAD_UNIT(t, g, E0 + (tile * 128 + w4 * 32) * e_rs);
     }
-    int slot = 0;                                // chunks since the start: chunk `slot` sits in LDS buffer slot & 1
-    if (grp == 0) {
-        load_mu(0, 0);
-        dma_drain();
-    }
-    __builtin_amdgcn_s_barrier();
+#ifdef __HIP_DEVICE_COMPILE__                    /* the first tile's E0 has landed before the loop is entered: with that known on
+                                                    every path into it, the loop body needs no compiler-made vmcnt wait */
+    asm volatile("" ::"v"(acc[NT - 1]));
+#endif
+    int slot = 0, slot3 = 0;                     // slots since the start, and that number mod 3
+    auto next_slot = [&]() { slot++; slot3 = slot3 == 2 ? 0 : slot3 + 1; };
     if (grp == 1) {
-        for (int s = 0; s < NT; s++, slot++) __builtin_amdgcn_s_barrier();
+        // group 0's first MFMA half is fed by group 1, which has nothing else to do yet: first what slots 0 and 1
+        // need (feed(-1) and feed(-2) in the numbering above), then slot by slot
+        feed(-2, 1);
+        feed(-1, 2);
+        dma_drain();
+        __builtin_amdgcn_s_barrier();
+        for (int s = 0; s < NT; s++) {
+            const bool xp = feed(slot, slot3);
+            PHL_WAIT_BUT(xp, 0);
+            __builtin_amdgcn_s_barrier();
+            next_slot();
+        }
+    } else {
+        __builtin_amdgcn_s_barrier();
     }
 
-    // One K chunk of the MFMA half.  PAR = kc & 1 picks the A registers; for even NT it is also the LDS buffer (a
-    // half is NT slots, so `slot` is even whenever a half starts) and every LDS offset is an immediate.
-    auto chunk = [&](auto par, int kc, const float *xrows) {
-        constexpr int PAR = decltype(par)::value;
-        const int buf = (NT % 2 == 0) ? PAR : (slot & 1);
-        // The prefetch for the NEXT slot -- Mu's chunk (of this tile, or chunk 0 for the other group's tile; its buffer
-        // was last read in the previous slot, behind the barrier) and this tile's next A fragments -- is issued in
-        // pieces BETWEEN the MFMA steps: an LDS-DMA instruction takes 100-200 cycles to issue, and the 8 of them + 4
-        // loads in one block ahead of the MFMAs kept the matrix pipe idle for a quarter of the chunk (in-kernel
-        // stamps: 2.7k of 10.9k cycles).
-        const int kc_next = kc + 1 < NT ? kc + 1 : 0;
-        CS_ARRIVE(kc * 4 + 0);
-        if (valid) {
-            if (PAD && kc == NT - 1) {
+    // The softmax arithmetic, run by a wave at the END of its MFMA half (inside the last slot, before the barrier):
+    // next to the other group's MFMA stream a wave gets a VALU issue slot about once per MFMA -- the ~400 instructions
+    // below took 17k cycles there, and the slot waited for them; here they take their own 3-4k, with the matrix pipe
+    // idle and the other group in the one slot of its epilogue half that has nothing else to do.
+    auto softmax_in_place = [&]() {
+    if (valid && !LOGITS) {
+        // softmax(-E) of this lane's pixel: 4 NT registers here, the other half of the row in lane ^ 32.
+        // Shift by the row MINIMUM of E; exp(-(E - min)) = exp2(min log2e - E log2e)
+        float m = acc[0][0];
 #pragma unroll
-                for (int q = 0; q < 4; q++) pad_x(a[PAR][q], 32 * kc + 8 * q);
+        for (int t = 0; t < NT; t++)
+#pragma unroll
+            for (int r = (t == 0 ? 1 : 0); r + 1 < 16; r += 2) m = vmin3(m, acc[t][r], acc[t][r + 1]);
+#pragma unroll
+        for (int t = 1; t < NT; t++) m = vmin3(m, acc[t][15], acc[t][15]);        // (r = 15 of t = 0 is in the pairs above)
+        {
+            float ma = m, mb = m;
+            PHL_HALF_SWAP(ma, mb);
+            m = vmin3(ma, mb, mb) * 1.4426950408889634f;
+        }
+        // whole-accumulator vector arithmetic: packed f32 instructions on aligned register pairs
+        f32x16 vs = 0.f;
+#pragma unroll
+        for (int t = 0; t < NT; t++) {
+            acc[t] = __builtin_elementwise_fma(acc[t], (f32x16)(-1.4426950408889634f), (f32x16)m);
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[t][r] = __builtin_amdgcn_exp2f(acc[t][r]);
+            vs += acc[t];
+        }
+        typedef float f32x8 __attribute__((ext_vector_type(8)));
+        typedef float f32x4 __attribute__((ext_vector_type(4)));
+        const f32x8 v8 = __builtin_shufflevector(vs, vs, 0, 1, 2, 3, 4, 5, 6, 7) + __builtin_shufflevector(vs, vs, 8, 9, 10, 11, 12, 13, 14, 15);
+        const f32x4 v4 = __builtin_shufflevector(v8, v8, 0, 1, 2, 3) + __builtin_shufflevector(v8, v8, 4, 5, 6, 7);
+        float sum = (v4[0] + v4[1]) + (v4[2] + v4[3]);
+        {
+            float sa = sum, sb = sum;
+            PHL_HALF_SWAP(sa, sb);
+            sum = sa + sb;
+        }
+        // Q = exp / sum, in place and BEFORE the first E0 load of the next tile is issued: a write to one
+        // register of a 16-register accumulator while a load into another one is in flight makes the
+        // compiler wait for that load (it tracks the accumulator as one unit)
+        const float inv = __builtin_amdgcn_rcpf(sum);
+#pragma unroll
+        for (int t = 0; t < NT; t++) acc[t] *= inv;
+    } else if (valid) {                  // CRFasRNN returns -E of the last iteration, not Q (crf_module.py:103)
+#pragma unroll
+        for (int t = 0; t < NT; t++) acc[t] = -acc[t];
+    }
+    };
+
+    // One K chunk of the MFMA half: operands from LDS only (ring position slot3)
+    auto chunk = [&](int kc) {
+        if (valid) {
+            float4 a[4];
+            const float *bb[4];                  // (the ring position is the only vector arithmetic of the chunk)
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                a[q] = *reinterpret_cast<const float4 *>(arow[q] + slot3 * X_FLOATS);
+                bb[q] = brow[q] + slot3 * MU_FLOATS;
             }
             // B operands in half-groups of NT/2 label tiles, software-pipelined by hand: the LDS reads of step s+1 are
             // issued BEFORE the MFMAs of step s (only one wave per SIMD is on the matrix cores at a time, so an LDS round
@@ -381,64 +462,57 @@ __global__ __launch_bounds__(512) void k_compat_softmax(const float *__restrict_
                 const int q = NT > 1 ? st >> 1 : st, t0 = NT > 1 ? (st & 1) * HT : 0;
 #pragma unroll
                 for (int t = 0; t < HT; t++)
-                    if (t0 + t < NT) dst[t] = *reinterpret_cast<const float4 *>(brow[q] + buf * (L * 32) + (t0 + t) * 32 * 32);
+                    if (t0 + t < NT) dst[t] = *reinterpret_cast<const float4 *>(bb[q] + (t0 + t) * 32 * 32);
             };
             read_b(0, b[0]);
+            if (PAD && kc == NT - 1) {
+#pragma unroll
+                for (int q = 0; q < 4; q++) pad_x(a[q], 32 * kc + 8 * q);
+            }
 #pragma unroll
             for (int st = 0; st < STEPS; st++) {
                 const int q = NT > 1 ? st >> 1 : st, t0 = NT > 1 ? (st & 1) * HT : 0;
                 if (st + 1 < STEPS) read_b(st + 1, b[(st + 1) & 1]);
-#pragma unroll
-                for (int r = 0; r < NT; r++)
-                    if (r * STEPS / NT == st) load_mu_piece(kc_next, buf ^ 1, r);
-                if (kc + 1 < NT) {
-                    if (STEPS == 8 && (st & 1)) x_load_q(a[PAR ^ 1][st >> 1], xrows, kc + 1, st >> 1);
-                    if (STEPS == 4) x_load_q(a[PAR ^ 1][st], xrows, kc + 1, st);
-                }
                 __builtin_amdgcn_sched_barrier(0);
                 float4(&bc)[HT] = b[st & 1];
-                const float4 av = a[PAR][q];
+                const float4 av = a[q];
 #pragma unroll
-                for (int t = 0; t < HT; t++) if (t0 + t < NT) acc[t0 + t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bc[t].x, acc[t0 + t], 0, 0, 0);
+                for (int t = 0; t < HT; t++) if (t0 + t < NT) acc[t0 + t] = __builtin_amdgcn_mfma_f32_32x32x2f32(bc[t].x, av.x, acc[t0 + t], 0, 0, 0);
 #pragma unroll
-                for (int t = 0; t < HT; t++) if (t0 + t < NT) acc[t0 + t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bc[t].y, acc[t0 + t], 0, 0, 0);
+                for (int t = 0; t < HT; t++) if (t0 + t < NT) acc[t0 + t] = __builtin_amdgcn_mfma_f32_32x32x2f32(bc[t].y, av.y, acc[t0 + t], 0, 0, 0);
 #pragma unroll
-                for (int t = 0; t < HT; t++) if (t0 + t < NT) acc[t0 + t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bc[t].z, acc[t0 + t], 0, 0, 0);
+                for (int t = 0; t < HT; t++) if (t0 + t < NT) acc[t0 + t] = __builtin_amdgcn_mfma_f32_32x32x2f32(bc[t].z, av.z, acc[t0 + t], 0, 0, 0);
 #pragma unroll
-                for (int t = 0; t < HT; t++) if (t0 + t < NT) acc[t0 + t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bc[t].w, acc[t0 + t], 0, 0, 0);
+                for (int t = 0; t < HT; t++) if (t0 + t < NT) acc[t0 + t] = __builtin_amdgcn_mfma_f32_32x32x2f32(bc[t].w, av.w, acc[t0 + t], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
-        } else {
-            load_mu(kc_next, buf ^ 1);           // (a group out of tiles only keeps the LDS ring fed)
         }
-        CS_ARRIVE(kc * 4 + 2);
-        dma_drain();                             // the next chunk's DMA
-        CS_ARRIVE(kc * 4 + 3);
+        if (kc == NT - 1) softmax_in_place();
+        CS_ARRIVE(kc);
+        asm volatile("" ::: "memory");           // LDS reads of this slot stay on this side of the barrier
         __builtin_amdgcn_s_barrier();
-        slot++;
+        next_slot();
     };
 
     for (int64_t it = 0; it < iters; it++) {
         CS_STAMP(2 * it);
-        // =========== MFMA half: E = E0 + X @ Mu on `tile`; the group in this half feeds the LDS ring ===========
+        // =========== MFMA half: E = E0 + X @ Mu on `tile` =======================================================
         {
-            const float *xrows = X + ((valid ? tile : 0) * 128 + w4 * 32) * x_rs;
-            // every E0 load has landed by now (they were issued at least a slot ago); saying so HERE, with a use of
-            // the accumulator that was loaded last, keeps the compiler from guarding single registers later
-#ifdef __HIP_DEVICE_COMPILE__                    /* (the host pass has no "v" registers) */
+#ifdef __HIP_DEVICE_COMPILE__                    /* (see the last epilogue slot: no wait is generated here, but without this
+                                                    use the compiler guards single accumulator registers in the epilogue) */
             asm volatile("" ::"v"(acc[NT - 1]));
 #endif
             pad_e0(acc[NT - 1]);
-            for (int kc = 0; kc < NT; kc += 2) {
-                chunk(std::integral_constant<int, 0>(), kc, xrows);
-                if (kc + 1 < NT) chunk(std::integral_constant<int, 1>(), kc + 1, xrows);
-            }
+            for (int kc = 0; kc < NT; kc++) chunk(kc);
         }
         CS_STAMP(2 * it + 1);
-        // =========== epilogue half: softmax and store of `tile`, E0 / X of the group's next tile in ===============
-        // One piece per slot of the other group's MFMA half: the 16 pixel rows a lane holds go out over the first
-        // NT-1 slots, the last slot only lets the loads land.  Nothing here waits on memory: a stored row's registers
-        // take the next tile's E0 at once (the MFMA's C input, so E = E0 + X @ Mu comes out of the matrix pipe).
+        // =========== epilogue half: softmax and store of `tile`, E0 of the group's next tile in, loader duty =======
+        // One piece per slot of the other group's MFMA half.  Slot s first feeds slot s+1 of whoever is on the matrix
+        // cores then (the other group's chunk s+1; after the last slot this group itself, chunk 0 of its next tile),
+        // then moves its share of the 16 pixel rows a lane holds: a stored row's registers take the next tile's E0 at
+        // once (the MFMA's C input, so E = E0 + X @ Mu comes out of the matrix pipe).  Before the barrier it waits for
+        // the DMAs only (a counted wait: the row traffic issued after them stays in flight); the last slot moves no
+        // rows and drains everything.
         // C/D map: column = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5): for one register the 32 lanes of a
         // half-wave hold 32 consecutive labels of one pixel (128 B per access).
         {
@@ -446,71 +520,43 @@ __global__ __launch_bounds__(512) void k_compat_softmax(const float *__restrict_
             const bool has_next = nxt < ntiles;  // uniform
             float *orows = out + (tile * 128 + w4 * 32) * o_rs;                        // wave-uniform
             const float *erows = E0 + ((has_next ? nxt : tile) * 128 + w4 * 32) * e_rs;
-            float scale[16];
-#ifdef PHL_CS_NO_EPILOGUE            /* timing experiment: the MFMA halves alone */
-            if (false) {
-#else
-            if (valid && !LOGITS) {
+            static_for<NT>([&](auto sc) {
+                constexpr int s = decltype(sc)::value;
+                if (s == NT - 1) {
+                    // the units of this half are out and the next tile's E0 was requested at least a slot ago: the
+                    // compiler waits for it HERE (a use of the accumulator loaded last), before this slot's DMAs
+                    // are in flight, instead of draining them at the first MFMA
+#ifdef __HIP_DEVICE_COMPILE__                    /* (the host pass has no "v" registers) */
+                    asm volatile("" ::"v"(acc[NT - 1]));
 #endif
-                float m[16];
-#pragma unroll
-                for (int r = 0; r < 16; r++) {   // softmax(-E): shift by the row MINIMUM of E
-                    m[r] = acc[0][r];
-#pragma unroll
-                    for (int t = 1; t + 1 < NT; t += 2) m[r] = vmin3(m[r], acc[t][r], acc[t + 1][r]);
-                    if (NT % 2 == 0) m[r] = vmin3(m[r], acc[NT - 1][r], acc[NT - 1][r]);
                 }
-                // the 16 rows are reduced TOGETHER: sixteen independent chains per step
-                half_wave_min16(m);
+                // not at once: right behind the barrier the other group issues the LDS reads its first MFMAs wait for,
+                // and a burst of DMA pieces ahead of them in the queue cost it 0.8 us per slot (measured)
+                __builtin_amdgcn_s_sleep(4);
+                const bool xp = feed(slot, slot3);
+                // this slot's share of the 4 NT units: store Q, and the freed registers take the next tile's E0 at
+                // once (the MFMA's C input, so E = E0 + X @ Mu comes out of the matrix pipe)
+                constexpr int U = 4 * NT, D = NT > 1 ? NT - 1 : 1;
+                constexpr int u_lo = s < D ? (U * s + D - 1) / D : U, u_hi = s + 1 < D ? (U * (s + 1) + D - 1) / D : U;
 #pragma unroll
-                for (int r = 0; r < 16; r++) m[r] *= 1.4426950408889634f;
-#pragma unroll
-                for (int r = 0; r < 16; r++) {
-                    float s0 = 0.f, s1 = 0.f;
-#pragma unroll
-                    for (int t = 0; t < NT; t++) {   // exp(-(E - min)) = exp2(min log2e - E log2e)
-                        acc[t][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(acc[t][r], -1.4426950408889634f, m[r]));
-                        if (t & 1) s1 += acc[t][r]; else s0 += acc[t][r];
-                    }
-                    scale[r] = s0 + s1;
+                for (int u = 0; u < U; u++) {    // (constant trip count: unrolls, and the test folds)
+                    if (u < u_lo || u >= u_hi) continue;
+                    const int t = u >> 2, g = u & 3;
+                    if (valid && (!PAD || t < NT - 1 || 32 * t + 8 * g + h4 < Lr))
+                        *reinterpret_cast<float4 *>(reinterpret_cast<char *>(orows + 32 * t + 8 * g) + lo_o) =
+                            make_float4(acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3]);
+                    if (has_next) PHL_E0_LOAD_UNIT(t, g, erows);
                 }
-                half_wave_sum16(scale);
-                // Q = exp / sum, in place and BEFORE the first E0 load of the next tile is issued: a write to one
-                // register of a 16-register accumulator while a load into another one is in flight makes the
-                // compiler wait for that load (it tracks the accumulator as one unit)
-#pragma unroll
-                for (int r = 0; r < 16; r++) {
-                    scale[r] = __builtin_amdgcn_rcpf(scale[r]);
-#pragma unroll
-                    for (int t = 0; t < NT; t++) acc[t][r] *= scale[r];
-                }
-            } else if (valid) {                  // CRFasRNN returns -E of the last iteration, not Q (crf_module.py:103)
-#pragma unroll
-                for (int t = 0; t < NT; t++) acc[t] = -acc[t];
-            }
-#pragma unroll
-            for (int s = 0; s < NT; s++) {
-                constexpr int D = NT > 1 ? NT - 1 : 1;
-                const int r_lo = s < D ? (16 * s + D - 1) / D : 16, r_hi = s + 1 < D ? (16 * (s + 1) + D - 1) / D : 16;
-#pragma unroll
-                for (int r = 0; r < 16; r++) {   // (constant trip counts: both loops unroll and the test folds)
-                    if (r < r_lo || r >= r_hi) continue;
-#ifdef PHL_CS_NO_EPILOGUE
-                    if (n != -12345) continue;     /* (never true: keeps the accumulators alive) */
-#endif
-                    if (valid) {
-                        char *p = reinterpret_cast<char *>(orows + rr(r) * o_rs);
-#pragma unroll
-                        for (int t = 0; t < NT; t++)
-                            if (!PAD || t < NT - 1 || lane_stores_last) *reinterpret_cast<float *>(p + 128 * t + lo_o) = acc[t][r];
-                    }
-                    // this row's registers are free: the next tile's E0 goes in
-                    if (has_next) PHL_E0_LOAD_ROW(r, erows);
-                }
-                if (s == NT - 1 && has_next) x_load(a[0], X + (nxt * 128 + w4 * 32) * x_rs, 0);
+                // Mu for the next slot and the X requested a slot ago must have landed; this slot's X pieces and the
+                // units issued after them need not (vmcnt counts in issue order)
+                constexpr int UNITS = (NT > 1 && s == NT - 1) ? 0 : (u_hi > u_lo ? u_hi - u_lo : 0);
+                if (valid && has_next) PHL_WAIT_BUT(xp, 2 * UNITS);
+                else if (valid || has_next) PHL_WAIT_BUT(xp, UNITS);
+                else PHL_WAIT_BUT(xp, 0);
+                CS_ARRIVE(NT + s);
                 __builtin_amdgcn_s_barrier();
-                slot++;
-            }
+                next_slot();
+            });
             tile = nxt;
             valid = has_next;
         }
@@ -519,6 +565,8 @@ __global__ __launch_bounds__(512) void k_compat_softmax(const float *__restrict_
         for (int s = 0; s < NT; s++) __builtin_amdgcn_s_barrier();
     }
 }
+#undef PHL_E0_LOAD_UNIT
+#undef PHL_WAIT_BUT
 
 // The last n % 128 pixels of phl_compat_softmax (the tile kernel takes whole tiles only): one workgroup per pixel,
 // thread c owns label c -- an fmaf chain over k straight from the transposed compatibility matrix, then the row
@@ -561,7 +609,6 @@ __global__ __launch_bounds__(256) void k_compat_tail(const float *__restrict__ E
     if (c < L) out[p * o_rs + c] = v * __builtin_amdgcn_rcpf(red[0]);
 }
 
-#undef PHL_E0_LOAD_ROW
 inline unsigned rows_grid(int64_t n)
 {
     int64_t b = (n + 3) / 4;
@@ -607,7 +654,7 @@ int phl_compat_softmax(const float *E0, int64_t e_rs, const float *X, int64_t x_
     // the last n % 128 pixels go to k_compat_tail
     const int64_t n_main = n / 128 * 128, npairs = (n / 128 + 1) / 2;
     const unsigned grid = (unsigned)(npairs < 256 ? npairs : 256);
-    const size_t lds = (size_t)2 * Lp * 32 * sizeof(float);
+    const size_t lds = ((size_t)3 * Lp * 32 + 3 * 4 * 1024) * sizeof(float);     // Mu ring + X ring: 144 KiB at L = 256
     const bool logits = (flags & PHL_COMPAT_LOGITS) != 0;     // LDS is 2*L*128 B <= 64 KiB: no attribute needed
 #ifdef PHL_COMPAT_TIMELINE
     static unsigned long long *tl_buf = nullptr;
@@ -624,12 +671,19 @@ int phl_compat_softmax(const float *E0, int64_t e_rs, const float *X, int64_t x_
         hipMemset(tl_buf, 0, 512 * 64 * 8);
     }
 #endif
+#define PHL_CS_LAUNCH(NT_, LG_, PD_)                                                                                    \
+    do {                                                                                                                  \
+        if (lds > 64 * 1024)                                                                                              \
+            PHL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_compat_softmax<NT_, LG_, PD_>),                 \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                           \
+        k_compat_softmax<NT_, LG_, PD_><<<dim3(grid), dim3(512), lds, st>>>(E0, e_rs, X, x_rs, MuT, out, o_rs, n, L);     \
+    } while (0)
 #define PHL_CS(NT_)                                                                                                       \
     case NT_:                                                                                                             \
-        if (logits && pad) k_compat_softmax<NT_, true, true><<<dim3(grid), dim3(512), lds, st>>>(E0, e_rs, X, x_rs, MuT, out, o_rs, n, L);        \
-        else if (logits) k_compat_softmax<NT_, true, false><<<dim3(grid), dim3(512), lds, st>>>(E0, e_rs, X, x_rs, MuT, out, o_rs, n, L);         \
-        else if (pad) k_compat_softmax<NT_, false, true><<<dim3(grid), dim3(512), lds, st>>>(E0, e_rs, X, x_rs, MuT, out, o_rs, n, L);            \
-        else k_compat_softmax<NT_, false, false><<<dim3(grid), dim3(512), lds, st>>>(E0, e_rs, X, x_rs, MuT, out, o_rs, n, L);                    \
+        if (logits && pad) PHL_CS_LAUNCH(NT_, true, true);                                                                \
+        else if (logits) PHL_CS_LAUNCH(NT_, true, false);                                                                 \
+        else if (pad) PHL_CS_LAUNCH(NT_, false, true);                                                                    \
+        else PHL_CS_LAUNCH(NT_, false, false);                                                                            \
         break;
     if (n_main > 0) {
         switch (Lp / 32) {
@@ -641,6 +695,7 @@ int phl_compat_softmax(const float *E0, int64_t e_rs, const float *X, int64_t x_
         else k_compat_tail<false><<<dim3((unsigned)(n - n_main)), dim3(256), 0, st>>>(E0, e_rs, X, x_rs, MuT, Lp, out, o_rs, n_main, L);
     }
 #undef PHL_CS
+#undef PHL_CS_LAUNCH
     PHL_HIP(hipGetLastError());
     return PHL_OK;
 }

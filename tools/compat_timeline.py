@@ -22,7 +22,7 @@ a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True
 a.record(); phl.compat_softmax(E0, X, Mu, out=out); b.record(); torch.cuda.synchronize()
 print("PHL_CS_EXP", os.environ.get("PHL_CS_EXP"), "kernel ms", a.elapsed_time(b))
 t = np.fromfile(path, dtype=np.uint64)[:256 * 2 * 64].reshape(256, 2, 64).astype(np.int64)
-fine = t[:, :, 16:48].reshape(256, 2, 8, 4)          # shader-clock stamps of the third tile's 8 chunks: entry, prefetch issued, MFMAs done, drained
+arr = t[:, :, 16:32]                                  # shader-clock arrival at each slot's barrier in the third iteration: 8 MFMA slots, 8 epilogue slots
 t = t[:, :, :16]
 t0 = t[t > 0].min()
 us = (t - t0) / 100.0                                 # [workgroup, group, stamp]: stamp 2k = MFMA half of the k-th tile, 2k+1 = its epilogue half
@@ -30,10 +30,7 @@ mf = us[:, :, 1::2] - us[:, :, 0::2]
 ep = us[:, :, 2::2] - us[:, :, 1:-1:2]
 for k in range(7):
     print(f"tile {k}: MFMA half {mf[:, :, k].mean():6.1f} us (min {mf[:, :, k].min():5.1f} max {mf[:, :, k].max():5.1f})   epilogue half {ep[:, :, k].mean():6.1f} (min {ep[:, :, k].min():5.1f} max {ep[:, :, k].max():5.1f})")
-d = np.diff(fine, axis=3).astype(np.float64)          # per chunk: issue, MFMA stream, drain (shader cycles)
-nxt = (fine[:, :, 1:, 0] - fine[:, :, :-1, 3]).astype(np.float64)   # drained -> next chunk's entry (the barrier)
-print("per chunk, shader cycles (mean over workgroups and groups):")
-print("  prefetch issue :", " ".join("%6.0f" % v for v in d[:, :, :, 0].mean(axis=(0, 1))))
-print("  MFMA stream    :", " ".join("%6.0f" % v for v in d[:, :, :, 1].mean(axis=(0, 1))), "  (128 MFMAs = 8192)")
-print("  drain          :", " ".join("%6.0f" % v for v in d[:, :, :, 2].mean(axis=(0, 1))))
-print("  barrier        :", " ".join("%6.0f" % v for v in nxt.mean(axis=(0, 1))))
+# group 0's epilogue slots (8..15) are group 1's MFMA slots (0..7) of the same iteration
+d = (arr[:, 1, 0:8] - arr[:, 0, 8:16]).astype(np.float64)
+print("arrival(MFMA wave) - arrival(epilogue wave), shader cycles per slot:", " ".join("%6.0f" % v for v in d.mean(axis=0)))
+print("slot length (MFMA wave arrival to arrival):", " ".join("%6.0f" % v for v in np.diff(arr[:, 1, 0:8].astype(np.float64), axis=1).mean(axis=0)))

@@ -1,34 +1,39 @@
-// scratch test of the half-wave all-reduce helpers (DPP rotations + v_permlane16_swap)
+// Semantics check of the lane-swap instructions the compat kernel's softmax uses (gfx950):
+//   v_permlane16_swap_b32 a, b : the odd 16-lane rows of a trade places with the even rows of b
+//   v_permlane32_swap_b32 a, b : the upper 32 lanes of a trade places with the lower 32 lanes of b
+// and of the compiler builtin, which returns its FIRST result twice (ROCm 7.2) -- hence inline assembly in the kernel.
+// build: hipcc --offload-arch=gfx950 -O3 tools/dpp_probe.hip -o tools/dpp_probe
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <math.h>
-#define PHL_DPP_ROR(op, x, n) asm("s_nop 1\n\t" op " %0, %1, %1 row_ror:" #n " row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(x) : "v"(x))
-__global__ void k(const float *in, float *omin, float *osum, float *oswap0, float *oswap1)
+__global__ void k(const float *in, float *o16a, float *o16b, float *o32a, float *o32b, float *ob0, float *ob1)
 {
-    float x = in[threadIdx.x], y = x;
-    PHL_DPP_ROR("v_min_f32_dpp", x, 8); PHL_DPP_ROR("v_min_f32_dpp", x, 4); PHL_DPP_ROR("v_min_f32_dpp", x, 2); PHL_DPP_ROR("v_min_f32_dpp", x, 1);
-    float xa = x, xb = x;
-    asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(xa), "+v"(xb));
-    oswap0[threadIdx.x] = xa; oswap1[threadIdx.x] = xb;
-    omin[threadIdx.x] = fminf(xa, xb);
-    PHL_DPP_ROR("v_add_f32_dpp", y, 8); PHL_DPP_ROR("v_add_f32_dpp", y, 4); PHL_DPP_ROR("v_add_f32_dpp", y, 2); PHL_DPP_ROR("v_add_f32_dpp", y, 1);
-    float ya = y, yb = y;
-    asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(ya), "+v"(yb));
-    osum[threadIdx.x] = ya + yb;
+    const float x = in[threadIdx.x];
+    float a = x, b = x;
+    asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    o16a[threadIdx.x] = a; o16b[threadIdx.x] = b;
+    a = x; b = x;
+    asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    o32a[threadIdx.x] = a; o32b[threadIdx.x] = b;
+    const unsigned u = __builtin_bit_cast(unsigned, x);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    ob0[threadIdx.x] = __builtin_bit_cast(float, r[0]); ob1[threadIdx.x] = __builtin_bit_cast(float, r[1]);
 }
 int main()
 {
-    float h[64], *d, *o; hipMalloc(&d, 256); hipMalloc(&o, 4 * 256);
-    for (int i = 0; i < 64; i++) h[i] = (float)((i * 37) % 64) + 1;
+    float h[64], *d, *o; hipMalloc(&d, 256); hipMalloc(&o, 6 * 256);
+    for (int i = 0; i < 64; i++) h[i] = (float)i;
     hipMemcpy(d, h, 256, hipMemcpyHostToDevice);
-    k<<<1, 64>>>(d, o, o + 64, o + 128, o + 192);
-    float r[256]; hipMemcpy(r, o, 1024, hipMemcpyDeviceToHost);
-    for (int hf = 0; hf < 2; hf++) {
-        float m = 1e9, s = 0; for (int i = 0; i < 32; i++) { m = fminf(m, h[hf * 32 + i]); s += h[hf * 32 + i]; }
-        printf("half %d expect min %g sum %g | got", hf, m, s);
-        for (int i = 0; i < 32; i += 5) printf(" [%g %g]", r[hf * 32 + i], r[64 + hf * 32 + i]);
-        printf("\n");
+    k<<<1, 64>>>(d, o, o + 64, o + 128, o + 192, o + 256, o + 320);
+    float r[384]; hipMemcpy(r, o, sizeof(r), hipMemcpyDeviceToHost);
+    int bad16 = 0, bad32 = 0, builtin_same = 0;
+    for (int l = 0; l < 64; l++) {
+        const int row = l >> 4, c = l & 15;
+        bad16 += r[l] != (float)((row & ~1) * 16 + c) || r[64 + l] != (float)((row | 1) * 16 + c);
+        bad32 += r[128 + l] != (float)(l & 31) || r[192 + l] != (float)(32 + (l & 31));
+        builtin_same += r[256 + l] == r[320 + l];
     }
-    printf("row mins after rotations (lanes 0,16,32,48): swap0 %g %g %g %g  swap1 %g %g %g %g\n", r[128], r[144], r[160], r[176], r[192], r[208], r[224], r[240]);
-    return 0;
+    printf("v_permlane16_swap (asm): %d mismatches; v_permlane32_swap (asm): %d mismatches; builtin: both results equal in %d of 64 lanes\n",
+           bad16, bad32, builtin_same);
+    return bad16 || bad32;
 }
