@@ -1,6 +1,8 @@
-"""Debug: phase timeline of k_compat_softmax's persistent workgroups (needs a library built with
-`make -C depth-estimation_amd/csrc EXTRA=-DPHL_COMPAT_TIMELINE`; 100 MHz stamps of each workgroup's first 8 tiles).
-  python tools/compat_timeline.py  -> durations of the MFMA and epilogue halves per wave group."""
+"""Debug: phase timeline of k_compat_softmax's two wave groups.  Needs a library built with
+`touch depth-estimation_amd/csrc/phl_meanfield.hip; make -C depth-estimation_amd/csrc EXTRA="-DPHL_COMPAT_TIMELINE"`
+(100 MHz stamps at the start of each half of a group's first 8 tiles); add -DPHL_CS_FINE for shader-clock stamps of
+every barrier arrival in the third iteration (each stamp costs ~800 cycles: read differences, not totals).
+  python tools/compat_timeline.py  -> duration of the MFMA and epilogue halves; who arrives last at each slot's barrier."""
 import os, sys
 path = "/tmp/phl_compat_timeline.bin"
 os.environ["PHL_COMPAT_TIMELINE"] = path
