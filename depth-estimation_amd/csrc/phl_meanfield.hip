@@ -547,11 +547,20 @@ __global__ __launch_bounds__(512) void k_compat_softmax(const float *__restrict_
                             make_float4(acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3]);
                     if (has_next) PHL_E0_LOAD_UNIT(t, g, erows);
                 }
-                // Mu for the next slot and the X requested a slot ago must have landed; this slot's X pieces and the
-                // units issued after them need not (vmcnt counts in issue order)
-                constexpr int UNITS = (NT > 1 && s == NT - 1) ? 0 : (u_hi > u_lo ? u_hi - u_lo : 0);
-                if (valid && has_next) PHL_WAIT_BUT(xp, 2 * UNITS);
-                else if (valid || has_next) PHL_WAIT_BUT(xp, UNITS);
+                // What slot S+1 reads was requested in slot S-1 and must have landed.  vmcnt counts in issue order, so
+                // everything younger may stay in flight: the units of slot S-1 (issued behind its DMAs), this slot's
+                // DMAs and this slot's units -- E0 loads and Q stores get two slots to complete, not one (with one,
+                // the slot length was the loaded memory latency)
+                // (counted: loads always issue; under PAD a store of the last label tile may have no lane left and be
+                // skipped, so those are not counted -- allowing fewer in flight only waits longer)
+                constexpr int p_lo = s >= 1 && s - 1 < D ? (U * (s - 1) + D - 1) / D : U, p_hi = s >= 1 && s < D ? (U * s + D - 1) / D : U;
+                constexpr int FIRM = PAD ? 4 * (NT - 1) : U;             // units below this index always store
+                constexpr int LOADS = (u_hi > u_lo ? u_hi - u_lo : 0) + (p_hi > p_lo ? p_hi - p_lo : 0);
+                constexpr int STORES = ((u_hi < FIRM ? u_hi : FIRM) > u_lo ? (u_hi < FIRM ? u_hi : FIRM) - u_lo : 0) +
+                                       ((p_hi < FIRM ? p_hi : FIRM) > p_lo ? (p_hi < FIRM ? p_hi : FIRM) - p_lo : 0);
+                if (valid && has_next) PHL_WAIT_BUT(xp, LOADS + STORES);
+                else if (has_next) PHL_WAIT_BUT(xp, LOADS);
+                else if (valid) PHL_WAIT_BUT(xp, STORES);
                 else PHL_WAIT_BUT(xp, 0);
                 CS_ARRIVE(NT + s);
                 __builtin_amdgcn_s_barrier();
