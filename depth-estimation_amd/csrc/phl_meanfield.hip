@@ -9,6 +9,7 @@
 //   k_expected_value    out[p] = sum_c Q[p,c] * labels[c]                (Experiments/DenseCrf.ipynb cell 11)
 #include <math.h>
 #include <type_traits>
+#include <atomic>
 
 #include "phl_internal.h"
 
@@ -680,11 +681,19 @@ int phl_compat_softmax(const float *E0, int64_t e_rs, const float *X, int64_t x_
         hipMemset(tl_buf, 0, 512 * 64 * 8);
     }
 #endif
+    // more than 64 KiB of dynamic LDS needs the attribute, once per device and instance (not per launch: the call is
+    // not a stream operation, and a launch may sit inside a stream capture)
+    int dev = 0;
+    PHL_HIP(hipGetDevice(&dev));
 #define PHL_CS_LAUNCH(NT_, LG_, PD_)                                                                                    \
     do {                                                                                                                  \
-        if (lds > 64 * 1024)                                                                                              \
+        static std::atomic<unsigned long long> ready{0};                                                                  \
+        const unsigned long long bit = 1ull << (dev & 63);                                                                \
+        if (lds > 64 * 1024 && !(ready.load(std::memory_order_acquire) & bit)) {                                          \
             PHL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_compat_softmax<NT_, LG_, PD_>),                 \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                           \
+            ready.fetch_or(bit, std::memory_order_release);                                                               \
+        }                                                                                                                 \
         k_compat_softmax<NT_, LG_, PD_><<<dim3(grid), dim3(512), lds, st>>>(E0, e_rs, X, x_rs, MuT, out, o_rs, n, L);     \
     } while (0)
 #define PHL_CS(NT_)                                                                                                       \

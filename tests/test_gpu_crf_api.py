@@ -233,6 +233,51 @@ def test_fused_compat_softmax_kernel(n, L):
     assert phl.compat_softmax(E0, X, Mu, out=out) is out and torch.equal(out, got)
 
 
+def test_compat_softmax_many_tiles_both_groups_and_tails():
+    """The tile kernel walks pairs of 128-pixel tiles with two wave groups per workgroup, fed through LDS rings two
+    slots ahead: sizes with an odd tile count, more tile pairs than workgroups (several iterations per group), exactly
+    one tile (group 1 idle), and every tail length class; bitwise reproducible from call to call (no race in the
+    ring hand-off)."""
+    import phl
+
+    g = torch.Generator(device="cuda").manual_seed(11)
+    for n, L in ((128, 256), (3 * 128, 256), (128 * 1031 + 77, 64), (128 * 2 * 256 * 3 + 128 + 5, 32), (128 * 700, 128), (127, 256)):
+        E0 = torch.rand((n, L), device="cuda", generator=g) * 30 - 5
+        X = torch.rand((n, L), device="cuda", generator=g)
+        Mu = torch.rand((L, L), device="cuda", generator=g) * 3
+        got = phl.compat_softmax(E0, X, Mu)
+        want = torch.softmax(-(E0 + X @ Mu), dim=1)
+        err = float((got - want).abs().max())
+        print(f"[measured] compat_softmax n={n} L={L}: max abs diff to torch fp32 {err:.2e}")
+        assert err <= 2e-5 and bool(torch.isfinite(got).all())
+        for _ in range(3):
+            assert torch.equal(phl.compat_softmax(E0, X, Mu), got)
+
+
+def test_compat_softmax_inside_a_captured_graph_and_unaligned_rows():
+    import phl
+
+    g = torch.Generator(device="cuda").manual_seed(5)
+    n, L = 128 * 40 + 9, 256
+    E0 = torch.rand((n, L), device="cuda", generator=g) * 10
+    X = torch.rand((n, L), device="cuda", generator=g)
+    Mu = torch.rand((L, L), device="cuda", generator=g)
+    out = torch.empty_like(E0)
+    want = phl.compat_softmax(E0, X, Mu).clone()              # (also the warm-up: LDS attribute, Mu^T cache)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        phl.compat_softmax(E0, X, Mu, out=out)
+    out.zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, want)
+    # rows that are not 16-byte aligned cannot use the 16-byte epilogue accesses: the library GEMM path takes over
+    E0u = (torch.rand((n, L + 1), device="cuda", generator=g) * 10)[:, 1:]
+    assert E0u.data_ptr() % 16 != 0 or E0u.stride(0) % 4 != 0
+    got = phl.compat_softmax(E0u, X, Mu)
+    assert float((got - torch.softmax(-(E0u + X @ Mu), dim=1)).abs().max()) <= 2e-5
+
+
 def test_compat_softmax_falls_back_for_other_label_counts():
     import phl
 
