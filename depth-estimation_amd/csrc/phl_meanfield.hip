@@ -508,14 +508,11 @@ __global__ __launch_bounds__(512) void k_compat_softmax(const float *__restrict_
         }
         CS_STAMP(2 * it + 1);
         // =========== epilogue half: softmax and store of `tile`, E0 of the group's next tile in, loader duty =======
-        // One piece per slot of the other group's MFMA half.  Slot s first feeds slot s+1 of whoever is on the matrix
-        // cores then (the other group's chunk s+1; after the last slot this group itself, chunk 0 of its next tile),
-        // then moves its share of the 16 pixel rows a lane holds: a stored row's registers take the next tile's E0 at
-        // once (the MFMA's C input, so E = E0 + X @ Mu comes out of the matrix pipe).  Before the barrier it waits for
-        // the DMAs only (a counted wait: the row traffic issued after them stays in flight); the last slot moves no
-        // rows and drains everything.
-        // C/D map: column = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5): for one register the 32 lanes of a
-        // half-wave hold 32 consecutive labels of one pixel (128 B per access).
+        // One piece per slot of the other group's MFMA half.  A slot first does its loader duty (feed(): what the
+        // matrix cores read two slots from now), then moves its share of the 4 NT units of 4 registers a lane holds: a
+        // stored unit's registers take the next tile's E0 at once (the MFMA's C input, so E = E0 + X @ Mu comes out of
+        // the matrix pipe).  Before the barrier it waits for the DMAs that the NEXT slot reads, nothing younger (a
+        // counted wait); the last slot moves no units, so that the E0 loads have landed when the MFMA half begins.
         {
             const int64_t nxt = tile + G2;
             const bool has_next = nxt < ntiles;  // uniform
@@ -574,6 +571,7 @@ __global__ __launch_bounds__(512) void k_compat_softmax(const float *__restrict_
     if (grp == 0) {
         for (int s = 0; s < NT; s++) __builtin_amdgcn_s_barrier();
     }
+    dma_drain();                                 // the last feeds nobody reads: landed before the LDS is given back
 }
 #undef PHL_E0_LOAD_UNIT
 #undef PHL_WAIT_BUT
