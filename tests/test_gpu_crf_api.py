@@ -254,6 +254,36 @@ def test_compat_softmax_many_tiles_both_groups_and_tails():
             assert torch.equal(phl.compat_softmax(E0, X, Mu), got)
 
 
+def test_compat_softmax_random_shapes():
+    """Random (n, L) incl. padded label counts, tails and the logits epilogue, E0 / X / out as row-padded views with
+    different strides, against torch's fp32 GEMM + softmax."""
+    import random
+
+    import phl
+
+    rnd = random.Random(20261004)
+    g = torch.Generator(device="cuda").manual_seed(99)
+    worst = 0.0
+    for _ in range(40):
+        L = 4 * rnd.randint(1, 64)
+        n = rnd.choice([rnd.randint(1, 300), rnd.randint(300, 5000), 128 * rnd.randint(1, 600), 128 * rnd.randint(500, 1200) + rnd.randint(0, 127)])
+        pe, px, po = (4 * rnd.randint(0, 3) for _ in range(3))
+        E0 = (torch.rand((n, L + pe), device="cuda", generator=g) * 25 - 5)[:, :L]
+        X = (torch.rand((n, L + px), device="cuda", generator=g) - 0.2)[:, :L]
+        Mu = torch.rand((L, L), device="cuda", generator=g) * 2
+        out = torch.full((n, L + po), -7.0, device="cuda")
+        logits = rnd.random() < 0.3
+        got = phl.compat_softmax(E0, X, Mu, out=out[:, :L], logits=logits)
+        E = E0 + X @ Mu
+        want = -E if logits else torch.softmax(-E, dim=1)
+        tol = 1e-4 * float(E.abs().max()) if logits else 2e-5
+        err = float((got - want).abs().max())
+        worst = max(worst, err / tol)
+        assert err <= tol, (n, L, logits, err)
+        assert po == 0 or bool((out[:, L:] == -7.0).all()), "wrote into the row padding"
+    print(f"[measured] compat_softmax random shapes: worst error / tolerance = {worst:.2f}")
+
+
 def test_compat_softmax_inside_a_captured_graph_and_unaligned_rows():
     import phl
 
