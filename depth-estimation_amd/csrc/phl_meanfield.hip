@@ -94,6 +94,64 @@ __global__ __launch_bounds__(256) void k_softmax_neg_add_generic(const float *__
     }
 }
 
+// Compatibility matrices of the Potts family, Mu = alpha J + beta I (J all ones: `potts` is alpha = 1, beta = -1,
+// crf_module.py:55-64): X @ Mu = alpha rowsum(X) + beta X, so the whole non-lattice half of the iteration is one
+// streaming pass over E0, X and Q -- no matrix product at all.  A wave per pixel row, NV float4 per lane.
+template <int NV, bool LOGITS>
+__global__ __launch_bounds__(256) void k_uniform_compat_softmax(const float *__restrict__ E0, int64_t e_rs,
+                                                                const float *__restrict__ X, int64_t x_rs, float alpha,
+                                                                float beta, float *__restrict__ out, int64_t o_rs,
+                                                                int64_t n, int L)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t nw = (int64_t)gridDim.x * 4;
+    for (int64_t p = wave; p < n; p += nw) {
+        float4 e[NV], x[NV];
+        float xs = 0.f;
+#pragma unroll
+        for (int j = 0; j < NV; j++) {
+            const int c = (j * 64 + lane) * 4;
+            if (c < L) {
+                e[j] = *reinterpret_cast<const float4 *>(E0 + p * e_rs + c);
+                x[j] = *reinterpret_cast<const float4 *>(X + p * x_rs + c);
+                xs += (x[j].x + x[j].y) + (x[j].z + x[j].w);
+            }
+        }
+        const float base = alpha * wave_sum(xs);
+        float m = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < NV; j++) {
+            const int c = (j * 64 + lane) * 4;
+            if (c < L) {            // x := -E = -(E0 + alpha sum + beta x)
+                x[j] = make_float4(-(e[j].x + (base + beta * x[j].x)), -(e[j].y + (base + beta * x[j].y)),
+                                   -(e[j].z + (base + beta * x[j].z)), -(e[j].w + (base + beta * x[j].w)));
+                m = fmaxf(fmaxf(m, fmaxf(x[j].x, x[j].y)), fmaxf(x[j].z, x[j].w));
+            }
+        }
+        float inv = 1.f;
+        if (!LOGITS) {
+            m = wave_max(m);
+            float s = 0.f;
+#pragma unroll
+            for (int j = 0; j < NV; j++) {
+                const int c = (j * 64 + lane) * 4;
+                if (c < L) {
+                    x[j] = make_float4(expf(x[j].x - m), expf(x[j].y - m), expf(x[j].z - m), expf(x[j].w - m));
+                    s += (x[j].x + x[j].y) + (x[j].z + x[j].w);
+                }
+            }
+            inv = 1.0f / wave_sum(s);
+        }
+#pragma unroll
+        for (int j = 0; j < NV; j++) {
+            const int c = (j * 64 + lane) * 4;
+            if (c < L)
+                *reinterpret_cast<float4 *>(out + p * o_rs + c) = make_float4(x[j].x * inv, x[j].y * inv, x[j].z * inv, x[j].w * inv);
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void k_expected_value(const float *__restrict__ Q, int64_t q_rs,
                                                         const float *__restrict__ labels, float *__restrict__ out,
                                                         int64_t n, int L)
@@ -641,6 +699,32 @@ int phl_softmax_neg_add(const float *E0, int64_t e_rs, const float *G, int64_t g
     else if (v4 && L <= 512) k_softmax_neg_add<2><<<dim3(grid), dim3(256), 0, st>>>(E0, e_rs, G, g_rs, out, o_rs, n, L);
     else if (v4 && L <= 1024) k_softmax_neg_add<4><<<dim3(grid), dim3(256), 0, st>>>(E0, e_rs, G, g_rs, out, o_rs, n, L);
     else k_softmax_neg_add_generic<<<dim3(grid), dim3(256), 0, st>>>(E0, e_rs, G, g_rs, out, o_rs, n, L);
+    PHL_HIP(hipGetLastError());
+    return PHL_OK;
+}
+
+int phl_uniform_compat_softmax(const float *E0, int64_t e_rs, const float *X, int64_t x_rs, float alpha, float beta, float *out,
+                               int64_t o_rs, int64_t n, int L, unsigned flags, phl_stream stream)
+{
+    if (n < 0 || L < 1 || (n > 0 && (!E0 || !X || !out))) { phl_set_error("phl_uniform_compat_softmax: bad arguments"); return PHL_ERR_INVALID; }
+    if (n == 0) return PHL_OK;
+    if (L % 4 || L > 1024 || x_rs % 4 || e_rs % 4 || o_rs % 4 ||
+        ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(E0) | reinterpret_cast<uintptr_t>(out)) & 15)) {
+        phl_set_error("phl_uniform_compat_softmax: needs L %% 4 == 0, L <= 1024 and 16-byte aligned E0 / X / out rows (L=%d)", L);
+        return PHL_ERR_UNSUPPORTED;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned grid = rows_grid(n);
+    const bool logits = (flags & PHL_COMPAT_LOGITS) != 0;
+#define PHL_UC(NV_)                                                                                                       \
+    do {                                                                                                                  \
+        if (logits) k_uniform_compat_softmax<NV_, true><<<dim3(grid), dim3(256), 0, st>>>(E0, e_rs, X, x_rs, alpha, beta, out, o_rs, n, L);  \
+        else k_uniform_compat_softmax<NV_, false><<<dim3(grid), dim3(256), 0, st>>>(E0, e_rs, X, x_rs, alpha, beta, out, o_rs, n, L);        \
+    } while (0)
+    if (L <= 256) PHL_UC(1);
+    else if (L <= 512) PHL_UC(2);
+    else PHL_UC(4);
+#undef PHL_UC
     PHL_HIP(hipGetLastError());
     return PHL_OK;
 }

@@ -88,6 +88,7 @@ def load_library():
         lib.phl_softmax_neg_add.argtypes = [vp, i64, vp, i64, vp, i64, i64, i32, vp]
         lib.phl_expected_value.argtypes = [vp, i64, vp, vp, i64, i32, vp]
         lib.phl_compat_softmax.argtypes = [vp, i64, vp, i64, vp, vp, i64, i64, i32, u32, vp]
+        lib.phl_uniform_compat_softmax.argtypes = [vp, i64, vp, i64, C.c_float, C.c_float, vp, i64, i64, i32, u32, vp]
         lib.phl_stream_copy.argtypes = [vp, vp, i64, vp]
         lib.phl_cost_volume.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, vp, i64, vp]
         lib.phl_get_keys.argtypes = [vp, vp]
@@ -407,17 +408,50 @@ def _mu_transposed(Mu, device):
     return hit[0]
 
 
-def compat_softmax(E0, X, Mu, out=None, logits=False):
+_mu_uniform_cache = {}
+
+
+def _mu_uniform(Mu):
+    """(alpha, beta) if Mu == alpha * ones + beta * eye exactly (the Potts family: the reference's ``potts`` layer is
+    (1, -1), crf_module.py:55-64), else None.  One device -> host read per (storage, version) of Mu."""
+    key = (Mu.data_ptr(), Mu._version, tuple(Mu.shape), tuple(Mu.stride()))
+    if key in _mu_uniform_cache:
+        return _mu_uniform_cache[key][0]
+    if len(_mu_uniform_cache) > 8:
+        _mu_uniform_cache.clear()
+    L = Mu.shape[0]
+    res = None
+    m = Mu.detach().to(torch.float32)
+    if L >= 2:
+        alpha = m[0, 1]
+        beta = m[0, 0] - alpha
+        if bool(((m - alpha) - beta * torch.eye(L, dtype=torch.float32, device=m.device) == 0).all()) and bool(torch.isfinite(m).all()):
+            res = (float(alpha), float(beta))
+    _mu_uniform_cache[key] = (res, Mu)           # keeps Mu alive
+    return res
+
+
+def compat_softmax(E0, X, Mu, out=None, logits=False, structure=True):
     """softmax(-(E0 + X @ Mu), dim=1): the whole non-lattice half of a mean-field iteration
     (crf/crf_module.py:51-52) for fp32 CUDA E0, X [n, L] and Mu [L, L], in one fused MFMA kernel
     (phl_compat_softmax) when L % 4 == 0 and L <= 256 (label counts that are not a multiple of 32 run on a padded
-    tile); other label counts take a library GEMM followed by the fused add + softmax pass.  logits=True returns -(E0 + X @ Mu) instead (CRFasRNN's output)."""
+    tile); other label counts take a library GEMM followed by the fused add + softmax pass.  A Mu of the Potts family
+    (alpha * ones + beta * eye, detected once per Mu; ``structure=False`` switches that off) needs no product at all:
+    phl_uniform_compat_softmax streams E0, X and Q once.  logits=True returns -(E0 + X @ Mu) instead (CRFasRNN's output)."""
     if not (_rowmajor(E0) and _rowmajor(X) and X.shape == E0.shape and Mu.shape == (E0.shape[1], E0.shape[1])):
         raise TypeError("compat_softmax: expects fp32 CUDA E0, X [n, L] with unit channel stride and Mu [L, L]")
     n, L = E0.shape
     if out is None:
         out = torch.empty((n, L), dtype=torch.float32, device=E0.device)
-    if L % 4 == 0 and L <= 256 and all(t.stride(0) % 4 == 0 and t.data_ptr() % 16 == 0 for t in (X, E0, out)):
+    aligned = L % 4 == 0 and all(t.stride(0) % 4 == 0 and t.data_ptr() % 16 == 0 for t in (X, E0, out))
+    uniform = _mu_uniform(Mu) if (structure and aligned and L <= 1024) else None
+    if uniform is not None:                      # Potts family: X @ Mu = alpha rowsum(X) + beta X, one streaming pass
+        with torch.cuda.device(E0.device):
+            _check(load_library().phl_uniform_compat_softmax(
+                C.c_void_p(E0.data_ptr()), E0.stride(0), C.c_void_p(X.data_ptr()), X.stride(0), C.c_float(uniform[0]),
+                C.c_float(uniform[1]), C.c_void_p(out.data_ptr()), out.stride(0), n, L, 1 if logits else 0, _stream(E0.device)))
+        return out
+    if aligned and L <= 256:
         mu_t = _mu_transposed(Mu, E0.device)
         with torch.cuda.device(E0.device):
             _check(load_library().phl_compat_softmax(

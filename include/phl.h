@@ -216,6 +216,14 @@ enum phl_compat_flags { PHL_COMPAT_SOFTMAX = 0, PHL_COMPAT_LOGITS = 1 };
 int phl_compat_softmax(const float *E0_dev, int64_t e0_row_stride, const float *X_dev, int64_t x_row_stride,
                        const float *mu_t_dev, float *out_dev, int64_t out_row_stride, int64_t n, int L, unsigned flags,
                        phl_stream stream);
+/* The same step for compatibility matrices of the Potts family, Mu = alpha*J + beta*I (J all ones; the reference's
+ * `potts` layer is alpha = 1, beta = -1, crf_module.py:55-64): X @ Mu = alpha*rowsum(X) + beta*X, so
+ * out[p,:] = softmax(-(E0[p,:] + alpha*sum_c X[p,c] + beta*X[p,:])) is one streaming pass, no matrix product.
+ * Needs L % 4 == 0, L <= 1024, row strides % 4 == 0 and 16-byte aligned E0 / X / out (else PHL_ERR_UNSUPPORTED).
+ * flags: phl_compat_flags. */
+int phl_uniform_compat_softmax(const float *E0_dev, int64_t e0_row_stride, const float *X_dev, int64_t x_row_stride,
+                               float alpha, float beta, float *out_dev, int64_t out_row_stride, int64_t n, int L,
+                               unsigned flags, phl_stream stream);
 /* out[p] = sum_c Q[p,c]*labels[c] : the expected disparity `mf @ labels`
  * (Experiments/DenseCrf.ipynb cell 11). */
 int phl_expected_value(const float *Q_dev, int64_t q_row_stride, const float *labels_dev, float *out_dev,

@@ -284,6 +284,36 @@ def test_compat_softmax_random_shapes():
     print(f"[measured] compat_softmax random shapes: worst error / tolerance = {worst:.2f}")
 
 
+def test_potts_family_compatibility_takes_the_streaming_path():
+    """Mu = alpha * ones + beta * eye (the reference's `potts` layer is 1 - I, crf_module.py:55-64) needs no matrix
+    product: phl_uniform_compat_softmax must agree with the dense MFMA kernel on the same Mu and with torch, for
+    the softmax and the logits epilogue, and a Mu outside the family must NOT take it."""
+    import phl
+
+    g = torch.Generator(device="cuda").manual_seed(21)
+    for n, L, alpha, beta in ((5000, 256, 1.0, -1.0), (777, 64, 0.5, 2.0), (129, 16, 0.0, -3.0), (4000, 512, 1.0, -1.0)):
+        E0 = torch.rand((n, L), device="cuda", generator=g) * 12
+        X = torch.rand((n, L), device="cuda", generator=g) * 0.1
+        Mu = alpha * torch.ones((L, L), device="cuda") + beta * torch.eye(L, device="cuda")
+        assert phl._mu_uniform(Mu) == (alpha, beta)
+        E = E0.double() + X.double() @ Mu.double()
+        for logits in (False, True):
+            want = -E if logits else torch.softmax(-E, dim=1)
+            fast = phl.compat_softmax(E0, X, Mu, logits=logits)
+            dense = phl.compat_softmax(E0, X, Mu, logits=logits, structure=False)
+            tol = 1e-5 * float(E.abs().max()) if logits else 2e-6
+            e_fast, e_dense = float((fast.double() - want).abs().max()), float((dense.double() - want).abs().max())
+            print(f"[measured] potts family n={n} L={L} logits={logits}: streaming {e_fast:.2e}, dense {e_dense:.2e} (tol {tol:.1e})")
+            assert e_fast <= tol and e_dense <= max(tol, 3e-5 if not logits else tol)
+    Mu = torch.ones((64, 64), device="cuda") - torch.eye(64, device="cuda")
+    Mu[3, 5] += 1e-3
+    assert phl._mu_uniform(Mu) is None
+    # the reference-shaped caller: CRF mean field with the potts layer's matrix
+    from crf import crf_module
+    Mu = crf_module.potts(32).weight.detach()[:, :, 0, 0].t().contiguous().cuda()
+    assert phl._mu_uniform(Mu) == (1.0, -1.0)
+
+
 def test_compat_softmax_inside_a_captured_graph_and_unaligned_rows():
     import phl
 
@@ -370,6 +400,28 @@ def test_crf_as_rnn_nchw_golden(golden_dir):
     from crf.crf_module import ijrgbGuide
     mine = ijrgbGuide(trainable=False)(torch.from_numpy(g["img"]).to(dev))
     assert float((mine - refs).abs().max()) <= 1e-6 * float(refs.abs().max())
+
+
+def test_crf_as_rnn_with_the_potts_layer():
+    """CRFasRNN(potts(L), lattice=True) (crf_module.py:55-64, 81-104): the no-grad path recognises the layer's 1 - I
+    weights and runs the streaming compatibility pass; it must agree with the autograd path (plain conv modules)."""
+    from crf.crf_module import CRFasRNN, ijrgbGuide, potts
+
+    torch.manual_seed(3)
+    L = 16
+    net = CRFasRNN(potts(L), niters=3, lattice=True).cuda()
+    img = torch.rand(2, 3, 24, 32, device="cuda")
+    logits = torch.randn(2, L, 24, 32, device="cuda")
+    refs = ijrgbGuide(trainable=False)(img)
+    with torch.no_grad():
+        fused = net(refs, logits)
+    lg = logits.clone().requires_grad_(True)
+    plain = net(refs, lg)
+    err = float((fused - plain.detach()).abs().max() / plain.detach().abs().max())
+    print(f"[measured] CRFasRNN + potts: fused vs autograd path {err:.2e} of the largest logit")
+    assert err <= 1e-5
+    plain.sum().backward()
+    assert torch.isfinite(lg.grad).all()
 
 
 def test_mean_field_gradient_through_the_lattice_operator():

@@ -26,3 +26,7 @@ G = torch.empty_like(E0)
 ms_mm = t(lambda: torch.mm(X, Mu, out=G))
 ms_sm = t(lambda: phl.softmax_neg_add(E0, G, out=out))
 print(f"rocBLAS mm {ms_mm:.3f} ms ({2 * n * L * L / ms_mm / 1e9:.1f} TF) + fused add/softmax {ms_sm:.3f} ms = {ms_mm + ms_sm:.3f} ms")
+Mp = torch.ones((L, L), device=dev) - torch.eye(L, device=dev)          # the reference's potts layer (crf_module.py:55-64)
+ms_p = t(lambda: phl.compat_softmax(E0, X, Mp, out=out))
+ms_pd = t(lambda: phl.compat_softmax(E0, X, Mp, out=out, structure=False))
+print(f"Potts compatibility (1 - I): streaming pass {ms_p:.3f} ms = {3 * n * L * 4 / ms_p / 1e6:.0f} GB/s of E0 + X + Q; as a dense product {ms_pd:.3f} ms")
