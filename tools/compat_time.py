@@ -1,5 +1,6 @@
 """Timing of the fused compatibility + softmax kernel (phl_compat_softmax) against rocBLAS mm + fused softmax,
-on C3-size operands (3,145,728 x 256).  Run on the GPU box; prints HIP-event times."""
+on C3-size operands (3,145,728 x 256).  Run on the GPU box; prints steady-state HIP-event times (10 launches after 10
+warm-up launches; tools/compat_seq.py shows the ramp: an isolated launch is ~15 % slower than the tenth in a row)."""
 import os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, 'depth-estimation_amd')); sys.path.insert(0, ROOT)
@@ -11,8 +12,9 @@ E0 = torch.rand((n, L), device=dev, generator=g) * 10
 X = torch.rand((n, L), device=dev, generator=g)
 Mu = torch.rand((L, L), device=dev, generator=g) * 3
 out = torch.empty_like(E0)
-def t(f, reps=5):
-    f(); torch.cuda.synchronize()
+def t(f, reps=10):
+    for _ in range(10): f()          # steady state: the clocks take ~6 back-to-back launches (25 ms) to come up from idle
+    torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
     for _ in range(reps): f()

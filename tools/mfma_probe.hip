@@ -212,8 +212,25 @@ void coexec(int mfma_iters, int other_iters, int mode, float *mem)
     printf("\n");
     hipFree(d); hipFree(st);
 }
+// sustained rate: the same launch 24 times back to back, each timed (clock ramp-up from idle, power limits)
+void sustain()
+{
+    float *d; hipMalloc(&d, 512 * 256 * 4);
+    hipEvent_t ev[25];
+    for (auto &e : ev) hipEventCreate(&e);
+    for (int random = 0; random < 2; random++) {
+        hipEventRecord(ev[0]);
+        for (int k = 0; k < 24; k++) { k_loop<1, 256><<<512, 256>>>(d, 1024, random); hipEventRecord(ev[k + 1]); }
+        hipDeviceSynchronize();
+        printf("inner loop (LDS operands%s), 2 waves/SIMD, 24 launches back to back, TFLOP/s:", random ? ", random data" : "");
+        for (int k = 0; k < 24; k++) { float ms; hipEventElapsedTime(&ms, ev[k], ev[k + 1]); printf(" %.0f", 512.0 * 4 * 1024 * 128 * 4096 / ms / 1e9); }
+        printf("\n");
+    }
+    hipFree(d);
+}
 int main(int argc, char **argv)
 {
+    if (argc > 1 && argv[1][0] == 's') { sustain(); return 0; }
     if (argc > 1) {
         float *mem; const size_t bytes = (size_t)256 * 4 * 1024 * 8192;    // other_iters <= 1024
         hipMalloc(&mem, bytes); hipMemset(mem, 0, bytes);
