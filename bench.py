@@ -328,8 +328,9 @@ def dry_rank(args, rank, world):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=40)
+    # (tools/step_seq.py: from an idle GPU the clocks take ~8 steps to come up; 3 warm-up steps left 1 % on the table)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-tiles", action="store_true", help="plain gather kernels (A/B against the LDS-staged chunk path)")
