@@ -192,25 +192,26 @@ __global__ __launch_bounds__(256) void k_stream_copy(const vf4 *__restrict__ src
 // ------------------------------------------------------------------------------------------------------------
 // k_compat_softmax: out[p,:] = softmax(-(E0[p,:] + X[p,:] @ Mu)) -- everything of a mean-field iteration that is
 // not the lattice filter (crf/crf_module.py:51-52 with X = W@Q), in ONE kernel: the [n,L]x[L,L] compatibility
-// product on the fp32-input matrix cores (v_mfma_f32_32x32x2_f32: exact f32, bitwise an fmaf chain in k order;
+// product on the fp32-input matrix cores (v_mfma_f32_16x16x4_f32: exact f32, bitwise an fmaf chain in k order;
 // gfx950 has no xf32/TF32 path and the reference computes in f32), with +E0, negate and the row softmax done on
 // the accumulators.  Neither G = X@Mu nor E ever exists in HBM: the iteration's non-lattice half moves 3 x [n,L]
 // (read X, read E0, write Q) instead of the 7 x [n,L] of GEMM + fused softmax, and is MFMA-bound
 // (2 n L^2 flop at ~150 TF f32: 2.75 ms for 2048x1536x256).
 //
-// Tiling.  L = 32*NT <= 256, so a pixel's whole label row fits one wave: a wave owns 32 pixels x all L labels = NT
-// accumulator tiles of 32x32 (16 VGPRs each, 128 at L = 256).  One persistent 512-thread workgroup per CU = two
+// Tiling.  L = 32*NT <= 256, so a pixel's whole label row fits one wave: a wave owns 32 pixels x all L labels = 2 x 2NT
+// accumulator tiles of 16x16 (4 VGPRs each, 128 at L = 256).  One persistent 512-thread workgroup per CU = two
 // GROUPS of four waves, one wave of each per SIMD, working in anti-phase on alternate 128-pixel tiles: while one
 // group walks K = L in NT chunks of 32 on the matrix cores ("MFMA half", NT slots), the other one is in the
 // "epilogue half" of its previous tile -- stores Q, fetches the next tile's E0 straight into the accumulators (the
 // MFMA's C input) -- and FEEDS the first: both operands of the MFMA stream come through LDS rings (Mu's chunk,
 // 32 k x L labels = 32 KiB shared by the four waves; the tile's X chunk, 16 KiB), filled by LDS-DMA two slots
 // ahead.  Every slot ends in the workgroup barrier.  The product is computed transposed (labels = MFMA rows), so
-// that a lane holds four consecutive labels of a pixel in four consecutive registers (16-byte E0 / Q accesses)
-// and a pixel's row sits in two lanes (softmax reductions: in-lane + one v_permlane32_swap).
+// that a lane holds four consecutive labels of a pixel in the four registers of an accumulator (16-byte E0 / Q
+// accesses, 64 contiguous bytes per pixel) and a pixel's row sits in four lanes (softmax reductions: in-lane + two
+// lane swaps).
 //
 // What shaped it (all measured on gfx950; tools/mfma_probe.hip, tools/compat_timeline.py):
-//  * v_mfma_f32_32x32x2_f32 does not overlap with anything else the SIMD issues: a VALU instruction slipped between
+//  * an f32 MFMA stream (measured on v_mfma_f32_32x32x2_f32) does not overlap with anything else the SIMD issues: a VALU instruction slipped between
 //    two MFMAs costs its own time plus a bubble (SQ_VALU_MFMA_COEXEC_CYCLES = 0), and the OTHER wave of the SIMD --
 //    VALU, scalar or memory instructions alike -- only gets issue slots in the stream's gaps.  Two independent
 //    workgroups per CU therefore do not hide an epilogue behind a partner's MFMAs; they take turns anyway, and
@@ -223,11 +224,15 @@ __global__ __launch_bounds__(256) void k_stream_copy(const vf4 *__restrict__ src
 //  * LDS-DMA pieces issued right behind the barrier delay the LDS reads the other group's first MFMAs wait for
 //    (0.8 us per slot): the feeder sleeps 256 cycles first.
 //
-// Operand maps (32x32x2: lane l = (i = l&31, h = l>>5) supplies A[i][k-slot h] and B[k-slot h][j = i]).  A = Mu^T
-// (rows = labels 32t + i), B = X^T (columns = the wave's pixels).  The k order of a contraction is free as long as
-// A and B agree, so a lane reads 16 B = X[pixel i][8q+4h .. 8q+4h+3] and the four values feed MFMAs u = 0..3 of
-// group q: MFMA (q,u) contracts k = 8q+u (lower half-wave) and k = 8q+4+u (upper); for A the lane reads
-// Mu^T[32t+i][8q+4h .. +3] -- 16 contiguous bytes of the TRANSPOSED compatibility matrix, which is what the caller
+//  * what the CU's memory pipe charges for is cache lines per instruction: on 32x32x2 tiles a 16-byte access of the
+//    transposed map touches 32 lines (32 pixels x 32 bytes), on 16x16x4 tiles 16 (16 pixels x 64 bytes) -- same
+//    matrix rate, 3.97 -> 3.67 ms.
+//
+// Operand maps (16x16x4: lane l = (i = l&15, g = l>>4) supplies A[i][k-slot g] and B[k-slot g][j = i]).  A = Mu^T
+// (rows = labels 16T + i), B = X^T (columns = pixels 16 pg + i of the wave's 32).  The k order of a contraction is
+// free as long as A and B agree, so a lane reads 16 B = X[pixel][16q+4g .. 16q+4g+3] and the four values feed MFMAs
+// u = 0..3 of group q: MFMA (q,u) contracts k = 16q + 4g' + u over the four k-slots g'; for A the lane reads
+// Mu^T[16T+i][16q+4g .. +3] -- 16 contiguous bytes of the TRANSPOSED compatibility matrix, which is what the caller
 // passes (MuT[c][k]).  Both LDS images are [row][32 k] with 128-byte rows whose 16-byte slots are XOR-swizzled (see
 // the feeder).  16 bytes global -> LDS without a register in between (global_load_lds_dwordx4): the LDS address is
 // wave-uniform (M0) plus lane*16, the global address is per lane.
@@ -245,7 +250,7 @@ __device__ __forceinline__ void glds16(const float *sbase, unsigned voff, unsign
 }
 __device__ __forceinline__ void dma_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
-// VALU helpers of the epilogue.  v_mfma_f32_32x32x2_f32 and ordinary VALU instructions do NOT overlap on gfx950
+// VALU helpers of the epilogue.  f32 MFMAs and ordinary VALU instructions do NOT overlap on gfx950
 // (tools/mfma_probe.hip: every v_fma slipped between two MFMAs costs its own issue time plus a ~10-cycle bubble,
 // SQ_VALU_MFMA_COEXEC_CYCLES reads 0), so every epilogue instruction is paid for in matrix-pipe time: minima
 // three at a time and without the compiler's NaN canonicalisation (v_max x,x before every v_min), the one
@@ -285,6 +290,8 @@ __device__ __forceinline__ void static_for(F &&f)
     }
 }
 
+// v_permlane16_swap_b32 a, b: the odd 16-lane rows of a trade places with the even rows of b
+#define PHL_ROW_SWAP(a, b) asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b))
 template <int NT, bool LOGITS, bool PAD>
 __global__ __launch_bounds__(512) void k_compat_softmax(const float *__restrict__ E0, int64_t e_rs,
                                                         const float *__restrict__ X, int64_t x_rs,
@@ -293,7 +300,8 @@ __global__ __launch_bounds__(512) void k_compat_softmax(const float *__restrict_
 {
     // Lr = the real label count (a multiple of 4, <= L): columns Lr..L-1 are padding -- MuT is zero there, E0 reads
     // as +inf (so exp gives 0 and the row minimum ignores them), X reads as 0, nothing is stored.
-    typedef float f32x16 __attribute__((ext_vector_type(16)));
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    constexpr int NL = 2 * NT;                     // label tiles of 16
     constexpr int L = 32 * NT;
     constexpr int MU_FLOATS = L * 32;             // one chunk of Mu^T: [L labels][32 k]
     constexpr int X_FLOATS = 4 * 1024;            // one chunk of the tile's X: 4 waves x [32 pixels][32 k]
@@ -304,13 +312,13 @@ __global__ __launch_bounds__(512) void k_compat_softmax(const float *__restrict_
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int grp = wave >> 2, w4 = wave & 3;     // wave group (0/1) and wave within it
-    const int i = lane & 31, h = lane >> 5;
+    const int i = lane & 15, g4 = lane >> 4;      // MFMA 16x16x4: column i, k-slot / row group g4
     const int64_t ntiles = n / 128;               // WHOLE tiles only: the launcher hands the last n % 128 pixels to k_compat_tail
     const int64_t G2 = 2 * (int64_t)gridDim.x;
 
     // RULES OF THIS KERNEL (each one measured, tools/mfma_probe.hip and the in-kernel stamps of the debug build):
     //  * the waves on the matrix cores issue NOTHING but MFMAs and LDS reads.  A VALU instruction between two
-    //    v_mfma_f32_32x32x2_f32 does not overlap with them on gfx950, and a vector-memory instruction takes 100-200
+    //    f32 MFMAs do not overlap with them on gfx950, and a vector-memory instruction takes 100-200
     //    cycles to ISSUE (an LDS-DMA piece as much as a load): 8 + 4 of them per chunk kept the pipe idle for a
     //    quarter of the time.  So both operands come through LDS, and the OTHER wave group -- the one in its epilogue
     //    half, whose SIMD partner is busy with MFMAs anyway -- does all the fetching (loader duty).
@@ -364,53 +372,36 @@ __global__ __launch_bounds__(512) void k_compat_softmax(const float *__restrict_
         if (xp) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((rows) + NT + 4 < 63 ? (rows) + NT + 4 : 63) : "memory");        \
         else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((rows) + NT < 63 ? (rows) + NT : 63) : "memory");                   \
     } while (0)
-    // operand reads: lane (i, h) takes k-part 2q + h of row i (a pixel of X, or label 32t + i of Mu^T) -> slot
-    // ((2q + h) ^ sw) of that row
+    // operand reads (16x16x4: lane (i, g4) supplies A[i][k-slot g4] and B[k-slot g4][i]): the lane takes k-part 4q + g4
+    // of row i (label 16T + i of Mu^T, pixel 16 pg + i of X) -> slot ((4q + g4) ^ sw) of that row; MFMA (q, u)
+    // contracts k = 16q + 4 g4 + u
     const int sw = (i >> 1) & 7;
-    const float *brow[4], *arow[4];
+    const float *brow[2], *arow[2];
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
-        brow[q] = lds + i * 32 + ((2 * q + h) ^ sw) * 4;
+    for (int q = 0; q < 2; q++) {
+        brow[q] = lds + i * 32 + ((4 * q + g4) ^ sw) * 4;
         arow[q] = brow[q] + 3 * MU_FLOATS + w4 * 1024;
     }
 
-    // The product is computed TRANSPOSED (D^T = Mu^T X^T: labels are the MFMA's rows, pixels its columns), so that the
-    // C/D map puts FOUR CONSECUTIVE LABELS of one pixel into four consecutive registers: lane (i, h) holds pixel i of
-    // the wave's 32, register r of tile t is label 32t + 8(r>>2) + 4h + (r&3).  E0 comes in and Q goes out as
-    // 16-byte accesses -- a quarter of the vector-memory instructions of a dword-per-lane layout, which matters
-    // because a wave can have only 63 of them in flight (at ~5 us loaded latency that cap, not bandwidth, set the pace
-    // of the epilogue half) -- and a pixel's row lives in just two lanes (l, l ^ 32): the softmax reductions are
-    // in-lane plus one exchange.
-    // E0 / out addressing: wave-uniform tile pointer (scalar registers) + one per-lane byte offset for the whole
-    // kernel + an immediate.  Every tile is whole: no row masking or clamping anywhere.
-    // Padding is applied where a value is CONSUMED, not where it is loaded (a select on a fresh load would make the
-    // wave wait for it): loads of padded columns are clamped into the row, pad_e0() / pad_x() overwrite them later.
-    const int h4 = 4 * h;
-    const unsigned lo_e = (unsigned)(i * e_rs + h4) * 4u, lo_o = (unsigned)(i * o_rs + h4) * 4u;
-    // unit (t, g): labels 32t + 8g + 4h .. +3 of this lane's pixel = registers 4g .. 4g+3 of accumulator t
-#define PHL_E0_LOAD_UNIT(t, g, wave_rows)  /* wave_rows: E0 row of the wave's first pixel */                               \
+    // The product is computed TRANSPOSED (D^T = Mu^T X^T: labels are the MFMA's rows, pixels its columns) on 16x16x4
+    // tiles: lane (i, g4) holds pixels i and 16 + i of the wave's 32 (pixel groups pg = 0, 1); the four registers of
+    // accumulator (pg, T) are labels 16T + 4 g4 .. +3.  An E0 / Q access is 16 bytes per lane and 64 contiguous bytes
+    // per pixel: 16 lines per instruction (the 32x32x2 map: 32 pixels x 32 bytes = 32 lines, and what the CU's memory
+    // pipe charges for is lines).  A pixel's row sits in four lanes (i + 16 g4).
+    const unsigned lo_e = (unsigned)(i * e_rs + 4 * g4) * 4u, lo_o = (unsigned)(i * o_rs + 4 * g4) * 4u;
+#define PHL_E0_LOAD_UNIT(pg, T, wave_rows)  /* wave_rows: E0 row of the wave's first pixel */                              \
     do {                                                                                                                  \
-        const char *p_ = reinterpret_cast<const char *>((wave_rows) + 32 * (t) + 8 * (g));                                \
+        const char *p_ = reinterpret_cast<const char *>((wave_rows) + (pg) * 16 * e_rs + 16 * (T));                       \
         unsigned lo_ = lo_e;                                                                                              \
-        if (PAD && (t) == NT - 1) {              /* clamp padded columns into the row (Lr >= 32 t + 4: never negative) */ \
-            p_ = reinterpret_cast<const char *>((wave_rows) + 32 * (t));                                                  \
-            lo_ = (unsigned)(i * e_rs + min(8 * (g) + h4, Lr - 4 - 32 * (t))) * 4u;                                       \
+        if (PAD && (T) >= NL - 2) {              /* clamp padded columns into the row */                                  \
+            p_ = reinterpret_cast<const char *>((wave_rows) + (pg) * 16 * e_rs);                                          \
+            lo_ = (unsigned)(i * e_rs + min(16 * (T) + 4 * g4, Lr - 4)) * 4u;                                             \
         }                                                                                                                 \
         const float4 v_ = *reinterpret_cast<const float4 *>(p_ + lo_);                                                    \
-        acc[t][4 * (g)] = v_.x; acc[t][4 * (g) + 1] = v_.y; acc[t][4 * (g) + 2] = v_.z; acc[t][4 * (g) + 3] = v_.w;       \
+        acc[pg][T] = f32x4{v_.x, v_.y, v_.z, v_.w};                                                                       \
     } while (0)
-    auto pad_e0 = [&](f32x16 &last) {                 // only the last label tile holds padding (L - Lr < 32)
-        if (PAD) {
-#pragma unroll
-            for (int g = 0; g < 4; g++)
-                if (32 * (NT - 1) + 8 * g + h4 >= Lr) {
-#pragma unroll
-                    for (int j = 0; j < 4; j++) last[4 * g + j] = INFINITY;
-                }
-        }
-    };
     auto pad_x = [&](float4 &v, int k0) {
-        if (PAD && k0 + h4 >= Lr) v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (PAD && k0 + 4 * g4 >= Lr) v = make_float4(0.f, 0.f, 0.f, 0.f);
     };
 
     // Tiles of this group: 2 (b + k gridDim) + grp, k = 0, 1, ...  Every wave alternates the MFMA half of a tile (NT
@@ -421,16 +412,26 @@ __global__ __launch_bounds__(512) void k_compat_softmax(const float *__restrict_
     const int64_t iters = (ntiles - 2 * (int64_t)blockIdx.x + G2 - 1) / G2;          // tiles 2b, 2b + G2, ... < ntiles
     int64_t tile = 2 * (int64_t)blockIdx.x + grp;
     bool valid = tile < ntiles;                  // wave-uniform
-    f32x16 acc[NT];
+    f32x4 acc[2][NL];
+    auto pad_e0 = [&]() {                             // only the last two label tiles can hold padding (L - Lr < 32)
+        if (PAD) {
+#pragma unroll
+            for (int T = NL - 2; T < NL; T++)
+                if (16 * T + 4 * g4 >= Lr) {
+                    acc[0][T] = f32x4{INFINITY, INFINITY, INFINITY, INFINITY};
+                    acc[1][T] = acc[0][T];
+                }
+        }
+    };
     if (valid) {
 #pragma unroll
-        for (int t = 0; t < NT; t++)
+        for (int pg = 0; pg < 2; pg++)
 #pragma unroll
-            for (int g = 0; g < 4; g++) PHL_E0_LOAD_UNIT(t, g, E0 + (tile * 128 + w4 * 32) * e_rs);
+            for (int T = 0; T < NL; T++) PHL_E0_LOAD_UNIT(pg, T, E0 + (tile * 128 + w4 * 32) * e_rs);
     }
 #ifdef __HIP_DEVICE_COMPILE__                    /* the first tile's E0 has landed before the loop is entered: with that known on
                                                     every path into it, the loop body needs no compiler-made vmcnt wait */
-    asm volatile("" ::"v"(acc[NT - 1]));
+    asm volatile("" ::"v"(acc[1][NL - 1]));
 #endif
     int slot = 0, slot3 = 0;                     // slots since the start, and that number mod 3
     auto next_slot = [&]() { slot++; slot3 = slot3 == 2 ? 0 : slot3 + 1; };
@@ -457,92 +458,96 @@ __global__ __launch_bounds__(512) void k_compat_softmax(const float *__restrict_
     // idle and the other group in the one slot of its epilogue half that has nothing else to do.
     auto softmax_in_place = [&]() {
     if (valid && !LOGITS) {
-        // softmax(-E) of this lane's pixel: 4 NT registers here, the other half of the row in lane ^ 32.
+        // softmax(-E) of this lane's two pixels: 4 NL registers each here, the rest of the rows in lanes i + 16 g4.
         // Shift by the row MINIMUM of E; exp(-(E - min)) = exp2(min log2e - E log2e)
-        float m = acc[0][0];
 #pragma unroll
-        for (int t = 0; t < NT; t++)
+        for (int pg = 0; pg < 2; pg++) {
+            float m = acc[pg][0][0];
+            m = vmin3(m, acc[pg][0][1], acc[pg][0][2]);
 #pragma unroll
-            for (int r = (t == 0 ? 1 : 0); r + 1 < 16; r += 2) m = vmin3(m, acc[t][r], acc[t][r + 1]);
+            for (int T = 1; T < NL; T++) {
+                m = vmin3(m, acc[pg][T][0], acc[pg][T][1]);
+                m = vmin3(m, acc[pg][T][2], acc[pg][T][3]);
+            }
+            m = vmin3(m, acc[pg][0][3], acc[pg][0][3]);
+            {
+                float ma = m, mb = m;
+                PHL_ROW_SWAP(ma, mb);
+                m = vmin3(ma, mb, mb);
+                ma = m; mb = m;
+                PHL_HALF_SWAP(ma, mb);
+                m = vmin3(ma, mb, mb) * 1.4426950408889634f;
+            }
+            f32x4 vs = 0.f;
 #pragma unroll
-        for (int t = 1; t < NT; t++) m = vmin3(m, acc[t][15], acc[t][15]);        // (r = 15 of t = 0 is in the pairs above)
-        {
-            float ma = m, mb = m;
-            PHL_HALF_SWAP(ma, mb);
-            m = vmin3(ma, mb, mb) * 1.4426950408889634f;
+            for (int T = 0; T < NL; T++) {
+                acc[pg][T] = __builtin_elementwise_fma(acc[pg][T], (f32x4)(-1.4426950408889634f), (f32x4)m);
+#pragma unroll
+                for (int r = 0; r < 4; r++) acc[pg][T][r] = __builtin_amdgcn_exp2f(acc[pg][T][r]);
+                vs += acc[pg][T];
+            }
+            float sum = (vs[0] + vs[1]) + (vs[2] + vs[3]);
+            {
+                float sa = sum, sb = sum;
+                PHL_ROW_SWAP(sa, sb);
+                sum = sa + sb;
+                sa = sum; sb = sum;
+                PHL_HALF_SWAP(sa, sb);
+                sum = sa + sb;
+            }
+            const float inv = __builtin_amdgcn_rcpf(sum);
+#pragma unroll
+            for (int T = 0; T < NL; T++) acc[pg][T] *= inv;
         }
-        // whole-accumulator vector arithmetic: packed f32 instructions on aligned register pairs
-        f32x16 vs = 0.f;
-#pragma unroll
-        for (int t = 0; t < NT; t++) {
-            acc[t] = __builtin_elementwise_fma(acc[t], (f32x16)(-1.4426950408889634f), (f32x16)m);
-#pragma unroll
-            for (int r = 0; r < 16; r++) acc[t][r] = __builtin_amdgcn_exp2f(acc[t][r]);
-            vs += acc[t];
-        }
-        typedef float f32x8 __attribute__((ext_vector_type(8)));
-        typedef float f32x4 __attribute__((ext_vector_type(4)));
-        const f32x8 v8 = __builtin_shufflevector(vs, vs, 0, 1, 2, 3, 4, 5, 6, 7) + __builtin_shufflevector(vs, vs, 8, 9, 10, 11, 12, 13, 14, 15);
-        const f32x4 v4 = __builtin_shufflevector(v8, v8, 0, 1, 2, 3) + __builtin_shufflevector(v8, v8, 4, 5, 6, 7);
-        float sum = (v4[0] + v4[1]) + (v4[2] + v4[3]);
-        {
-            float sa = sum, sb = sum;
-            PHL_HALF_SWAP(sa, sb);
-            sum = sa + sb;
-        }
-        // Q = exp / sum, in place and BEFORE the first E0 load of the next tile is issued: a write to one
-        // register of a 16-register accumulator while a load into another one is in flight makes the
-        // compiler wait for that load (it tracks the accumulator as one unit)
-        const float inv = __builtin_amdgcn_rcpf(sum);
-#pragma unroll
-        for (int t = 0; t < NT; t++) acc[t] *= inv;
     } else if (valid) {                  // CRFasRNN returns -E of the last iteration, not Q (crf_module.py:103)
 #pragma unroll
-        for (int t = 0; t < NT; t++) acc[t] = -acc[t];
+        for (int pg = 0; pg < 2; pg++)
+#pragma unroll
+            for (int T = 0; T < NL; T++) acc[pg][T] = -acc[pg][T];
     }
     };
 
     // One K chunk of the MFMA half: operands from LDS only (ring position slot3)
     auto chunk = [&](int kc) {
         if (valid) {
-            float4 a[4];
-            const float *bb[4];                  // (the ring position is the only vector arithmetic of the chunk)
+            float4 xb[2][2];                     // B operands: [pixel group][q]
+            const float *bb[2];                  // (the ring position is the only vector arithmetic of the chunk)
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
-                a[q] = *reinterpret_cast<const float4 *>(arow[q] + slot3 * X_FLOATS);
+            for (int q = 0; q < 2; q++) {
+                xb[0][q] = *reinterpret_cast<const float4 *>(arow[q] + slot3 * X_FLOATS);
+                xb[1][q] = *reinterpret_cast<const float4 *>(arow[q] + slot3 * X_FLOATS + 16 * 32);
                 bb[q] = brow[q] + slot3 * MU_FLOATS;
             }
-            // B operands in half-groups of NT/2 label tiles, software-pipelined by hand: the LDS reads of step s+1 are
-            // issued BEFORE the MFMAs of step s (only one wave per SIMD is on the matrix cores at a time, so an LDS round
-            // trip left exposed is matrix-pipe time lost).
-            constexpr int HT = (NT + 1) / 2, STEPS = NT > 1 ? 8 : 4;     // NT == 1: whole groups
-            float4 b[2][HT];
-            auto read_b = [&](int st, float4 (&dst)[HT]) {
-                const int q = NT > 1 ? st >> 1 : st, t0 = NT > 1 ? (st & 1) * HT : 0;
+            // A operands in blocks of TBS label tiles, software-pipelined by hand: the LDS reads of step s+1 are issued
+            // BEFORE the MFMAs of step s (only one wave per SIMD is on the matrix cores at a time, so an LDS round trip
+            // left exposed is matrix-pipe time lost)
+            constexpr int NB = NL < 4 ? NL : 4, TBS = (NL + NB - 1) / NB, STEPS = 2 * NB;
+            float4 ma[2][TBS];
+            auto read_a = [&](int st, float4 (&dst)[TBS]) {
+                const int q = st / NB, T0 = (st % NB) * TBS;
 #pragma unroll
-                for (int t = 0; t < HT; t++)
-                    if (t0 + t < NT) dst[t] = *reinterpret_cast<const float4 *>(bb[q] + (t0 + t) * 32 * 32);
+                for (int j = 0; j < TBS; j++)
+                    if (T0 + j < NL) dst[j] = *reinterpret_cast<const float4 *>(bb[q] + (T0 + j) * 16 * 32);
             };
-            read_b(0, b[0]);
+            read_a(0, ma[0]);
             if (PAD && kc == NT - 1) {
 #pragma unroll
-                for (int q = 0; q < 4; q++) pad_x(a[q], 32 * kc + 8 * q);
+                for (int q = 0; q < 2; q++) { pad_x(xb[0][q], 32 * kc + 16 * q); pad_x(xb[1][q], 32 * kc + 16 * q); }
             }
 #pragma unroll
             for (int st = 0; st < STEPS; st++) {
-                const int q = NT > 1 ? st >> 1 : st, t0 = NT > 1 ? (st & 1) * HT : 0;
-                if (st + 1 < STEPS) read_b(st + 1, b[(st + 1) & 1]);
+                const int q = st / NB, T0 = (st % NB) * TBS;
+                if (st + 1 < STEPS) read_a(st + 1, ma[(st + 1) & 1]);
                 __builtin_amdgcn_sched_barrier(0);
-                float4(&bc)[HT] = b[st & 1];
-                const float4 av = a[q];
-#pragma unroll
-                for (int t = 0; t < HT; t++) if (t0 + t < NT) acc[t0 + t] = __builtin_amdgcn_mfma_f32_32x32x2f32(bc[t].x, av.x, acc[t0 + t], 0, 0, 0);
-#pragma unroll
-                for (int t = 0; t < HT; t++) if (t0 + t < NT) acc[t0 + t] = __builtin_amdgcn_mfma_f32_32x32x2f32(bc[t].y, av.y, acc[t0 + t], 0, 0, 0);
-#pragma unroll
-                for (int t = 0; t < HT; t++) if (t0 + t < NT) acc[t0 + t] = __builtin_amdgcn_mfma_f32_32x32x2f32(bc[t].z, av.z, acc[t0 + t], 0, 0, 0);
-#pragma unroll
-                for (int t = 0; t < HT; t++) if (t0 + t < NT) acc[t0 + t] = __builtin_amdgcn_mfma_f32_32x32x2f32(bc[t].w, av.w, acc[t0 + t], 0, 0, 0);
+                float4(&mc)[TBS] = ma[st & 1];
+                const float4 x0 = xb[0][q], x1 = xb[1][q];
+#define PHL_MF16(comp)                                                                                                   \
+    _Pragma("unroll") for (int j = 0; j < TBS; j++) if (T0 + j < NL) {                                                  \
+        acc[0][T0 + j] = __builtin_amdgcn_mfma_f32_16x16x4f32(mc[j].comp, x0.comp, acc[0][T0 + j], 0, 0, 0);            \
+        acc[1][T0 + j] = __builtin_amdgcn_mfma_f32_16x16x4f32(mc[j].comp, x1.comp, acc[1][T0 + j], 0, 0, 0);            \
+    }
+                PHL_MF16(x) PHL_MF16(y) PHL_MF16(z) PHL_MF16(w)
+#undef PHL_MF16
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -559,9 +564,9 @@ __global__ __launch_bounds__(512) void k_compat_softmax(const float *__restrict_
         {
 #ifdef __HIP_DEVICE_COMPILE__                    /* (see the last epilogue slot: no wait is generated here, but without this
                                                     use the compiler guards single accumulator registers in the epilogue) */
-            asm volatile("" ::"v"(acc[NT - 1]));
+            asm volatile("" ::"v"(acc[1][NL - 1]));
 #endif
-            pad_e0(acc[NT - 1]);
+            pad_e0();
             for (int kc = 0; kc < NT; kc++) chunk(kc);
         }
         CS_STAMP(2 * it + 1);
@@ -583,7 +588,7 @@ __global__ __launch_bounds__(512) void k_compat_softmax(const float *__restrict_
                     // compiler waits for it HERE (a use of the accumulator loaded last), before this slot's DMAs
                     // are in flight, instead of draining them at the first MFMA
 #ifdef __HIP_DEVICE_COMPILE__                    /* (the host pass has no "v" registers) */
-                    asm volatile("" ::"v"(acc[NT - 1]));
+                    asm volatile("" ::"v"(acc[1][NL - 1]));
 #endif
                 }
                 // not at once: right behind the barrier the other group issues the LDS reads its first MFMAs wait for,
@@ -597,11 +602,11 @@ __global__ __launch_bounds__(512) void k_compat_softmax(const float *__restrict_
 #pragma unroll
                 for (int u = 0; u < U; u++) {    // (constant trip count: unrolls, and the test folds)
                     if (u < u_lo || u >= u_hi) continue;
-                    const int t = u >> 2, g = u & 3;
-                    if (valid && (!PAD || t < NT - 1 || 32 * t + 8 * g + h4 < Lr))
-                        *reinterpret_cast<float4 *>(reinterpret_cast<char *>(orows + 32 * t + 8 * g) + lo_o) =
-                            make_float4(acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3]);
-                    if (has_next) PHL_E0_LOAD_UNIT(t, g, erows);
+                    const int pg = u / NL, T = u % NL;
+                    if (valid && (!PAD || T < NL - 2 || 16 * T + 4 * g4 < Lr))
+                        *reinterpret_cast<float4 *>(reinterpret_cast<char *>(orows + pg * 16 * o_rs + 16 * T) + lo_o) =
+                            make_float4(acc[pg][T][0], acc[pg][T][1], acc[pg][T][2], acc[pg][T][3]);
+                    if (has_next) PHL_E0_LOAD_UNIT(pg, T, erows);
                 }
                 // What slot S+1 reads was requested in slot S-1 and must have landed.  vmcnt counts in issue order, so
                 // everything younger may stay in flight: the units of slot S-1 (issued behind its DMAs), this slot's
@@ -610,7 +615,7 @@ __global__ __launch_bounds__(512) void k_compat_softmax(const float *__restrict_
                 // (counted: loads always issue; under PAD a store of the last label tile may have no lane left and be
                 // skipped, so those are not counted -- allowing fewer in flight only waits longer)
                 constexpr int p_lo = s >= 1 && s - 1 < D ? (U * (s - 1) + D - 1) / D : U, p_hi = s >= 1 && s < D ? (U * s + D - 1) / D : U;
-                constexpr int FIRM = PAD ? 4 * (NT - 1) : U;             // units below this index always store
+                constexpr int FIRM = PAD ? 0 : U;                        // (PAD: stores of the last two label tiles of either pixel group may be skipped; count none)
                 constexpr int LOADS = (u_hi > u_lo ? u_hi - u_lo : 0) + (p_hi > p_lo ? p_hi - p_lo : 0);
                 constexpr int STORES = ((u_hi < FIRM ? u_hi : FIRM) > u_lo ? (u_hi < FIRM ? u_hi : FIRM) - u_lo : 0) +
                                        ((p_hi < FIRM ? p_hi : FIRM) > p_lo ? (p_hi < FIRM ? p_hi : FIRM) - p_lo : 0);
@@ -633,6 +638,7 @@ __global__ __launch_bounds__(512) void k_compat_softmax(const float *__restrict_
 }
 #undef PHL_E0_LOAD_UNIT
 #undef PHL_WAIT_BUT
+#undef PHL_ROW_SWAP
 
 // The last n % 128 pixels of phl_compat_softmax (the tile kernel takes whole tiles only): one workgroup per pixel,
 // thread c owns label c -- an fmaf chain over k straight from the transposed compatibility matrix, then the row
