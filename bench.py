@@ -578,11 +578,11 @@ def mean_field_iteration(torch, phl, lat, Q, L, device):
     E0 = torch.rand(Q.shape, generator=g, device=device) * 10.0
     Qn = torch.empty_like(Q)
     W = lambda U: lat.filter(U, subtract_input=True)
-    for _ in range(2):
+    for _ in range(6):                  # steady clocks (tools/compat_seq.py: ~25 ms of back-to-back work from idle)
         mean_field_step(E0, W, Mu, Q, out=Qn)
     ev = lambda: torch.cuda.Event(enable_timing=True)
     e0, e1 = ev(), ev()
-    reps = 5
+    reps = 10
     e0.record()
     for _ in range(reps):
         mean_field_step(E0, W, Mu, Q, out=Qn)
