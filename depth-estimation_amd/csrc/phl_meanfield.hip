@@ -222,7 +222,7 @@ __global__ __launch_bounds__(256) void k_stream_copy(const vf4 *__restrict__ src
 //  * a wave can have only 63 vector-memory operations in flight; with a dword per lane (the untransposed C/D map)
 //    that cap, at ~5 us loaded latency, paced the epilogue.  Hence 16-byte accesses.
 //  * LDS-DMA pieces issued right behind the barrier delay the LDS reads the other group's first MFMAs wait for
-//    (0.8 us per slot): the feeder sleeps 256 cycles first.
+//    (0.8 us per slot when the GPU is not at full clocks): the feeder sleeps 256 cycles first.
 //
 //  * what the CU's memory pipe charges for is cache lines per instruction: on 32x32x2 tiles a 16-byte access of the
 //    transposed map touches 32 lines (32 pixels x 32 bytes), on 16x16x4 tiles 16 (16 pixels x 64 bytes) -- same
@@ -592,7 +592,8 @@ __global__ __launch_bounds__(512) void k_compat_softmax(const float *__restrict_
 #endif
                 }
                 // not at once: right behind the barrier the other group issues the LDS reads its first MFMAs wait for,
-                // and a burst of DMA pieces ahead of them in the queue cost it 0.8 us per slot (measured)
+                // and a burst of DMA pieces ahead of them in the queue cost it 0.8 us per slot on a GPU that was
+                // not at full clocks (at full clocks the delay neither helps nor hurts: 3.67 ms with 0, 128 or 512 cycles)
                 __builtin_amdgcn_s_sleep(4);
                 const bool xp = feed(slot, slot3);
                 // this slot's share of the 4 NT units: store Q, and the freed registers take the next tile's E0 at
