@@ -90,19 +90,53 @@ def box_blur(a, r):
     return a
 
 
-def synthetic_features(H, W, sigma_xy=SIGMA_XY, sigma_c=SIGMA_C):
+def synthetic_features(H, W, sigma_xy=SIGMA_XY, sigma_c=SIGMA_C, iid=False):
     """x=col/sigma_xy, y=row/sigma_xy (pixels), 3 channels of N(0,1) noise
-    box-blurred r=16 twice, rescaled to [0,1], / sigma_c.  Returns [H, W, 5] fp32."""
+    box-blurred r=16 twice, rescaled to [0,1], / sigma_c.  Returns [H, W, 5] fp32.
+    iid=True: the 8(d) stress case, colours iid U[0,1] (every pixel in its own simplex, M/n -> d+1)."""
     rng = np.random.default_rng(1234)
-    col = rng.standard_normal((H, W, 3)).astype(np.float32)
-    col = box_blur(box_blur(col, 16), 16)
-    col -= col.min(axis=(0, 1), keepdims=True)
-    col /= col.max(axis=(0, 1), keepdims=True)
+    if iid:
+        col = rng.random((H, W, 3), dtype=np.float32)
+    else:
+        col = rng.standard_normal((H, W, 3)).astype(np.float32)
+        col = box_blur(box_blur(col, 16), 16)
+        col -= col.min(axis=(0, 1), keepdims=True)
+        col /= col.max(axis=(0, 1), keepdims=True)
     feat = np.empty((H, W, 5), np.float32)
     feat[..., 0] = (np.arange(W, dtype=np.float32) / sigma_xy)[None, :]
     feat[..., 1] = (np.arange(H, dtype=np.float32) / sigma_xy)[:, None]
     feat[..., 2:] = col / sigma_c
     return feat
+
+
+def tsukuba_features(H, W, sigma_c, sigma_p):
+    """Natural-image features in the reference notebook's own scaling (Experiments/DenseCrf.ipynb:142-146,
+    crf/lattice/lite/test_bilateral.ipynb cell 6): (rgb / sigma_c, ij / sqrt(h^2 + w^2) / sigma_p), the image being
+    the 384x288 Tsukuba frame stored as DATA in tests/golden/growth_tsukuba_384x288_vd4.npz (`img_u8`), bicubically
+    upsampled to H x W (the Middlebury-sized stand-in; the datasets themselves are absent).
+    Returns [H, W, 5] fp32 in the notebook's order (r, g, b, i, j)."""
+    import torch
+    import torch.nn.functional as F
+
+    z = np.load(os.path.join(ROOT, "tests", "golden", "growth_tsukuba_384x288_vd4.npz"))
+    img = torch.from_numpy(z["img_u8"].astype(np.float32) / 255.0).permute(2, 0, 1)[None]
+    if tuple(img.shape[2:]) != (H, W):
+        img = F.interpolate(img, size=(H, W), mode="bicubic", align_corners=False).clamp_(0, 1)
+    feat = np.empty((H, W, 5), np.float32)
+    feat[..., :3] = img[0].permute(1, 2, 0).numpy() / sigma_c
+    diag = float(np.sqrt(H * H + W * W))
+    feat[..., 3] = (np.arange(H, dtype=np.float32) / diag / sigma_p)[:, None]
+    feat[..., 4] = (np.arange(W, dtype=np.float32) / diag / sigma_p)[None, :]
+    return feat
+
+
+def features_for(H, W, sigma_xy=SIGMA_XY, sigma_c=SIGMA_C, iid=False, tsukuba=None):
+    """One place that turns the bench's feature options into [H, W, 5] features and a short label."""
+    if tsukuba is not None:
+        sc, sp = tsukuba
+        return tsukuba_features(H, W, sc, sp), f"tsukuba-upsampled sigma_c={sc} sigma_p={sp}"
+    return (synthetic_features(H, W, sigma_xy, sigma_c, iid),
+            f"synthetic {'iid' if iid else 'smooth'} colours sigma_xy={sigma_xy} sigma_c={sigma_c}")
 
 
 def synthetic_values(torch, rows, W, L, row0, device):
@@ -117,6 +151,28 @@ def synthetic_values(torch, rows, W, L, row0, device):
         u = torch.rand((k * W, L), generator=g, device=device) * 10.0
         out[r * W:(r + k) * W] = torch.softmax(-u, dim=1)
     return out
+
+
+def stage_times(torch, lat, src, out, kw, reps):
+    """HIP-event times (ms) of the three stages on the launch stream, averaged over `reps` passes."""
+    ev = lambda: torch.cuda.Event(enable_timing=True)
+    acc = {"splat": 0.0, "blur": 0.0, "slice": 0.0}
+    scratch = None
+    for _ in range(reps):
+        e = [ev() for _ in range(4)]
+        e[0].record()
+        v = lat.splat(src, **kw)
+        e[1].record()
+        scratch = torch.empty_like(v) if scratch is None else scratch
+        a = lat.blur(v, scratch)                 # all d+1 axes, two per launch
+        e[2].record()
+        lat.slice(a, out=out, **kw)
+        e[3].record()
+        torch.cuda.synchronize()
+        for k, name in enumerate(("splat", "blur", "slice")):
+            acc[name] += e[k].elapsed_time(e[k + 1])
+        del v, a
+    return {k: v / reps for k, v in acc.items()}
 
 
 def algorithmic_bytes(n, M, L, d):
@@ -332,6 +388,12 @@ def main():
     # (tools/step_seq.py: from an idle GPU the clocks take ~8 steps to come up; 3 warm-up steps left 1 % on the table)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
+    ap.add_argument("--sigma-xy", type=float, default=SIGMA_XY, help="pixels per feature unit in x, y (SURVEY 8d: 8, 3, 30)")
+    ap.add_argument("--sigma-c", type=float, default=SIGMA_C, help="colour scale of the synthetic features")
+    ap.add_argument("--iid", action="store_true", help="SURVEY 8d stress case: iid U[0,1] colours (M/n -> d+1)")
+    ap.add_argument("--tsukuba", default=None, metavar="SC,SP",
+                    help="natural-image features: the stored Tsukuba frame upsampled to the workload size, "
+                         "(rgb/SC, ij/diag/SP) as in DenseCrf.ipynb:142-146 (e.g. 0.1,0.1  0.08,0.03  0.125,0.01)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-tiles", action="store_true", help="plain gather kernels (A/B against the LDS-staged chunk path)")
     ap.add_argument("--exact", action="store_true", help="reference-exact arithmetic (bit-identical to the CPU path)")
@@ -390,7 +452,8 @@ def main():
 
     H, W, L, desc = WORKLOADS[args.workload]
     d = 5
-    feat = synthetic_features(H, W)
+    tsu = tuple(float(x) for x in args.tsukuba.split(",")) if args.tsukuba else None
+    feat, feat_desc = features_for(H, W, args.sigma_xy, args.sigma_c, args.iid, tsu)
     n_total = H * W
 
     rowtiled = world > 1 or args.force_rowtile
@@ -470,24 +533,7 @@ def main():
         extra["tiles"] = lat.tile_stats(L)
     if rank == 0:
         ev = lambda: torch.cuda.Event(enable_timing=True)
-        reps = max(3, min(args.steps, 10))
-        acc = {"splat": 0.0, "blur": 0.0, "slice": 0.0}
-        scratch = None
-        for _ in range(reps):
-            e = [ev() for _ in range(4)]
-            e[0].record()
-            v = lat.splat(src, **kw)
-            e[1].record()
-            scratch = torch.empty_like(v) if scratch is None else scratch
-            a = lat.blur(v, scratch)                 # all d+1 axes, two per launch
-            e[2].record()
-            lat.slice(a, out=out, **kw)
-            e[3].record()
-            torch.cuda.synchronize()
-            for k, name in enumerate(("splat", "blur", "slice")):
-                acc[name] += e[k].elapsed_time(e[k + 1])
-            del v, a
-        stage_ms = {k: v / reps for k, v in acc.items()}
+        stage_ms = stage_times(torch, lat, src, out, kw, max(3, min(args.steps, 10)))
         blur_launches = (d + 2) // 2
         dom = max(stage_ms, key=stage_ms.get)
         ab = algorithmic_bytes(n_local, M, L, d)
@@ -542,8 +588,8 @@ def main():
             "value": round(value, 1), "unit": "Mpixel-labels/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": "strong" if (world > 1 and rowtiled) else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{args.workload}: {desc}", "H": H, "W": W, "L": L, "d": d, "sigma_xy": SIGMA_XY,
-                       "sigma_c": SIGMA_C, "n": n_total, "M": int(M), "M_over_n": round(M / n_local, 4),
+            "config": {"workload": f"{args.workload}: {desc}", "H": H, "W": W, "L": L, "d": d, "features": feat_desc,
+                       "sigma_xy": None if tsu else args.sigma_xy, "sigma_c": tsu[0] if tsu else args.sigma_c, "n": n_total, "M": int(M), "M_over_n": round(M / n_local, 4),
                        "parallelism": ("single GPU" if world == 1 and not rowtiled else
                                        f"row bands x{world} + RCCL boundary-vertex exchange" if rowtiled else
                                        f"{world} independent volumes, one per GPU, no collective"),

@@ -62,6 +62,10 @@ struct phl_lattice {
     int32_t *vs_ptr;        // [M+1] slots of each vertex ...
     phl_contrib_t *vs;      // [S]   ... ascending (slot index in .pixel)
     int32_t *vorder;        // [M] vertices in chunk-major order (gather splat locality); may be null
+    int32_t *chunk_by_nv;   // [nchunks] chunk ids by descending local-vertex count (heavy class = a prefix)
+    int *nv_cum;            // HOST [nv_max+1]: number of chunks with at most x local vertices
+    int32_t *vlong;         // [n_long] vertices fed by more than LONG_LIST chunks (k_splat_reduce_long)
+    int64_t n_long;
     int64_t tile_bytes;
 
     // value workspaces (phl_api.hip): a filter call takes one for the duration of its launches, so any number

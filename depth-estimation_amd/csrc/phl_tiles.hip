@@ -406,6 +406,15 @@ __device__ __forceinline__ float4 sum8(float4 acc, const uint2 e, const char *rb
 // Each of a wavefront's 64/LPRS lane groups owns one local vertex and sums its pixel-sorted
 // segment sequentially out of LDS: a segmented reduction with one segment per lane group,
 // deterministic, no atomics (details at the loop).
+// splat: segments of at least this many entries are summed by a whole wavefront (see k_splat_tiled).  Two workgroups
+// share a CU, so imbalance inside one is mostly absorbed by the other and what counts is total work: the
+// cooperative form pads a segment to a multiple of 64 entries and pays a cross-row combine, so it is reserved for
+// segments that would otherwise be the whole critical path (flat image regions: all 256 pixels in one vertex).
+inline int long_seg()
+{
+    static const int v = getenv("PHL_LONG_SEG") ? atoi(getenv("PHL_LONG_SEG")) : 128;
+    return v < 16 ? 16 : v;
+}
 constexpr int TPB = 512;     // slice workgroup
 constexpr int TPB_S = 512;   // splat workgroup (1024 threads and 1 workgroup per CU measured no better)
 
@@ -416,7 +425,8 @@ __global__ __launch_bounds__(TPB_S) void k_splat_tiled(const float *__restrict__
                                                      const int *__restrict__ slot_pidx, const int2 *__restrict__ seg_rng,
                                                      const phl_contrib_t *__restrict__ seg, float *__restrict__ vert,
                                                      float *__restrict__ partial, int nchunks, int xcd_chunk,
-                                                     unsigned long long *__restrict__ tl, const int *__restrict__ chunk_list)
+                                                     unsigned long long *__restrict__ tl, const int *__restrict__ chunk_list,
+                                                     int nv_lo, int nv_hi, int long_seg)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int SL = LPRS * 4;
@@ -443,11 +453,14 @@ __global__ __launch_bounds__(TPB_S) void k_splat_tiled(const float *__restrict__
     const int E = cnt * dp1;
     const int64_t ebase = (int64_t)base * dp1;
     const int vbase = vptr[c], nv = vptr[c + 1] - vbase;
+    // chunk classes (phl_launch_splat_tiled): this launch's LDS is sized for chunks with nv_lo < nv <= nv_hi local
+    // vertices; the others belong to the launch of another class
+    if (nv <= nv_lo || nv > nv_hi) return;
     float *rows = lds;                                             // [P][SL] staged pixel rows + one row of zeros
     uint2 *ent = reinterpret_cast<uint2 *>(lds + (size_t)(P + 1) * SL);
     int4 *meta = reinterpret_cast<int4 *>(ent + P * dp1);          // [nv_cap] {seg begin, seg end, slot_vert, slot_pidx}
     int *pixl = reinterpret_cast<int *>(meta + nv_cap);           // [P]
-    int *ctr = pixl + P;                                           // two work counters, used by alternate slabs
+    int *ctr = pixl + P;                                           // two work counters, used by alternate slabs; [2] = #long segments
     // Loads are issued UNCONDITIONALLY from clamped (always valid) addresses and only the LDS
     // stores are predicated: a load under a divergent `if` makes hipcc wait vmcnt(0) per load.
     const int kclamp = cnt - 1;
@@ -464,9 +477,21 @@ __global__ __launch_bounds__(TPB_S) void k_splat_tiled(const float *__restrict__
         ent[e] = make_uint2((unsigned)(s.pixel * SL * 4), __float_as_uint(s.w));
     }
     for (int k = threadIdx.x; k < cnt; k += TPB_S) pixl[k] = pix_order[base + k];
-    for (int i = threadIdx.x; i < nv; i += TPB_S)
-        meta[i] = make_int4((int)(seg_rng[vbase + i].x - ebase), (int)(seg_rng[vbase + i].y - ebase), slot_vert[vbase + i],
-                            slot_pidx[vbase + i]);
+    for (int i = threadIdx.x; i < nv; i += TPB_S) {
+        const int2 rg = seg_rng[vbase + i];
+        meta[i] = make_int4((int)(rg.x - ebase), (int)(rg.y - ebase), slot_vert[vbase + i], slot_pidx[vbase + i]);
+        // Local vertices come in descending segment length (k_chunk_sort), so the LONG ones (>= long_seg entries:
+        // summed by a whole wavefront, below) are a prefix; its length is written by exactly one thread.
+        const bool lng = rg.y - rg.x >= long_seg;
+        if (i + 1 < nv) {
+            const int2 rn = seg_rng[vbase + i + 1];
+            if (lng && rn.y - rn.x < long_seg) ctr[2] = i + 1;
+        } else if (lng) {
+            ctr[2] = nv;
+        }
+        if (i == 0 && !lng) ctr[2] = 0;
+    }
+    if (nv == 0 && threadIdx.x == 0) ctr[2] = 0;
     if (threadIdx.x < 2) ctr[threadIdx.x] = NW;
     if (threadIdx.x < LPRS) st4(rows + (size_t)P * SL + threadIdx.x * 4, make_float4(0.f, 0.f, 0.f, 0.f));
     {
@@ -509,13 +534,20 @@ __global__ __launch_bounds__(TPB_S) void k_splat_tiled(const float *__restrict__
         // groups longest-first from a shared counter: no cross-lane combine, no padding, and the
         // per-vertex bookkeeping is paid once per Q vertices.
         int *slab_ctr = ctr + (slab & 1);
-        const int ngroups = (nv + Q - 1) / Q;
-        for (int gi = wave; gi < ngroups;) {
-            const int i = gi * Q + q;
+        // Work items, handed out longest-first: items [0, nlong) are single LONG vertices (LPRS >= 16 only), summed
+        // by all Q lane groups of the wave together -- group q takes the 16-entry batches q, q+Q, ... of the
+        // segment and the Q partial sums are combined across the DPP rows in a fixed order -- so that one 256-entry
+        // segment (a flat image region: every pixel of the chunk in one vertex) costs a wave 4 batches, not 16;
+        // the remaining items are groups of Q vertices, one per lane group.
+        const int nlong = (LPRS >= 16 && Q > 1) ? ctr[2] : 0;
+        const int nitems = nlong + (nv - nlong + Q - 1) / Q;
+        for (int gi = wave; gi < nitems;) {
+            const bool coop = gi < nlong;                       // wave-uniform
+            const int i = coop ? gi : nlong + (gi - nlong) * Q + q;
             int4 m = make_int4(0, 0, 0, 0);
             if (i < nv) m = meta[i];
             int nxt = 0;
-            if (lane == 0) nxt = atomicAdd(slab_ctr, 1);       // next group, fetched under this one's work
+            if (lane == 0) nxt = atomicAdd(slab_ctr, 1);       // next item, fetched under this one's work
             const int s1 = m.y;
             float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
             int s = m.x;
@@ -532,15 +564,26 @@ __global__ __launch_bounds__(TPB_S) void k_splat_tiled(const float *__restrict__
                 const int r16 = lane & 15;
                 const unsigned zoff = (unsigned)P * SL * 4;
                 const int elast = E - 1;
-                uint2 e = ent[min(s + r16, elast)];
+                // cooperative item: group q starts at batch q and strides over Q batches
+                const int step = coop ? 16 * Q : 16;
+                if (coop) s += 16 * q;
+                uint2 e = ent[min(max(s + r16, 0), elast)];
                 if (s + r16 >= s1) e = make_uint2(zoff, 0u);
-                for (int b = 0; b < lmax; b += 16) {
-                    const int nx = s + b + 16 + r16;
+                for (int b = 0; b < lmax; b += step) {
+                    const int nx = s + b + step + r16;
                     uint2 en = ent[min(nx, elast)];              // next sixteen, under this batch's work
                     if (nx >= s1) en = make_uint2(zoff, 0u);
                     acc = sum8<0>(acc, e, rbase);
                     if (b + 8 < lmax) acc = sum8<8>(acc, e, rbase);
                     e = en;
+                }
+                if (Q > 1 && coop) {
+                    // ((g0 + g1) + (g2 + g3)): every lane adds its partner's value, so all groups end with the same bits
+                    acc = make_float4(acc.x + __shfl_xor(acc.x, LPRS), acc.y + __shfl_xor(acc.y, LPRS),
+                                      acc.z + __shfl_xor(acc.z, LPRS), acc.w + __shfl_xor(acc.w, LPRS));
+                    if (Q > 2)
+                        acc = make_float4(acc.x + __shfl_xor(acc.x, 2 * LPRS), acc.y + __shfl_xor(acc.y, 2 * LPRS),
+                                          acc.z + __shfl_xor(acc.z, 2 * LPRS), acc.w + __shfl_xor(acc.w, 2 * LPRS));
                 }
             } else {
             // software pipeline: the index reads of batch b+1 are issued before the row reads of
@@ -575,7 +618,7 @@ __global__ __launch_bounds__(TPB_S) void k_splat_tiled(const float *__restrict__
                 acc = fma4(acc, __uint_as_float(e0.y), *reinterpret_cast<const float4 *>(rbase + e0.x));
             }
             }
-            if (i < nv && chok) {
+            if (i < nv && chok && !(coop && q != 0)) {
                 float *dst = m.z < 0 ? vert + (int64_t)(m.z & 0x7FFFFFFF) * vd : partial + (int64_t)m.w * vd;
                 st4(dst + ch, acc);
             }
@@ -600,12 +643,14 @@ __global__ __launch_bounds__(TPB_S) void k_splat_tiled(const float *__restrict__
 }
 
 // vertices with != 1 contributing chunk: sum their partial rows in ascending chunk order
-// (0 chunks = ghost vertex of a neighbouring row band: zeros).
+// (0 chunks = ghost vertex of a neighbouring row band: zeros).  One lane group per vertex, independent waves.
+// Vertices with more than `long_list` rows are left to k_splat_reduce_long.
+constexpr int LONG_LIST = 24;
 template <int LPR>
 __global__ __launch_bounds__(256) void k_splat_reduce(const float *__restrict__ partial, const int *__restrict__ vs_ptr,
                                                       const phl_contrib_t *__restrict__ vs,
                                                       const int *__restrict__ slot_pidx, int M, int vd,
-                                                      float *__restrict__ vert, const int *__restrict__ vlist)
+                                                      float *__restrict__ vert, const int *__restrict__ vlist, int long_list)
 {
     // vlist (optional): only these M vertex rows (phl_splat_part)
     constexpr int Gw = 64 / LPR;
@@ -613,26 +658,67 @@ __global__ __launch_bounds__(256) void k_splat_reduce(const float *__restrict__ 
     const int sub = lane / LPR, l = lane % LPR;
     const int wave = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
     const int64_t stride = (int64_t)gridDim.x * 4 * Gw;
+    auto add4 = [](float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); };
     for (int64_t v0 = (int64_t)wave * Gw; v0 < M; v0 += stride) {
         if (v0 + sub >= M) continue;
         const int64_t v = vlist ? vlist[v0 + sub] : v0 + sub;
         const int beg = vs_ptr[v], end = vs_ptr[v + 1];
-        if (end - beg == 1) continue;
+        if (end - beg == 1 || end - beg > long_list) continue;
         for (int ch = l * 4; ch < vd; ch += LPR * 4) {
             float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
             int e = beg;
-            for (; e + 2 <= end; e += 2) {
+            for (; e + 4 <= end; e += 4) {
                 const float4 q0 = ld4(partial + (int64_t)slot_pidx[vs[e].pixel] * vd + ch);
                 const float4 q1 = ld4(partial + (int64_t)slot_pidx[vs[e + 1].pixel] * vd + ch);
-                acc = make_float4(acc.x + q0.x, acc.y + q0.y, acc.z + q0.z, acc.w + q0.w);
-                acc = make_float4(acc.x + q1.x, acc.y + q1.y, acc.z + q1.z, acc.w + q1.w);
+                const float4 q2 = ld4(partial + (int64_t)slot_pidx[vs[e + 2].pixel] * vd + ch);
+                const float4 q3 = ld4(partial + (int64_t)slot_pidx[vs[e + 3].pixel] * vd + ch);
+                acc = add4(add4(add4(add4(acc, q0), q1), q2), q3);
             }
-            if (e < end) {
-                const float4 q0 = ld4(partial + (int64_t)slot_pidx[vs[e].pixel] * vd + ch);
-                acc = make_float4(acc.x + q0.x, acc.y + q0.y, acc.z + q0.z, acc.w + q0.w);
-            }
+            for (; e < end; e++) acc = add4(acc, ld4(partial + (int64_t)slot_pidx[vs[e].pixel] * vd + ch));
             st4(vert + v * vd + ch, acc);
         }
+    }
+}
+
+// A vertex fed by MANY chunks (a flat image region spans hundreds of 16x16 tiles: natural images at M/n ~ 0.01
+// have vertices with 100-600 partial rows, which one wave would add up one dependent load after the other) is
+// summed by a whole workgroup: lane group j of the 256/LPR groups adds rows j, j+NG, ... (four loads in flight
+// each) and the NG sums are added in ascending j -- a fixed order, so the result does not depend on scheduling.
+// One workgroup per entry of `list` (the lattice's long vertices, or the caller's rows: then short ones exit).
+template <int LPR>
+__global__ __launch_bounds__(256) void k_splat_reduce_long(const float *__restrict__ partial, const int *__restrict__ vs_ptr,
+                                                           const phl_contrib_t *__restrict__ vs,
+                                                           const int *__restrict__ slot_pidx, int vd,
+                                                           float *__restrict__ vert, const int *__restrict__ list, int long_list)
+{
+    constexpr int NG = 256 / LPR;
+    __shared__ float4 red[256];
+    const int l = (int)threadIdx.x % LPR, jg = (int)threadIdx.x / LPR;
+    const int64_t v = list[blockIdx.x];
+    const int b0 = vs_ptr[v], b1 = vs_ptr[v + 1];
+    if (b1 - b0 <= long_list) return;                       // workgroup-uniform
+    auto add4 = [](float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); };
+    for (int c0 = 0; c0 < vd; c0 += LPR * 4) {              // uniform trip count: there are barriers inside
+        const bool chok = c0 + l * 4 < vd;
+        const int ch = chok ? c0 + l * 4 : 0;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        int e = b0 + jg;
+        for (; e + 3 * NG < b1; e += 4 * NG) {
+            const float4 q0 = ld4(partial + (int64_t)slot_pidx[vs[e].pixel] * vd + ch);
+            const float4 q1 = ld4(partial + (int64_t)slot_pidx[vs[e + NG].pixel] * vd + ch);
+            const float4 q2 = ld4(partial + (int64_t)slot_pidx[vs[e + 2 * NG].pixel] * vd + ch);
+            const float4 q3 = ld4(partial + (int64_t)slot_pidx[vs[e + 3 * NG].pixel] * vd + ch);
+            acc = add4(add4(add4(add4(acc, q0), q1), q2), q3);
+        }
+        for (; e < b1; e += NG) acc = add4(acc, ld4(partial + (int64_t)slot_pidx[vs[e].pixel] * vd + ch));
+        red[threadIdx.x] = acc;
+        __syncthreads();
+        if (jg == 0 && chok) {
+            float4 t = red[l];
+            for (int k = 1; k < NG; k++) t = add4(t, red[k * LPR + l]);
+            st4(vert + v * vd + ch, t);
+        }
+        __syncthreads();
     }
 }
 
@@ -643,20 +729,23 @@ __global__ __launch_bounds__(TPB) void k_slice_tiled(const float *__restrict__ v
                                                      const unsigned short *__restrict__ lidx,
                                                      const phl_replay_t *__restrict__ replay, float *__restrict__ out,
                                                      int64_t out_rs, const float *__restrict__ sub_src, int64_t sub_rs,
-                                                     float cdiv, float rcdiv, int nchunks, int xcd_chunk)
+                                                     float cdiv, float rcdiv, int nchunks, int xcd_chunk,
+                                                     const int *__restrict__ chunk_list, int nv_lo, int nv_hi)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int SL = LPRS * 4;
     constexpr int G = TPB / LPRS;
     const int g = threadIdx.x / LPRS, l = threadIdx.x % LPRS;
     // XCD-aware chunk order (see k_blur): neighbouring chunks share boundary vertices
-    const int c = xcd_chunk > 0 ? (int)(blockIdx.x & 7) * xcd_chunk + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
-    if (c >= nchunks) return;
+    const int ci = xcd_chunk > 0 ? (int)(blockIdx.x & 7) * xcd_chunk + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    if (ci >= nchunks) return;
+    const int c = chunk_list ? chunk_list[ci] : ci;
     const int base = c * P;
     const int cnt = min(P, n - base);
     const int E = cnt * dp1;
     const int64_t ebase = (int64_t)base * dp1;
     const int vbase = vptr[c], nv = vptr[c + 1] - vbase;
+    if (nv <= nv_lo || nv > nv_hi) return;     // chunk classes: see phl_launch_slice_tiled
     float *rows = lds;
     uint2 *ent = reinterpret_cast<uint2 *>(lds + (size_t)rows_cap * SL);
     int *pixl = reinterpret_cast<int *>(ent + P * dp1);
@@ -725,6 +814,19 @@ __global__ __launch_bounds__(TPB) void k_slice_tiled(const float *__restrict__ v
     }
 }
 
+__global__ __launch_bounds__(256) void k_flag_long(const int *__restrict__ vs_ptr, int M, int long_list, int *__restrict__ flag)
+{
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v < M) flag[v] = (vs_ptr[v + 1] - vs_ptr[v] > long_list) ? 1 : 0;
+}
+
+__global__ __launch_bounds__(256) void k_compact_flagged(const int *__restrict__ flag, const int *__restrict__ rank, int M,
+                                                         int *__restrict__ out)
+{
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v < M && flag[v]) out[rank[v]] = v;
+}
+
 // vertex processing order for the gather splat: vertices sorted by the first chunk that touches
 // them, so that vertices summed at the same time read the same few chunks' pixel rows (L2 hits
 // instead of Infinity-Cache traffic).  first[s] = 1 iff slot s is the first slot of its vertex.
@@ -780,15 +882,95 @@ inline int64_t lds_extra(int P, int dp1, int nv_max) { return (int64_t)P * dp1 *
 // k_slice_tiled keeps less: entries, pixel ids, one vertex id per local vertex
 inline int64_t lds_extra_slice(int P, int dp1, int nv_max) { return (int64_t)P * dp1 * 8 + (int64_t)P * 4 + ((int64_t)nv_max + 4) * 4; }
 
-// lanes (of 4 floats) per slab row: as wide as vd, narrowed until `rows` rows + index data fit
-// in LDS; -1 if even the narrowest slab does not fit
-inline int pick_lprs(int vd, int rows, int64_t extra)
+// Launch configuration of a chunk kernel: lanes (of 4 floats) per slab row and LDS bytes per workgroup.
+// Candidates in order of preference: every slab width, widest first, at two workgroups per CU (80 KiB); only then
+// the same widths at one workgroup per CU.  Measured on C3: the splat with 128-channel slabs and one workgroup per
+// CU takes 0.96 ms against 0.78 with 64-channel slabs and two; at M/n = 0.5 64 channels / one workgroup 2.0 ms
+// against 1.47 with 32 channels / two -- a second workgroup hides the staging round trips of the first.
+struct tile_cfg {
+    int lprs = -1;
+    size_t lds = 0;
+    int cap = 0;        // most local vertices a chunk may have under this configuration
+};
+inline int64_t lds_big() { return lds_budget() > 160 * 1024 ? lds_budget() : 160 * 1024; }
+
+// k-th candidate for `vd` channels (k = 0 is the preferred one); returns false past the last
+inline bool cfg_candidate(int vd, bool for_slice, int k, int *lprs, int64_t *budget)
 {
     const int need = (vd + 3) / 4;
-    int lprs = 4;
-    while (lprs < 64 && lprs < need) lprs <<= 1;
-    while (lprs > 4 && (int64_t)rows * lprs * 16 + extra > lds_budget()) lprs >>= 1;
-    return (int64_t)rows * lprs * 16 + extra > lds_budget() ? -1 : lprs;
+    int w = 4;
+    while (w < 64 && w < need) w <<= 1;
+    static const int max_w[2] = {getenv("PHL_MAX_LPRS_SPLAT") ? atoi(getenv("PHL_MAX_LPRS_SPLAT")) : 64,
+                                 getenv("PHL_MAX_LPRS_SLICE") ? atoi(getenv("PHL_MAX_LPRS_SLICE")) : 64};   // experiments
+    while (w > 4 && w > max_w[for_slice ? 1 : 0]) w >>= 1;
+    int nw = 0;
+    for (int x = w; x >= 4; x >>= 1) nw++;
+    if (k >= 2 * nw) return false;
+    *lprs = w >> (k % nw);
+    *budget = k / nw ? lds_big() : lds_budget();
+    return true;
+}
+
+inline int64_t splat_lds(int P, int dp1, int lprs, int nv) { return (int64_t)(P + 1) * lprs * 16 + lds_extra(P, dp1, nv); }
+inline int64_t slice_lds(int P, int dp1, int lprs, int nv) { return (int64_t)nv * lprs * 16 + lds_extra_slice(P, dp1, nv); }
+
+// first candidate that holds a chunk of `nv` local vertices, sized for exactly that many
+inline tile_cfg pick_cfg(const phl_lattice *lat, int vd, bool for_slice, int nv)
+{
+    tile_cfg c;
+    int lprs;
+    int64_t budget;
+    const int P = lat->P, dp1 = lat->d + 1;
+    for (int k = 0; cfg_candidate(vd, for_slice, k, &lprs, &budget); k++) {
+        const int64_t need = for_slice ? slice_lds(P, dp1, lprs, nv) : splat_lds(P, dp1, lprs, nv);
+        if (need > budget) continue;
+        c.lprs = lprs;
+        c.cap = nv;
+        c.lds = (size_t)need;
+        return c;
+    }
+    return c;
+}
+
+// Chunk classes.  A launch's LDS layout is sized by the most local vertices a chunk of it may have.  Sizing every
+// chunk for the worst one (round 2) lets a single textured 16x16 tile narrow the slabs of the whole image: natural
+// images at M/n ~ 0.01 have 30 vertices in a typical chunk and 300 in the worst (0.3 % of the chunks above 158).
+// So the chunks are cut into at most two classes by their vertex count: LIGHT = the preferred configuration that
+// holds at least 3/4 of the chunks, run over the whole grid (the few others exit at once); HEAVY = the rest, a
+// short list (chunks sorted by descending vertex count, built with the lattice) run with the first configuration
+// that holds the worst chunk.
+struct tile_plan {
+    tile_cfg light, heavy;
+    int n_heavy = 0;    // 0: one launch (light) covers everything
+};
+inline int chunks_above(const phl_lattice *lat, int nv) { return nv >= lat->nv_max ? 0 : lat->nchunks - lat->nv_cum[nv < 0 ? 0 : nv]; }
+
+inline tile_plan plan_tiles(const phl_lattice *lat, int vd, bool for_slice)
+{
+    tile_plan p;
+    const tile_cfg all = pick_cfg(lat, vd, for_slice, lat->nv_max);
+    p.light = all;
+    static const bool classes = !(getenv("PHL_CLASSES") && atoi(getenv("PHL_CLASSES")) == 0);
+    if (all.lprs < 0 || !classes || !lat->nv_cum || !lat->chunk_by_nv) return p;
+    const int P = lat->P, dp1 = lat->d + 1;
+    int lprs;
+    int64_t budget;
+    for (int k = 0; cfg_candidate(vd, for_slice, k, &lprs, &budget); k++) {
+        const int64_t base = for_slice ? slice_lds(P, dp1, lprs, 0) : splat_lds(P, dp1, lprs, 0);
+        if (base > budget) continue;
+        const int64_t per_v = for_slice ? (int64_t)lprs * 16 + 4 : 16;
+        const int cap = (int)((budget - base) / per_v);
+        if (cap >= lat->nv_max) break;                        // this candidate is `all`: one launch does it
+        const int above = chunks_above(lat, cap);
+        if ((int64_t)above * 4 > lat->nchunks) continue;      // holds fewer than 3/4 of the chunks: try the next one
+        p.light.lprs = lprs;
+        p.light.cap = cap;
+        p.light.lds = (size_t)(for_slice ? slice_lds(P, dp1, lprs, cap) : splat_lds(P, dp1, lprs, cap));
+        p.heavy = all;
+        p.n_heavy = above;
+        return p;
+    }
+    return p;
 }
 
 template <typename K>
@@ -842,9 +1024,14 @@ inline int pick_lpr_row(int vd)
 int phl_tiles_free(phl_lattice *lat)
 {
     void *ptrs[] = {lat->pix_order, lat->chunk_vptr, lat->slot_vert, lat->slot_pidx, lat->seg_rng, lat->seg,
-                    lat->lidx, lat->vs_ptr, lat->vs, lat->vorder};
+                    lat->lidx, lat->vs_ptr, lat->vs, lat->vorder, lat->chunk_by_nv, lat->vlong};
     for (void *p : ptrs)
         if (p) (void)phl_dev_free(p);
+    free(lat->nv_cum);
+    lat->nv_cum = nullptr;
+    lat->chunk_by_nv = nullptr;
+    lat->vlong = nullptr;
+    lat->n_long = 0;
     lat->pix_order = lat->chunk_vptr = lat->slot_vert = lat->slot_pidx = lat->vs_ptr = nullptr;
     lat->seg_rng = nullptr;
     lat->vorder = nullptr;
@@ -902,6 +1089,24 @@ int phl_tiles_link_vertices(phl_lattice *lat, hipStream_t st)
     if (rc) return rc;
     int s_multi = 0;
     PHL_HIP(hipMemcpyAsync(&s_multi, lat->slot_pidx + S, sizeof(int), hipMemcpyDeviceToHost, st));
+    // vertices with long slot lists (k_splat_reduce_long): flag, scan, compact
+    int n_long = 0;
+    if (lat->vlong) PHL_HIP(phl_dev_free(lat->vlong));
+    lat->vlong = nullptr;
+    lat->n_long = 0;
+    {
+        int *lflag, *lrank;
+        PHL_HIP(tmp.get(&lflag, (size_t)M + 1));
+        PHL_HIP(tmp.get(&lrank, (size_t)M + 2));
+        hipLaunchKernelGGL(k_flag_long, dim3((M + 255) / 256), dim3(256), 0, st, lat->vs_ptr, M, LONG_LIST, lflag);
+        PHL_HIP(hipGetLastError());
+        rc = exclusive_scan(lflag, lrank, M, tile_sums, st);
+        if (rc) return rc;
+        PHL_HIP(hipMemcpyAsync(&n_long, lrank + M, sizeof(int), hipMemcpyDeviceToHost, st));
+        PHL_HIP(phl_dev_malloc((void **)&lat->vlong, sizeof(int) * ((size_t)M + 1)));      // worst case; usually almost empty
+        hipLaunchKernelGGL(k_compact_flagged, dim3((M + 255) / 256), dim3(256), 0, st, lflag, lrank, M, lat->vlong);
+        PHL_HIP(hipGetLastError());
+    }
     // chunk-major vertex order for the gather splat
     if (lat->vorder) PHL_HIP(phl_dev_free(lat->vorder));
     lat->vorder = nullptr;
@@ -921,6 +1126,7 @@ int phl_tiles_link_vertices(phl_lattice *lat, hipStream_t st)
     }
     PHL_HIP(hipStreamSynchronize(st));
     lat->S_multi = s_multi;
+    lat->n_long = n_long;
     return PHL_OK;
 }
 
@@ -1091,6 +1297,20 @@ int phl_tiles_build(phl_lattice *lat, const float *ref, int64_t rs, int64_t cs, 
     }
     lat->S = S;
     lat->nv_max = nv_max;
+    // chunk classes (plan_tiles): cumulative histogram of the vertex counts on the host, chunk ids by descending
+    // vertex count on the device (counting sort; ascending chunk id among equals)
+    std::vector<int> by_nv((size_t)nchunks);
+    {
+        lat->nv_cum = (int *)malloc(sizeof(int) * ((size_t)nv_max + 2));
+        if (!lat->nv_cum) { phl_set_error("phl_tiles_build: out of host memory"); return PHL_ERR_HIP; }
+        std::vector<int> start((size_t)nv_max + 2, 0);
+        for (int v : nv_host) start[(size_t)(nv_max - v) + 1]++;         // bin 0 = heaviest
+        for (int b = 0; b <= nv_max; b++) start[(size_t)b + 1] += start[(size_t)b];
+        for (int x = 0; x <= nv_max; x++) lat->nv_cum[x] = nchunks - start[(size_t)(nv_max - x)];   // #chunks with nv <= x
+        for (int c = 0; c < nchunks; c++) by_nv[(size_t)start[(size_t)(nv_max - nv_host[(size_t)c])]++] = c;
+        PHL_HIP(phl_dev_malloc((void **)&lat->chunk_by_nv, sizeof(int) * ((size_t)nchunks + 1)));
+        PHL_HIP(hipMemcpyAsync(lat->chunk_by_nv, by_nv.data(), sizeof(int) * (size_t)nchunks, hipMemcpyHostToDevice, st));
+    }
     PHL_HIP(phl_dev_malloc((void **)&lat->slot_vert, sizeof(int) * ((size_t)S + 1)));
     PHL_HIP(phl_dev_malloc((void **)&lat->seg_rng, sizeof(int2) * ((size_t)S + 1)));
     if (nv_max <= SLOT_STRIDE) {
@@ -1119,8 +1339,7 @@ int phl_tiles_build(phl_lattice *lat, const float *ref, int64_t rs, int64_t cs, 
 int phl_tiles_lprs(const phl_lattice *lat, int vd, int for_slice)
 {
     if (lat->nchunks == 0 || vd % 4 != 0) return -1;
-    return for_slice ? pick_lprs(vd, lat->nv_max, lds_extra_slice(lat->P, lat->d + 1, lat->nv_max))
-                     : pick_lprs(vd, lat->P + 1, lds_extra(lat->P, lat->d + 1, lat->nv_max));
+    return pick_cfg(lat, vd, for_slice != 0, lat->nv_max).lprs;
 }
 
 // which chunks hold a slot of any of the listed vertex rows
@@ -1167,14 +1386,12 @@ int phl_launch_splat_tiled(phl_lattice *lat, const float *src, int64_t src_rs, i
     // subset: run only the listed chunks, then complete only the listed vertex rows (either list may be empty)
     const int M = subset ? (int)nvl : (int)lat->M;
     if (lat->M == 0 || vd == 0) return PHL_OK;
-    const int64_t extra = lds_extra(lat->P, lat->d + 1, lat->nv_max);
-    const int lprs = pick_lprs(vd, lat->P + 1, extra);      // + the row of zeros
-    if (lprs < 0) {
+    const tile_plan plan = plan_tiles(lat, vd, false);
+    if (plan.light.lprs < 0) {
         phl_set_error("tiled splat: chunk does not fit LDS");
         return PHL_ERR_UNSUPPORTED;
     }
     int rc = PHL_OK;
-    const size_t lds = (size_t)(lat->P + 1) * lprs * 16 + (size_t)extra;
     unsigned cgrid;
     int xcd_chunk;
     const int nrun = subset ? nlist : lat->nchunks;
@@ -1186,13 +1403,31 @@ int phl_launch_splat_tiled(phl_lattice *lat, const float *src, int64_t src_rs, i
         PHL_HIP(phl_dev_malloc((void **)&tl, tl_n * 8));
         PHL_HIP(hipMemsetAsync(tl, 0, tl_n * 8, st));
     }
-    if (nrun > 0) dispatch_lprs(lprs, [&](auto L) {
+    // light class (or everything): the caller's chunk list / the whole grid; chunks of the other class exit at once
+    const int split = plan.n_heavy > 0 ? plan.light.cap : 0x7FFFFFFF;
+    if (nrun > 0) dispatch_lprs(plan.light.lprs, [&](auto L) {
         constexpr int LPRS = decltype(L)::value;
-        if ((rc = allow_lds(k_splat_tiled<LPRS>, lds)) != PHL_OK) return;
-        k_splat_tiled<LPRS><<<dim3(cgrid), dim3(TPB_S), lds, st>>>(
-            src, src_rs, vd, (int)lat->n, lat->P, lat->d + 1, lat->nv_max, lat->pix_order, lat->chunk_vptr, lat->slot_vert,
-            lat->slot_pidx, lat->seg_rng, lat->seg, vert, partial, nrun, xcd_chunk, tl, chunk_list);
+        if ((rc = allow_lds(k_splat_tiled<LPRS>, plan.light.lds)) != PHL_OK) return;
+        k_splat_tiled<LPRS><<<dim3(cgrid), dim3(TPB_S), plan.light.lds, st>>>(
+            src, src_rs, vd, (int)lat->n, lat->P, lat->d + 1, plan.light.cap, lat->pix_order, lat->chunk_vptr, lat->slot_vert,
+            lat->slot_pidx, lat->seg_rng, lat->seg, vert, partial, nrun, xcd_chunk, tl, chunk_list, -1, split, long_seg());
     });
+    // heavy class: the short list of chunks above the split (of a subset: the same list, filtered in the kernel)
+    if (rc == PHL_OK && nrun > 0 && plan.n_heavy > 0) {
+        const int *hlist = subset ? chunk_list : lat->chunk_by_nv;
+        const int hn = subset ? nlist : plan.n_heavy;
+        unsigned hgrid;
+        int hxcd;
+        chunk_grid(hn, &hgrid, &hxcd);
+        dispatch_lprs(plan.heavy.lprs, [&](auto L) {
+            constexpr int LPRS = decltype(L)::value;
+            if ((rc = allow_lds(k_splat_tiled<LPRS>, plan.heavy.lds)) != PHL_OK) return;
+            k_splat_tiled<LPRS><<<dim3(hgrid), dim3(TPB_S), plan.heavy.lds, st>>>(
+                src, src_rs, vd, (int)lat->n, lat->P, lat->d + 1, plan.heavy.cap, lat->pix_order, lat->chunk_vptr,
+                lat->slot_vert, lat->slot_pidx, lat->seg_rng, lat->seg, vert, partial, hn, hxcd, nullptr, hlist, split,
+                0x7FFFFFFF, long_seg());
+        });
+    }
     if (tl) {
         std::vector<unsigned long long> h(tl_n);
         PHL_HIP(hipMemcpyAsync(h.data(), tl, tl_n * 8, hipMemcpyDeviceToHost, st));
@@ -1209,9 +1444,16 @@ int phl_launch_splat_tiled(phl_lattice *lat, const float *src, int64_t src_rs, i
     int64_t waves = ((int64_t)M + (64 / lpr) - 1) / (64 / lpr);
     int64_t blocks = (waves + 3) / 4;
     if (blocks > 2048) blocks = 2048;
+    // long slot lists: the lattice's own list of such vertices, or (subset) the caller's rows, short ones exiting
+    const int *llist = subset ? vlist : lat->vlong;
+    const int64_t nl = subset ? nvl : lat->n_long;
+    const int long_list = llist ? LONG_LIST : 0x7FFFFFFF;
 #define PHL_RED(LPR_)                                                                                                  \
     k_splat_reduce<LPR_><<<dim3((unsigned)blocks), dim3(256), 0, st>>>(partial, lat->vs_ptr, lat->vs, lat->slot_pidx, \
-                                                                       M, vd, vert, vlist)
+                                                                       M, vd, vert, vlist, long_list);               \
+    if (llist && nl > 0)                                                                                               \
+        k_splat_reduce_long<LPR_><<<dim3((unsigned)nl), dim3(256), 0, st>>>(partial, lat->vs_ptr, lat->vs,            \
+                                                                            lat->slot_pidx, vd, vert, llist, long_list)
     switch (lpr) {
         case 64: PHL_RED(64); break;
         case 16: PHL_RED(16); break;
@@ -1227,34 +1469,37 @@ int phl_launch_slice_tiled(const phl_lattice *lat, const float *vert, int vd, fl
                            int64_t sub_rs, unsigned flags, hipStream_t st)
 {
     if (lat->n == 0 || vd == 0) return PHL_OK;
-    const int64_t extra = lds_extra_slice(lat->P, lat->d + 1, lat->nv_max);
-    const int lprs = pick_lprs(vd, lat->nv_max, extra);
-    if (lprs < 0) {
+    const tile_plan plan = plan_tiles(lat, vd, true);
+    if (plan.light.lprs < 0) {
         phl_set_error("tiled slice: chunk does not fit LDS");
         return PHL_ERR_UNSUPPORTED;
     }
     const float cdiv = 1 + powf(2, -lat->d);  // permutohedral.h:480
     const float rcdiv = 1.0f / cdiv;
-    const size_t lds = (size_t)lat->nv_max * lprs * 16 + (size_t)extra;
     const bool exact = (flags & PHL_FILTER_EXACT) != 0;
     int rc = PHL_OK;
-    unsigned cgrid;
-    int xcd_chunk;
-    chunk_grid(lat->nchunks, &cgrid, &xcd_chunk);
-    dispatch_lprs(lprs, [&](auto L) {
-        constexpr int LPRS = decltype(L)::value;
-        if (exact) {
-            if ((rc = allow_lds(k_slice_tiled<LPRS, true>, lds)) != PHL_OK) return;
-            k_slice_tiled<LPRS, true><<<dim3(cgrid), dim3(TPB), lds, st>>>(
-                vert, vd, (int)lat->n, lat->P, lat->d + 1, lat->nv_max, lat->pix_order, lat->chunk_vptr, lat->slot_vert,
-                lat->lidx, lat->replay, out, out_rs, sub, sub_rs, cdiv, rcdiv, lat->nchunks, xcd_chunk);
-        } else {
-            if ((rc = allow_lds(k_slice_tiled<LPRS, false>, lds)) != PHL_OK) return;
-            k_slice_tiled<LPRS, false><<<dim3(cgrid), dim3(TPB), lds, st>>>(
-                vert, vd, (int)lat->n, lat->P, lat->d + 1, lat->nv_max, lat->pix_order, lat->chunk_vptr, lat->slot_vert,
-                lat->lidx, lat->replay, out, out_rs, sub, sub_rs, cdiv, rcdiv, lat->nchunks, xcd_chunk);
-        }
-    });
+    const int split = plan.n_heavy > 0 ? plan.light.cap : 0x7FFFFFFF;
+    auto launch = [&](const tile_cfg &cfg, int nrun, const int *list, int lo, int hi) {
+        unsigned cgrid;
+        int xcd_chunk;
+        chunk_grid(nrun, &cgrid, &xcd_chunk);
+        dispatch_lprs(cfg.lprs, [&](auto L) {
+            constexpr int LPRS = decltype(L)::value;
+            if (exact) {
+                if ((rc = allow_lds(k_slice_tiled<LPRS, true>, cfg.lds)) != PHL_OK) return;
+                k_slice_tiled<LPRS, true><<<dim3(cgrid), dim3(TPB), cfg.lds, st>>>(
+                    vert, vd, (int)lat->n, lat->P, lat->d + 1, cfg.cap, lat->pix_order, lat->chunk_vptr, lat->slot_vert,
+                    lat->lidx, lat->replay, out, out_rs, sub, sub_rs, cdiv, rcdiv, nrun, xcd_chunk, list, lo, hi);
+            } else {
+                if ((rc = allow_lds(k_slice_tiled<LPRS, false>, cfg.lds)) != PHL_OK) return;
+                k_slice_tiled<LPRS, false><<<dim3(cgrid), dim3(TPB), cfg.lds, st>>>(
+                    vert, vd, (int)lat->n, lat->P, lat->d + 1, cfg.cap, lat->pix_order, lat->chunk_vptr, lat->slot_vert,
+                    lat->lidx, lat->replay, out, out_rs, sub, sub_rs, cdiv, rcdiv, nrun, xcd_chunk, list, lo, hi);
+            }
+        });
+    };
+    launch(plan.light, lat->nchunks, nullptr, -1, split);
+    if (rc == PHL_OK && plan.n_heavy > 0) launch(plan.heavy, plan.n_heavy, lat->chunk_by_nv, split, 0x7FFFFFFF);
     if (rc) return rc;
     PHL_HIP(hipGetLastError());
     return PHL_OK;

@@ -21,7 +21,8 @@ import numpy as np
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libphl.so")
+# PHL_LIB: another build of the same library (A/B timing of two source states on one box); never a fallback
+LIB_PATH = os.environ.get("PHL_LIB") or os.path.join(os.path.dirname(_HERE), "lib", "libphl.so")
 
 SUBTRACT_INPUT = 1
 EXACT = 4

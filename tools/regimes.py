@@ -1,0 +1,132 @@
+#!/usr/bin/env python3
+"""Operating-point sweep of the filter step (SURVEY.md 8d "synthetic inputs").
+
+For every (workload, feature regime): build the lattice, report M/n and the chunk statistics, time the three
+stages with HIP events (default path and, for comparison, the plain gather kernels) and the whole step.
+One process, one JSON document:
+
+    python tools/regimes.py [--workloads c3,c2] [--out gpurun_out/regimes.json] [--quick]
+
+Regimes: synthetic smooth colours at sigma_xy in {3, 8, 30}, the iid-colour stress case, and the stored Tsukuba
+frame upsampled to the workload size with the reference notebooks' three feature scalings
+(Experiments/DenseCrf.ipynb:142-146, crf/lattice/lite/test_bilateral.ipynb cell 6): M/n = 0.04 / 0.2 / 0.5 at
+384x288.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "depth-estimation_amd"))
+
+import bench  # noqa: E402
+
+REGIMES = [
+    ("sxy8", dict(sigma_xy=8.0)),
+    ("sxy3", dict(sigma_xy=3.0)),
+    ("sxy30", dict(sigma_xy=30.0)),
+    ("tsu_.1_.1", dict(tsukuba=(0.1, 0.1))),
+    ("tsu_.08_.03", dict(tsukuba=(0.08, 0.03))),
+    ("tsu_.125_.01", dict(tsukuba=(0.125, 0.01))),
+    ("iid", dict(sigma_xy=8.0, iid=True)),
+]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--workloads", default="c3,c2")
+    ap.add_argument("--regimes", default=",".join(r for r, _ in REGIMES))
+    ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "regimes.json"))
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=6)
+    ap.add_argument("--no-gather", action="store_true", help="skip the gather-kernel comparison")
+    args = ap.parse_args()
+
+    import torch
+
+    import phl
+
+    device = torch.device("cuda", 0)
+    rows = []
+    d = 5
+    for wl in args.workloads.split(","):
+        H, W, L, _ = bench.WORKLOADS[wl]
+        n = H * W
+        src = bench.synthetic_values(torch, H, W, L, 0, device)
+        out = torch.empty_like(src)
+        for name, opt in REGIMES:
+            if name not in args.regimes.split(","):
+                continue
+            feat, desc = bench.features_for(H, W, **opt)
+            ref = torch.from_numpy(feat.reshape(-1, d)).to(device)
+            torch.cuda.synchronize()
+            t0 = time.time()
+            try:
+                lat = phl.Lattice(ref)
+            except Exception as e:  # noqa: BLE001  (e.g. key range at an extreme scaling: report, go on)
+                rows.append({"workload": wl, "regime": name, "features": desc, "error": str(e)})
+                print(rows[-1], file=sys.stderr, flush=True)
+                continue
+            torch.cuda.synchronize()
+            build_ms = (time.time() - t0) * 1e3
+            M = lat.M
+            rec = {"workload": wl, "regime": name, "features": desc, "n": n, "L": L, "M": M, "M_over_n": round(M / n, 4),
+                   "build_ms": round(build_ms, 2), "tiles": lat.tile_stats(L)}
+            ab = bench.algorithmic_bytes(n, M, L, d)
+            total_bytes = sum(ab.values())
+            for mode, kw in (("default", dict(exact=False, no_tiles=False)), ("gather", dict(exact=False, no_tiles=True))):
+                if mode == "gather" and args.no_gather:
+                    continue
+                try:
+                    for _ in range(args.warmup):
+                        lat.filter(src, out=out, **kw)
+                    torch.cuda.synchronize()
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    for _ in range(args.steps):
+                        lat.filter(src, out=out, **kw)
+                    e1.record()
+                    torch.cuda.synchronize()
+                    ms = e0.elapsed_time(e1) / args.steps
+                    st = bench.stage_times(torch, lat, src, out, kw, 5)
+                except Exception as e:  # noqa: BLE001
+                    rec[mode] = {"error": str(e)}
+                    continue
+                rec[mode] = {"step_ms": round(ms, 4), "Mpixel_labels_per_s": round(n * L / (ms * 1e-3) / 1e6, 1),
+                             "algorithmic_GBps": round(total_bytes / (ms * 1e-3) / 1e9, 1),
+                             "stage_ms": {k: round(v, 4) for k, v in st.items()},
+                             "stage_GBps": {k: round(ab[k] / (st[k] * 1e-3) / 1e9, 1) for k in st}}
+            rows.append(rec)
+            print(json.dumps(rec), file=sys.stderr, flush=True)
+            lat.close()
+            del lat, ref
+            torch.cuda.empty_cache()
+            phl.load_library().phl_trim_scratch()
+        del src, out
+        torch.cuda.empty_cache()
+    # the "done" criterion of the sweep: algorithmic GB/s of every regime relative to sigma_xy = 8 on the same workload
+    base = {r["workload"]: r["default"]["algorithmic_GBps"] for r in rows if r.get("regime") == "sxy8" and "default" in r and "algorithmic_GBps" in r["default"]}
+    for r in rows:
+        if "default" in r and "algorithmic_GBps" in r["default"] and r["workload"] in base:
+            r["default"]["rel_to_sxy8"] = round(r["default"]["algorithmic_GBps"] / base[r["workload"]], 3)
+    doc = {"what": "filter step (splat+blur+slice) across feature regimes; algorithmic bytes per SURVEY 8d",
+           "device": torch.cuda.get_device_name(0), "rows": rows}
+    os.makedirs(os.path.dirname(args.out), exist_ok=True)
+    with open(args.out, "w") as f:
+        json.dump(doc, f, indent=1)
+    for r in rows:
+        if "default" in r and "step_ms" in r["default"]:
+            g = r.get("gather", {})
+            print(f"{r['workload']:3s} {r['regime']:13s} M/n {r['M_over_n']:6.3f} nv_max {r['tiles']['max_local_vertices']:4d} "
+                  f"staged {r['tiles']['staged_splat']}/{r['tiles']['staged_slice']} step {r['default']['step_ms']:8.3f} ms "
+                  f"alg {r['default']['algorithmic_GBps']:7.1f} GB/s rel {r['default'].get('rel_to_sxy8', 0):5.2f} "
+                  f"stages {r['default']['stage_ms']} gather {g.get('step_ms')}")
+        else:
+            print(r)
+
+
+if __name__ == "__main__":
+    main()
