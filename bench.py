@@ -215,21 +215,23 @@ def _cpu_model():
     return "unknown"
 
 
-def _cpu_filter_once(src, ref):
+def _cpu_filter_once(src, ref, want_out=False):
     """One reference-shaped call (lattice rebuilt inside, as the reference does) on the CPU checker:
     the reference's own engine when oracle/_ref travelled with the tree, else our C port."""
     from oracle import phl_oracle as po
 
     if po.reference_available():
         t0 = time.time()
-        _, M, st = po.reference_filter_timed(src, ref)
-        return "reference", time.time() - t0, int(M), dict(init=st[0], splat=st[1], blur=st[2], slice=st[3])
+        out, M, st = po.reference_filter_timed(src, ref)
+        res = ("reference", time.time() - t0, int(M), dict(init=st[0], splat=st[1], blur=st[2], slice=st[3]))
+        return res + (out,) if want_out else res
     po.build_oracle()
     t0 = time.time()
-    O = po.Oracle(ref)
+    O = po.Oracle(ref, faithful_table=True)       # the reference's table behaviour across its doublings
     tb = time.time() - t0
-    _, st = O.filter(src, timing=True)
-    return "port", time.time() - t0, int(O.M), dict(build=tb, splat=st[0], blur=st[1], slice=st[2])
+    out, st = O.filter(src, timing=True)
+    res = ("port", time.time() - t0, int(O.M), dict(build=tb, splat=st[0], blur=st[1], slice=st[2]))
+    return res + (out,) if want_out else res
 
 
 def cpu_worker(path):
@@ -237,11 +239,47 @@ def cpu_worker(path):
     that filters one stored item -- the reference's `mp.Pool(num_threads).starmap(latticefilter, ...)`
     worker (crf/gaussian_matrix.py:370-377)."""
     z = np.load(path)
-    kind, dt, M, _ = _cpu_filter_once(z["src"], z["ref"])
+    kind, dt, M, _ = _cpu_filter_once(z["src"], z["ref"])[:4]
     print(json.dumps({"kind": kind, "seconds": dt, "M": M}))
 
 
-def cpu_baseline(feat, H, W, L, d):
+def gpu_vs_reference(ref, src, want, M_ref):
+    """Bar (1) at BASELINE scale, checked inside the driver's own bench run: the crop the CPU leg just filtered
+    with the reference engine (M ~ 150 k: four doublings of the reference's hash table, permutohedral.h:59-62,
+    101-103) is filtered on the GPU and compared with that output.
+      * reference-table build + exact arithmetic: must be BIT-IDENTICAL;
+      * reference-table build + default arithmetic: fp32 rounding only;
+      * clean-table build (one vertex per key; the reference's duplicates are a defect of its table): the rows that
+        differ beyond 1e-4 are the ones the duplicates touch."""
+    import torch
+
+    import phl
+
+    dev = torch.device("cuda", torch.cuda.current_device())
+    r = torch.from_numpy(ref).to(dev)
+    s = torch.from_numpy(src).to(dev)
+    res = {}
+    scale = np.maximum(np.abs(want), 1e-3 * float(np.abs(want).max()))
+
+    def compare(got):
+        rel = np.abs(got - want) / scale
+        return float(rel.max()), float((rel.max(axis=1) > 1e-4).mean())
+
+    lat = phl.Lattice(r, reference_table=True)
+    got = lat.filter(s, exact=True).cpu().numpy()
+    res["gpu_bit_equal_to_reference"] = bool(lat.M == M_ref and np.array_equal(got.view(np.uint32), want.view(np.uint32)))
+    res["M_gpu_reference_table"] = int(lat.M)
+    mx, fr = compare(lat.filter(s).cpu().numpy())
+    res["reference_table_default_arithmetic"] = {"max_rel": mx, "rows_beyond_1e-4": fr}
+    lat.close()
+    lat = phl.Lattice(r, reference_table=False)
+    mx, fr = compare(lat.filter(s).cpu().numpy())
+    res["clean_table_default_arithmetic"] = {"max_rel": mx, "rows_beyond_1e-4": fr, "M": int(lat.M)}
+    lat.close()
+    return res
+
+
+def cpu_baseline(feat, H, W, L, d, check_gpu=True):
     """SURVEY.md 8(d) CPU baseline, timed on this box's host cores, beside (never inside) the GPU timing:
       (i)   1 thread on a bounded crop of the bench workload (the reference filters one image per thread);
       (ii)  batch mode: 8 independent items on P = min(8, nproc) worker PROCESSES, as the reference's
@@ -257,13 +295,17 @@ def cpu_baseline(feat, H, W, L, d):
     rng = np.random.default_rng(4321)
     src = rng.random((ch * cw, L), dtype=np.float32)
     src /= src.sum(1, keepdims=True)
-    kind, dt, M, stages = _cpu_filter_once(src, ref)
+    kind, dt, M, stages, cpu_out = _cpu_filter_once(src, ref, want_out=True)
     out = {"value": round(ch * cw * L / dt / 1e6, 3), "unit": "Mpixel-labels/s", "cores": 1, "kind": kind,
            "sample": f"top-left {cw}x{ch} crop of the same features, L={L}, 1 thread, lattice rebuilt per call (reference behaviour)",
            "seconds": round(dt, 3), "M_over_n": round(M / (ch * cw), 4),
            "stage_seconds": {k: round(float(v), 4) for k, v in stages.items()},
            "nproc": nproc, "cpu_model": _cpu_model(),
            "compiler": "g++ -O2 (oracle/build_ref.sh)" if kind == "reference" else "gcc -O2 -ffp-contract=off (oracle/Makefile)"}
+
+    if check_gpu:
+        out.update(gpu_vs_reference(ref, src, cpu_out, M))
+    del cpu_out
 
     # (ii) the reference's batch mode: one worker process per item, P at a time
     items, P = 8, min(8, nproc)
@@ -302,7 +344,7 @@ def cpu_baseline(feat, H, W, L, d):
     s1 /= s1.sum(1, keepdims=True)
     reps, t = 5, []
     for _ in range(reps):
-        _, dt1, M1, _ = _cpu_filter_once(s1, f1)
+        _, dt1, M1, _ = _cpu_filter_once(s1, f1)[:4]
         t.append(dt1)
     out["c1_full"] = {"value": round(H1 * W1 * L1 / min(t) / 1e6, 3), "unit": "Mpixel-labels/s", "cores": 1,
                       "seconds": round(min(t), 4), "M_over_n": round(M1 / (H1 * W1), 4),
@@ -395,11 +437,17 @@ def main():
                     help="natural-image features: the stored Tsukuba frame upsampled to the workload size, "
                          "(rgb/SC, ij/diag/SP) as in DenseCrf.ipynb:142-146 (e.g. 0.1,0.1  0.08,0.03  0.125,0.01)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-regimes", action="store_true", help="skip the compact operating-point sweep (extra key `regimes`)")
+    ap.add_argument("--clean-table", action="store_true",
+                    help="build the lattice with one vertex per key instead of reproducing the reference's hash-table "
+                         "behaviour across its doublings (duplicate vertices above M = 16383); see config.table")
     ap.add_argument("--no-tiles", action="store_true", help="plain gather kernels (A/B against the LDS-staged chunk path)")
     ap.add_argument("--exact", action="store_true", help="reference-exact arithmetic (bit-identical to the CPU path)")
     ap.add_argument("--graph", action="store_true", help="replay the step from a captured HIP graph (launch-bound sizes)")
     ap.add_argument("--force-rowtile", action="store_true", help="debug: run the row-band driver even with one rank")
-    ap.add_argument("--mean-field", action="store_true", help="also time one full mean-field iteration (extra key)")
+    ap.add_argument("--mean-field", dest="mean_field", action="store_true", default=True,
+                    help="also time one full mean-field iteration and its fused compatibility kernel (extra key; default on)")
+    ap.add_argument("--no-mean-field", dest="mean_field", action="store_false")
     ap.add_argument("--dry-launch", action="store_true", help="launcher / rendezvous plumbing only, gloo on CPU, no filter")
     ap.add_argument("--cpu-worker", default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
@@ -473,25 +521,32 @@ def main():
         src = synthetic_values(torch, H, W, L, 1000 * rank, device)      # every rank its own volume
         torch.cuda.synchronize()
         t0 = time.time()
-        lat = phl.Lattice(ref)
+        ref_table = not args.clean_table
+        lat = phl.Lattice(ref, reference_table=ref_table)
         torch.cuda.synchronize()
         build_ms = (time.time() - t0) * 1e3
         # steady-state rebuild (the reference builds a lattice in every filter call): build + destroy in a loop, so
         # that work arrays come from the cached scratch block and the lattice's own arrays from the block cache
-        build_warm_ms = float("inf")
-        for _ in range(4):
-            t0 = time.time()
-            lat_warm = phl.Lattice(ref)
-            torch.cuda.synchronize()
-            build_warm_ms = min(build_warm_ms, (time.time() - t0) * 1e3)
-            lat_warm.close()
-        del lat_warm
+        def warm_build(table):
+            best = float("inf")
+            for _ in range(4):
+                t0 = time.time()
+                lat_warm = phl.Lattice(ref, reference_table=table)
+                torch.cuda.synchronize()
+                best = min(best, (time.time() - t0) * 1e3)
+                lat_warm.close()
+            return best
+
+        build_warm_ms = warm_build(ref_table)
+        build_warm_other_ms = warm_build(not ref_table)
         lat.reserve(L)
         out = torch.empty_like(src)
         kw = dict(exact=args.exact, no_tiles=args.no_tiles)
         step = lambda: lat.filter(src, out=out, **kw)
         M, n_local = lat.M, n_total
-        extra = {"tiles": lat.tile_stats(L), "lattice_build_warm_ms": round(build_warm_ms, 2)}
+        extra = {"tiles": lat.tile_stats(L), "lattice_build_warm_ms": round(build_warm_ms, 2),
+                 ("lattice_build_warm_ms_reference_table" if args.clean_table else "lattice_build_warm_ms_clean_table"):
+                     round(build_warm_other_ms, 2)}
 
     def sync_all():
         torch.cuda.synchronize()
@@ -521,6 +576,23 @@ def main():
     ms_per_step = dt / args.steps * 1e3
     volumes = world if (world > 1 and not rowtiled) else 1     # independent volumes: one per rank
     value = volumes * n_total * L / (dt / args.steps) / 1e6
+
+    # the same step on the lattice built the other way (clean <-> reference table): same kernels, a handful of
+    # duplicate vertices more or fewer
+    if rank == 0 and world == 1 and not rowtiled:
+        lat_o = phl.Lattice(ref, reference_table=args.clean_table)
+        for _ in range(3):
+            lat_o.filter(src, out=out, **kw)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            lat_o.filter(src, out=out, **kw)
+        e1.record()
+        torch.cuda.synchronize()
+        extra["ms_per_step_reference_table" if args.clean_table else "ms_per_step_clean_table"] = round(e0.elapsed_time(e1) / 10, 4)
+        extra["M_reference_table" if args.clean_table else "M_clean_table"] = int(lat_o.M)
+        lat_o.close()
+        del lat_o
 
     # ---- per-kernel timing with HIP events on the launch stream (rank-local lattice) ---------
     roofline = None
@@ -578,6 +650,18 @@ def main():
     if args.mean_field and rank == 0 and not rowtiled:
         mean_field = mean_field_iteration(torch, phl, lat, src, L, device)
 
+    regimes = None
+    default_features = tsu is None and not args.iid and args.sigma_xy == SIGMA_XY and args.sigma_c == SIGMA_C
+    if (rank == 0 and world == 1 and not rowtiled and not args.no_regimes and default_features
+            and not (args.exact or args.no_tiles or args.graph)):
+        regimes = regime_sweep(torch, phl, H, W, L, d, src, out, ms_per_step, M)
+
+    # ---- N > 1: the run validates itself ------------------------------------------------------
+    check = None
+    if world > 1 or args.force_rowtile:
+        check = self_check(torch, phl, dist, backend, rank, world, device, rowtiled, job if rowtiled else None,
+                           lat if not rowtiled else None, feat, H, W, L, d, src, out_rt if rowtiled else out)
+
     cpu = None
     if rank == 0 and world == 1 and not rowtiled and not args.no_cpu_baseline:
         cpu = cpu_baseline(feat, H, W, L, d)
@@ -594,7 +678,12 @@ def main():
                                        f"row bands x{world} + RCCL boundary-vertex exchange" if rowtiled else
                                        f"{world} independent volumes, one per GPU, no collective"),
                        "launch": "hip graph replay" if (args.graph and not rowtiled) else "eager",
-                       "arithmetic": "reference-exact (bit-identical to the CPU path)" if args.exact else "default (fp32-rounding-equivalent, ~1e-7 rel)"},
+                       "arithmetic": "reference-exact (bit-identical to the CPU path)" if args.exact else "default (fp32-rounding-equivalent, ~1e-7 rel)",
+                       # "reference": vertices, duplicates included, are the reference's (its hash table files the key in
+                       # flight at every doubling from a stale slot, permutohedral.h:59-62,101-103) -- with --exact the
+                       # output is bit-identical to the reference engine at this size (cpu_baseline.gpu_bit_equal_to_reference
+                       # checks it in this run); "clean": one vertex per key.  Row bands build per-band lattices: always clean.
+                       "table": "clean" if (rowtiled or args.clean_table) else "reference"},
             "ranks": world, "backend": backend, "devices_visible": ndev,
             "launched_by": "bench.py launcher" if os.environ.get("PHL_BENCH_LAUNCHED") else ("torchrun" if "TORCHELASTIC_RUN_ID" in os.environ else "direct"),
             "lattice_build_ms": round(build_ms, 2),
@@ -605,11 +694,104 @@ def main():
         }
         if mean_field is not None:
             line["mean_field_iteration"] = mean_field
+        if regimes is not None:
+            line["regimes"] = regimes
+        if check is not None:
+            line["check"] = check
         line.update(extra)
         print(json.dumps(line), file=JSON_OUT, flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if check is not None and not check["ok"]:
+        sys.exit(f"bench.py: multi-rank result check FAILED: {check}")
+
+
+CHECK_TOL = 1e-4     # north_star: "within 1e-4 relative per pixel"
+
+
+def self_check(torch, phl, dist, backend, rank, world, device, rowtiled, job, lat, feat, H, W, L, d, src, out):
+    """An N > 1 line must not print a number nobody verified (the first RCCL run of this code happens on the
+    driver's node).  Row bands: every rank filters the WHOLE seeded volume through one single-image lattice on its
+    own GPU -- no communication involved -- and compares the rows of its band with what the row-band step just
+    produced; the worst relative error over all ranks is reduced with MAX.  Independent volumes (c5): the rank's
+    default (LDS-staged) result against the gather kernels in the reference's summation order -- another code
+    path over the same lattice -- plus run-to-run bit equality.  Also times the exchange (rowtile.exchange_probe)."""
+    def rel(got, want):
+        scale = torch.clamp(want.abs(), min=1e-3 * float(want.abs().max()))
+        return float(((got - want).abs() / scale).max())
+
+    res = {"tolerance": CHECK_TOL}
+    if rowtiled:
+        probe = job.exchange_probe(src, out)
+        mine = torch.tensor([job.row0, job.own_rows], dtype=torch.int64)
+        bands = [torch.zeros(2, dtype=torch.int64) for _ in range(world)]
+        if world > 1:
+            if backend == "nccl":
+                g = [b.to(device) for b in bands]
+                dist.all_gather(g, mine.to(device))
+                bands = [b.cpu() for b in g]
+            else:
+                dist.all_gather(bands, mine)
+        else:
+            bands = [mine]
+        full = torch.cat([synthetic_values(torch, int(r), W, L, int(r0), device) for r0, r in bands])
+        whole = phl.Lattice(torch.from_numpy(feat.reshape(-1, d)).to(device))
+        want = whole.filter(full)
+        a = job.row0 * W
+        err = rel(out, want[a:a + job.n_local])
+        res.update(what="row-band result vs a single-lattice filter of the whole volume on the same GPU", **probe)
+        whole.close()
+        del want, full
+    else:
+        a = lat.filter(src)
+        b = lat.filter(src)
+        repeat = bool(torch.equal(a, b))
+        err = rel(a, lat.filter(src, exact=True))
+        if not repeat:
+            err = float("inf")
+        res.update(what="default path vs gather kernels (reference summation order) on this rank's volume; run-to-run bit equality",
+                   repeatable=repeat)
+    t = torch.tensor([err], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    res["check_max_rel"] = float(t.item())
+    res["ok"] = bool(res["check_max_rel"] <= CHECK_TOL)
+    return res
+
+
+def regime_sweep(torch, phl, H, W, L, d, src, out, base_ms, base_M):
+    """SURVEY 8(d) "synthetic inputs": the same volume filtered under other feature distributions -- sigma_xy 3
+    and 30, and natural-image features (the stored Tsukuba frame upsampled, DenseCrf.ipynb:142-146 scaling) -- so
+    that the headline is not one operating point's speed.  Compact: M/n, ms per step, algorithmic GB/s (8d byte
+    counts) and that figure relative to the default features'.  The full sweep (both large workloads, stage times,
+    gather-kernel comparison, iid stress case) is tools/regimes.py -> profiles/r03_regimes.json."""
+    n = H * W
+    alg = lambda M: sum(algorithmic_bytes(n, M, L, d).values())
+    base_gbs = alg(base_M) / (base_ms * 1e-3) / 1e9
+    rows = {"default": {"M_over_n": round(base_M / n, 4), "ms": round(base_ms, 4), "algorithmic_GBps": round(base_gbs, 1), "rel": 1.0}}
+    for name, opt in (("sigma_xy=3", dict(sigma_xy=3.0)), ("sigma_xy=30", dict(sigma_xy=30.0)),
+                      ("tsukuba 0.08/0.03", dict(tsukuba=(0.08, 0.03))), ("tsukuba 0.1/0.1", dict(tsukuba=(0.1, 0.1)))):
+        feat, _ = features_for(H, W, **opt)
+        lat = phl.Lattice(torch.from_numpy(feat.reshape(-1, d)).to(src.device))
+        for _ in range(4):
+            lat.filter(src, out=out)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(10):
+            lat.filter(src, out=out)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 10
+        gbs = alg(lat.M) / (ms * 1e-3) / 1e9
+        st = lat.tile_stats(L)
+        rows[name] = {"M_over_n": round(lat.M / n, 4), "ms": round(ms, 4), "Mpixel_labels_per_s": round(n * L / (ms * 1e-3) / 1e6, 1),
+                      "algorithmic_GBps": round(gbs, 1), "rel": round(gbs / base_gbs, 3),
+                      "max_local_vertices": st["max_local_vertices"], "staged": [st["staged_splat"], st["staged_slice"]]}
+        lat.close()
+        del lat
+    return rows
 
 
 def mean_field_iteration(torch, phl, lat, Q, L, device):
@@ -635,8 +817,26 @@ def mean_field_iteration(torch, phl, lat, Q, L, device):
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
-    return {"ms": round(ms, 3), "Mpixel_labels_per_s": round(Q.shape[0] * L / (ms * 1e-3) / 1e6, 1),
-            "what": "filter - Q (fused), (.)@Mu + E0 + softmax(-.)"}
+    # the fused compatibility product + softmax (phl_compat_softmax: hand-written f32 MFMA 16x16x4 tiles with the
+    # softmax as epilogue) alone, steady state: HIP events around `reps` back-to-back launches after the warm-up above
+    X = W(Q)
+    for _ in range(4):
+        phl.compat_softmax(E0, X, Mu, out=Qn)
+    e2, e3 = ev(), ev()
+    e2.record()
+    for _ in range(reps):
+        phl.compat_softmax(E0, X, Mu, out=Qn)
+    e3.record()
+    torch.cuda.synchronize()
+    cms = e2.elapsed_time(e3) / reps
+    n = Q.shape[0]
+    tflops = 2.0 * n * L * L / (cms * 1e-3) / 1e12
+    F32_MFMA_PEAK = 157.3      # MI355X_MICROARCH.md: dense fp32 matrix peak, TFLOP/s
+    return {"ms": round(ms, 3), "Mpixel_labels_per_s": round(n * L / (ms * 1e-3) / 1e6, 1),
+            "what": "filter - Q (fused), (.)@Mu + E0 + softmax(-.)",
+            "compat": {"kernel": "k_compat_softmax", "ms": round(cms, 4), "tflops": round(tflops, 1),
+                       "frac_of_157.3": round(tflops / F32_MFMA_PEAK, 3), "hbm_bytes_algorithmic": int(3 * 4 * n * L),
+                       "what": "softmax(-(E0 + X@Mu)) in one kernel: reads E0 and X, writes Q; G and E never exist in HBM"}}
 
 
 if __name__ == "__main__":

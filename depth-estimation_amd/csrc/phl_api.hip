@@ -483,7 +483,10 @@ bool use_tiled_splat(const phl_lattice *lat, int vd, unsigned flags, const void 
     if (flags & (PHL_FILTER_EXACT | PHL_FILTER_NO_TILES)) return false;
     if (phl_tiles_lprs(lat, vd, 0) < 0) return false;
     if ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) & 15 || rs % 4) return false;
-    return lat->S_multi <= lat->n;   // partial-row traffic must stay below what staging saves
+    // Partial rows cost 2 * S_multi row transfers (written, re-read); staging saves d of the d+1 reads the gather
+    // splat makes of every pixel row.  Break-even is far out (S_multi = d/2 * n); beyond 2n the chunks share so
+    // little that the gather form is taken (the iid stress case sits at ~0.9n and is still 1.3x faster staged).
+    return lat->S_multi <= 2 * lat->n;
 }
 bool use_tiled_slice(const phl_lattice *lat, int vd, unsigned flags, const void *a, const void *b, const void *c, int64_t rs,
                      int64_t rs2)
@@ -509,7 +512,7 @@ namespace {
 int64_t need_partial(const phl_lattice *lat, int vd, unsigned flags)
 {
     if (flags & (PHL_FILTER_EXACT | PHL_FILTER_NO_TILES)) return 0;
-    if (phl_tiles_lprs(lat, vd, 0) < 0 || lat->S_multi > lat->n) return 0;
+    if (phl_tiles_lprs(lat, vd, 0) < 0 || lat->S_multi > 2 * lat->n) return 0;
     return lat->S_multi * (int64_t)vd;
 }
 }  // namespace

@@ -36,6 +36,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
 #include <queue>
 #include <unordered_map>
 #include <vector>
@@ -44,14 +45,34 @@
 
 namespace {
 
+// The simulated table.  Same hash (:109-116, size_t arithmetic), same linear probe (:65-90), same slot-order
+// re-filing in grow() (:122-155).  Host-speed details that do not change what it computes (C3, M = 297 k, five
+// doublings: 35 ms -> a few ms): the capacity is a power of two (2^15 doubling), so `% capacity` is a mask and the
+// low 32 bits of a hash decide the slot at any capacity; a slot is 8 bytes {low half of the key's hash, vertex + 1}
+// with 0 = empty, so a probe compares keys (a random access into the key array) only on a hash match, grow()
+// re-files straight from the old slots without touching keys, and clearing is a memset; the two slot arrays
+// (current / next) are kept per thread across builds -- most of the 35 ms were page faults on fresh 16 MB
+// vectors -- and both loops prefetch their target slots ahead.
 struct ref_sim {
+    typedef uint64_t slot_t;
+    static slot_t mk(uint64_t hfull, int32_t v) { return ((uint64_t)(uint32_t)(v + 1) << 32) | (uint32_t)hfull; }
+    static int32_t vertex(slot_t s) { return (int32_t)(s >> 32) - 1; }
     int d = 0;
     uint64_t cap = (uint64_t)1 << 15;   // :36
-    std::vector<int32_t> slots;
+    std::vector<slot_t> *cur, *nxt;
+    slot_t *slots;
     std::vector<int16_t> keys;          // [F][d], insertion order
     int64_t F = 0;
 
-    explicit ref_sim(int d_) : d(d_), slots((size_t)1 << 15, -1) {}
+    explicit ref_sim(int d_) : d(d_)
+    {
+        static thread_local std::vector<slot_t> pool[2];
+        cur = &pool[0];
+        nxt = &pool[1];
+        if (cur->size() < cap) cur->resize((size_t)cap);
+        slots = cur->data();
+        memset(slots, 0, sizeof(slot_t) * (size_t)cap);
+    }
     uint64_t hash(const int16_t *k) const    // :109-116, size_t arithmetic
     {
         uint64_t h = 0;
@@ -62,39 +83,64 @@ struct ref_sim {
         return h;
     }
     bool need_grow() const { return (uint64_t)F >= cap / 2 - 1; }   // :62
+    void prefetch(uint64_t hfull) const { __builtin_prefetch(&slots[(size_t)(hfull & (cap - 1))], 1, 1); }
     void grow()                                                      // :122-155, entries re-filed in old slot order
     {
-        std::vector<int32_t> old;
-        old.swap(slots);
+        const slot_t *old = slots;
         const uint64_t oldcap = cap;
         cap *= 2;
-        slots.assign((size_t)cap, -1);
+        if (nxt->size() < cap) nxt->resize((size_t)cap);
+        std::swap(cur, nxt);
+        slots = cur->data();
+        memset(slots, 0, sizeof(slot_t) * (size_t)cap);
+        const uint64_t mask = cap - 1;
+        constexpr int B = 32;
+        slot_t pend[B];
+        int np = 0;
+        auto flush = [&]() {
+            for (int k = 0; k < np; k++) {
+                uint64_t h = pend[k] & mask;
+                while (slots[h]) h = (h + 1) & mask;
+                slots[h] = pend[k];
+            }
+            np = 0;
+        };
         for (uint64_t i = 0; i < oldcap; i++) {
-            if (old[i] < 0) continue;
-            uint64_t h = hash(keys.data() + (size_t)old[i] * d) % cap;
-            while (slots[h] >= 0) { h++; if (h == cap) h = 0; }
-            slots[h] = old[i];
+            if (!old[i]) continue;
+            __builtin_prefetch(&slots[(size_t)(old[i] & mask)], 1, 1);
+            pend[np] = old[i];
+            if (++np == B) flush();                                  // same order as the one-by-one loop
         }
+        flush();
     }
-    // linear probe from slot h (:65-90); returns the vertex or -1
-    int32_t probe(const int16_t *key, uint64_t h, bool create, bool *created)
+    // linear probe from slot h (:65-90); returns the vertex or -1.  hfull = the key's hash.
+    int32_t probe(const int16_t *key, uint64_t hfull, uint64_t h, bool create, bool *created)
     {
         *created = false;
+        const uint64_t mask = cap - 1;
         for (;;) {
-            const int32_t v = slots[h];
-            if (v < 0) {
+            const slot_t s = slots[h];
+            if (!s) {
                 if (!create) return -1;
                 keys.insert(keys.end(), key, key + d);
-                slots[h] = (int32_t)F;
+                slots[h] = mk(hfull, (int32_t)F);
                 *created = true;
                 return (int32_t)(F++);
             }
-            if (memcmp(keys.data() + (size_t)v * d, key, sizeof(int16_t) * d) == 0) return v;
-            h++;
-            if (h == cap) h = 0;
+            if ((uint32_t)s == (uint32_t)hfull && memcmp(keys.data() + (size_t)vertex(s) * d, key, sizeof(int16_t) * d) == 0)
+                return vertex(s);
+            h = (h + 1) & mask;
         }
     }
-    int32_t lookup(const int16_t *key, bool create, bool *created) { return probe(key, hash(key) % cap, create, created); }
+    int32_t lookup(const int16_t *key, bool create, bool *created)
+    {
+        const uint64_t hf = hash(key);
+        return probe(key, hf, hf & (cap - 1), create, created);
+    }
+    int32_t lookup_hashed(const int16_t *key, uint64_t hf, bool create, bool *created)
+    {
+        return probe(key, hf, hf & (cap - 1), create, created);
+    }
 };
 
 struct dup_key {
@@ -111,8 +157,15 @@ struct dup_key {
 int phl_reference_table_sim(const int16_t *keys_clean, const int32_t *efirst, int64_t M, int d, int64_t N,
                             phl_reftable_query &q, phl_reftable_result &out)
 {
+    const auto t_begin = std::chrono::steady_clock::now();
+    double t_query = 0, t_grow = 0, t_hash = 0, t_loop = 0;
     ref_sim sim(d);
     sim.keys.reserve((size_t)(M + 64) * d);
+    // hashes of the clean keys up front (a streaming pass), so that the creation loop can prefetch its slots
+    std::vector<uint64_t> hclean((size_t)M);
+    for (int64_t v = 0; v < M; v++) hclean[(size_t)v] = sim.hash(keys_clean + (size_t)v * d);
+    constexpr int64_t AHEAD = 12;
+    t_hash = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
     std::vector<int32_t> primary((size_t)M, -1);
     std::vector<dup_key> dups;
     std::unordered_map<int, int> dup_index;
@@ -139,14 +192,19 @@ int phl_reference_table_sim(const int16_t *keys_clean, const int32_t *efirst, in
             const int64_t eg = t_last + 1;
             if (eg >= N) break;                       // that lookup is blur's first one: below
             const bool first_touch = vi < M && efirst[vi] == eg;
+            const auto tq0 = std::chrono::steady_clock::now();
             int K = first_touch ? (int)vi : q.vid_at(eg);
+            t_query += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tq0).count();
             if (K < 0 || K >= M) return PHL_ERR_INVALID;
             const int16_t *key = key_of(K);
-            const uint64_t h_old = sim.hash(key) % sim.cap;     // :102, computed before grow()
+            const uint64_t hf = hclean[(size_t)K];
+            const uint64_t h_old = hf % sim.cap;                // :102, computed before grow()
+            const auto tg0 = std::chrono::steady_clock::now();
             sim.grow();
-            const uint64_t h_new = sim.hash(key) % sim.cap;
+            t_grow += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tg0).count();
+            const uint64_t h_new = hf % sim.cap;
             bool created = false;
-            const int32_t r = sim.probe(key, h_old, true, &created);
+            const int32_t r = sim.probe(key, hf, h_old, true, &created);
             if (first_touch) {
                 primary[K] = r;
                 vi++;
@@ -166,7 +224,9 @@ int phl_reference_table_sim(const int16_t *keys_clean, const int32_t *efirst, in
                     dups[i].seg.push_back({(int32_t)(eg + 1), rr});
                 } else if (dups[i].pending_e <= eg) {
                     // only an unreachable copy exists: the key's next lookup will append another vertex
+                    const auto tq1 = std::chrono::steady_clock::now();
                     const int64_t en = q.next_occurrence(dups[i].clean, eg);
+                    t_query += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tq1).count();
                     dups[i].pending_e = en;
                     if (en >= 0) pending.push({en, (int)i});
                 }
@@ -180,7 +240,8 @@ int phl_reference_table_sim(const int16_t *keys_clean, const int32_t *efirst, in
         if (e_c == INF && e_p == INF) break;
         bool created = false;
         if (e_c <= e_p) {
-            const int32_t r = sim.lookup(key_of((int)vi), true, &created);
+            if (vi + AHEAD < M) sim.prefetch(hclean[(size_t)(vi + AHEAD)]);
+            const int32_t r = sim.lookup_hashed(key_of((int)vi), hclean[(size_t)vi], true, &created);
             if (!created) return PHL_ERR_INVALID;     // a clean first touch must be new to the table
             primary[vi] = r;
             vi++;
@@ -195,6 +256,7 @@ int phl_reference_table_sim(const int16_t *keys_clean, const int32_t *efirst, in
         }
     }
 
+    t_loop = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
     // blur()'s lookups (create = false) grow the table too when splat left it at the threshold (:62 has no
     // `create` test); the first neighbour lookup -- axis 0, vertex 0, key+1 with coordinate 0 at key-d
     // (:504-509) -- is then the one probed from a stale slot.
@@ -204,17 +266,16 @@ int phl_reference_table_sim(const int16_t *keys_clean, const int32_t *efirst, in
         std::vector<int16_t> n1(d);
         for (int i = 0; i < d; i++) n1[i] = (int16_t)(sim.keys[i] + 1);
         n1[0] = (int16_t)(sim.keys[0] - d);
-        const uint64_t h_old = sim.hash(n1.data()) % sim.cap;
+        const uint64_t hf = sim.hash(n1.data());
+        const uint64_t h_old = hf % sim.cap;
         sim.grow();
         bool c;
-        out.blur_first_nbr = sim.probe(n1.data(), h_old, false, &c);
+        out.blur_first_nbr = sim.probe(n1.data(), hf, h_old, false, &c);
         out.blur_grow = true;
     }
 
     out.M_ref = sim.F;
-    out.keys.swap(sim.keys);
-    sim.keys = out.keys;                    // the final lookups below still need them
-    out.remap.assign(primary.begin(), primary.end());
+    out.remap.swap(primary);
     out.dup_clean.clear();
     out.dup_ptr.assign(1, 0);
     out.seg_e.clear();
@@ -239,6 +300,12 @@ int phl_reference_table_sim(const int16_t *keys_clean, const int32_t *efirst, in
         out.dup_ptr.push_back((int32_t)out.seg_e.size());
     }
     std::sort(out.hidden.begin(), out.hidden.end());
+    out.keys.swap(sim.keys);                // (after the final lookups above, which compare keys)
+    static const bool dbg = getenv("PHL_DEBUG") != nullptr;
+    if (dbg)
+        fprintf(stderr, "[phl] reference-table replay: M %lld -> %lld, %zu tracked keys, hashes by %.2f, loop done by %.2f (grow %.2f), total %.2f ms (of which %.2f ms in candidate queries)\n",
+                (long long)M, (long long)out.M_ref, dups.size(), t_hash, t_loop, t_grow,
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count(), t_query);
     return PHL_OK;
 }
 
@@ -318,6 +385,9 @@ int phl_apply_reference_table(phl_lattice *lat, const int *flag, const int *rank
     lat->n_hidden = 0;
     lat->nbr00_override = -2;
     if (M < (1 << 14) - 1) return PHL_OK;            // the reference's table never doubles: nothing to reproduce
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count(); };
+    static const bool dbg = getenv("PHL_DEBUG") != nullptr;
     temp_pool tmp;
     int *efirst_dev, *scratch;
     PHL_HIP(tmp.get(&efirst_dev, (size_t)M));
@@ -329,6 +399,7 @@ int phl_apply_reference_table(phl_lattice *lat, const int *flag, const int *rank
     PHL_HIP(hipMemcpyAsync(keys.data(), lat->vkeys, sizeof(int16_t) * keys.size(), hipMemcpyDeviceToHost, st));
     PHL_HIP(hipMemcpyAsync(efirst.data(), efirst_dev, sizeof(int32_t) * efirst.size(), hipMemcpyDeviceToHost, st));
     PHL_HIP(hipStreamSynchronize(st));
+    if (dbg) fprintf(stderr, "[phl] reference table: keys + first touches on the host after %.2f ms\n", since());
 
     device_query q;
     q.replay = lat->replay;
@@ -364,6 +435,7 @@ int phl_apply_reference_table(phl_lattice *lat, const int *flag, const int *rank
         lat->vkeys = vkeys_new;
         lat->M = R.M_ref;
     }
+    if (dbg) fprintf(stderr, "[phl] reference table: applied after %.2f ms\n", since());
     lat->n_hidden = (int)R.hidden.size();
     for (int i = 0; i < lat->n_hidden; i++) lat->hidden[i] = R.hidden[i];
     if (R.blur_grow) lat->nbr00_override = R.blur_first_nbr;

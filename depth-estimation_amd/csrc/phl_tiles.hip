@@ -458,7 +458,7 @@ __global__ __launch_bounds__(TPB_S) void k_splat_tiled(const float *__restrict__
     if (nv <= nv_lo || nv > nv_hi) return;
     float *rows = lds;                                             // [P][SL] staged pixel rows + one row of zeros
     uint2 *ent = reinterpret_cast<uint2 *>(lds + (size_t)(P + 1) * SL);
-    int4 *meta = reinterpret_cast<int4 *>(ent + P * dp1);          // [nv_cap] {seg begin, seg end, slot_vert, slot_pidx}
+    int2 *meta = reinterpret_cast<int2 *>(ent + P * dp1);          // [nv_cap] {seg begin | seg end << 16, destination row}
     int *pixl = reinterpret_cast<int *>(meta + nv_cap);           // [P]
     int *ctr = pixl + P;                                           // two work counters, used by alternate slabs; [2] = #long segments
     // Loads are issued UNCONDITIONALLY from clamped (always valid) addresses and only the LDS
@@ -479,7 +479,9 @@ __global__ __launch_bounds__(TPB_S) void k_splat_tiled(const float *__restrict__
     for (int k = threadIdx.x; k < cnt; k += TPB_S) pixl[k] = pix_order[base + k];
     for (int i = threadIdx.x; i < nv; i += TPB_S) {
         const int2 rg = seg_rng[vbase + i];
-        meta[i] = make_int4((int)(rg.x - ebase), (int)(rg.y - ebase), slot_vert[vbase + i], slot_pidx[vbase + i]);
+        // destination: the vertex row (bit 31 set) if this chunk is the vertex's only contributor, else a partial row
+        const int sv = slot_vert[vbase + i];
+        meta[i] = make_int2((int)(rg.x - ebase) | ((int)(rg.y - ebase) << 16), sv < 0 ? sv : slot_pidx[vbase + i]);
         // Local vertices come in descending segment length (k_chunk_sort), so the LONG ones (>= long_seg entries:
         // summed by a whole wavefront, below) are a prefix; its length is written by exactly one thread.
         const bool lng = rg.y - rg.x >= long_seg;
@@ -544,13 +546,13 @@ __global__ __launch_bounds__(TPB_S) void k_splat_tiled(const float *__restrict__
         for (int gi = wave; gi < nitems;) {
             const bool coop = gi < nlong;                       // wave-uniform
             const int i = coop ? gi : nlong + (gi - nlong) * Q + q;
-            int4 m = make_int4(0, 0, 0, 0);
+            int2 m = make_int2(0, 0);
             if (i < nv) m = meta[i];
             int nxt = 0;
             if (lane == 0) nxt = atomicAdd(slab_ctr, 1);       // next item, fetched under this one's work
-            const int s1 = m.y;
+            const int s1 = (int)((unsigned)m.x >> 16);
             float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-            int s = m.x;
+            int s = m.x & 0xFFFF;
             if constexpr (LPRS >= 16) {
                 // A lane group is one or more whole 16-lane DPP rows.  Each row keeps SIXTEEN entries of its
                 // vertex's segment in registers, one per lane (a single 8-byte LDS read per lane), and hands
@@ -619,7 +621,7 @@ __global__ __launch_bounds__(TPB_S) void k_splat_tiled(const float *__restrict__
             }
             }
             if (i < nv && chok && !(coop && q != 0)) {
-                float *dst = m.z < 0 ? vert + (int64_t)(m.z & 0x7FFFFFFF) * vd : partial + (int64_t)m.w * vd;
+                float *dst = m.y < 0 ? vert + (int64_t)(m.y & 0x7FFFFFFF) * vd : partial + (int64_t)m.y * vd;
                 st4(dst + ch, acc);
             }
             gi = __builtin_amdgcn_readfirstlane(nxt);
@@ -668,13 +670,13 @@ __global__ __launch_bounds__(256) void k_splat_reduce(const float *__restrict__ 
             float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
             int e = beg;
             for (; e + 4 <= end; e += 4) {
-                const float4 q0 = ld4(partial + (int64_t)slot_pidx[vs[e].pixel] * vd + ch);
-                const float4 q1 = ld4(partial + (int64_t)slot_pidx[vs[e + 1].pixel] * vd + ch);
-                const float4 q2 = ld4(partial + (int64_t)slot_pidx[vs[e + 2].pixel] * vd + ch);
-                const float4 q3 = ld4(partial + (int64_t)slot_pidx[vs[e + 3].pixel] * vd + ch);
+                const float4 q0 = ld4(partial + (int64_t)__float_as_int(vs[e].w) * vd + ch);
+                const float4 q1 = ld4(partial + (int64_t)__float_as_int(vs[e + 1].w) * vd + ch);
+                const float4 q2 = ld4(partial + (int64_t)__float_as_int(vs[e + 2].w) * vd + ch);
+                const float4 q3 = ld4(partial + (int64_t)__float_as_int(vs[e + 3].w) * vd + ch);
                 acc = add4(add4(add4(add4(acc, q0), q1), q2), q3);
             }
-            for (; e < end; e++) acc = add4(acc, ld4(partial + (int64_t)slot_pidx[vs[e].pixel] * vd + ch));
+            for (; e < end; e++) acc = add4(acc, ld4(partial + (int64_t)__float_as_int(vs[e].w) * vd + ch));
             st4(vert + v * vd + ch, acc);
         }
     }
@@ -703,14 +705,14 @@ __global__ __launch_bounds__(256) void k_splat_reduce_long(const float *__restri
         const int ch = chok ? c0 + l * 4 : 0;
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         int e = b0 + jg;
-        for (; e + 3 * NG < b1; e += 4 * NG) {
-            const float4 q0 = ld4(partial + (int64_t)slot_pidx[vs[e].pixel] * vd + ch);
-            const float4 q1 = ld4(partial + (int64_t)slot_pidx[vs[e + NG].pixel] * vd + ch);
-            const float4 q2 = ld4(partial + (int64_t)slot_pidx[vs[e + 2 * NG].pixel] * vd + ch);
-            const float4 q3 = ld4(partial + (int64_t)slot_pidx[vs[e + 3 * NG].pixel] * vd + ch);
-            acc = add4(add4(add4(add4(acc, q0), q1), q2), q3);
+        for (; e + 7 * NG < b1; e += 8 * NG) {               // eight row loads in flight per lane group
+            float4 q[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) q[u] = ld4(partial + (int64_t)__float_as_int(vs[e + u * NG].w) * vd + ch);
+#pragma unroll
+            for (int u = 0; u < 8; u++) acc = add4(acc, q[u]);
         }
-        for (; e < b1; e += NG) acc = add4(acc, ld4(partial + (int64_t)slot_pidx[vs[e].pixel] * vd + ch));
+        for (; e < b1; e += NG) acc = add4(acc, ld4(partial + (int64_t)__float_as_int(vs[e].w) * vd + ch));
         red[threadIdx.x] = acc;
         __syncthreads();
         if (jg == 0 && chok) {
@@ -722,72 +724,65 @@ __global__ __launch_bounds__(256) void k_splat_reduce_long(const float *__restri
     }
 }
 
-template <int LPRS, bool EXACT>
-__global__ __launch_bounds__(TPB) void k_slice_tiled(const float *__restrict__ vert, int vd, int n, int P, int dp1,
-                                                     int rows_cap, const int *__restrict__ pix_order,
-                                                     const int *__restrict__ vptr, const int *__restrict__ slot_vert,
-                                                     const unsigned short *__restrict__ lidx,
-                                                     const phl_replay_t *__restrict__ replay, float *__restrict__ out,
-                                                     int64_t out_rs, const float *__restrict__ sub_src, int64_t sub_rs,
-                                                     float cdiv, float rcdiv, int nchunks, int xcd_chunk,
-                                                     const int *__restrict__ chunk_list, int nv_lo, int nv_hi)
+// One workgroup per chunk; the SLAB WIDTH IS CHOSEN BY THE WORKGROUP from its own chunk: 2^LSH lanes (of 4 floats)
+// per row, the widest (up to `lsh_max`) whose nv staged vertex rows fit next to the index data in the `lds_bytes`
+// the launch was given.  A typical chunk of a natural image has 20-60 local vertices and takes all 256 channels in
+// one slab, a textured one with 300 takes 32-channel slabs, and neither decides for the other (round 2 sized every
+// chunk for the worst one).  A chunk whose rows do not fit even the narrowest slab gathers them from global memory
+// (DIRECT: pixels that share next to nothing -- there is nothing to stage).  The width is a template parameter of
+// the body (a workgroup-uniform switch in the kernel): with a run-time width the same loops ran 40 % slower.
+struct slice_args {
+    const float *vert;
+    int vd, dp1, cnt, nv;
+    float *out;
+    int64_t out_rs;
+    const float *sub_src;
+    int64_t sub_rs;
+    float cdiv, rcdiv;
+};
+
+template <int LSH, bool EXACT, bool DIRECT>
+__device__ __forceinline__ void slice_chunk(const slice_args &a, const uint2 *__restrict__ ent, const int *__restrict__ pixl,
+                                            const int *__restrict__ vl, float *__restrict__ rows)
 {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int LPRS = 1 << LSH;
     constexpr int SL = LPRS * 4;
     constexpr int G = TPB / LPRS;
     const int g = threadIdx.x / LPRS, l = threadIdx.x % LPRS;
-    // XCD-aware chunk order (see k_blur): neighbouring chunks share boundary vertices
-    const int ci = xcd_chunk > 0 ? (int)(blockIdx.x & 7) * xcd_chunk + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
-    if (ci >= nchunks) return;
-    const int c = chunk_list ? chunk_list[ci] : ci;
-    const int base = c * P;
-    const int cnt = min(P, n - base);
-    const int E = cnt * dp1;
-    const int64_t ebase = (int64_t)base * dp1;
-    const int vbase = vptr[c], nv = vptr[c + 1] - vbase;
-    if (nv <= nv_lo || nv > nv_hi) return;     // chunk classes: see phl_launch_slice_tiled
-    float *rows = lds;
-    uint2 *ent = reinterpret_cast<uint2 *>(lds + (size_t)rows_cap * SL);
-    int *pixl = reinterpret_cast<int *>(ent + P * dp1);
-    int *vl = pixl + P;
-    for (int k = threadIdx.x; k < cnt; k += TPB) pixl[k] = pix_order[base + k];
-    for (int i = threadIdx.x; i < nv; i += TPB) vl[i] = slot_vert[vbase + i] & 0x7FFFFFFF;
-    for (int e = threadIdx.x; e < E; e += TPB) {
-        const int k = e / dp1, r = e - k * dp1;
-        const int p = pix_order[base + k];
-        ent[e] = make_uint2((unsigned)lidx[ebase + e] * (SL * 4), __float_as_uint(replay[(int64_t)p * dp1 + r].w));
-    }
-    __syncthreads();
+    const int vd = a.vd, dp1 = a.dp1, cnt = a.cnt, nv = a.nv;
     for (int c0 = 0; c0 < vd; c0 += SL) {
         const int ch = c0 + l * 4;
         const bool chok = ch < vd;
-        {
-            const int chc = chok ? ch : 0;
+        const int chc = chok ? ch : 0;
+        if (!DIRECT) {
             const int iclamp = nv - 1;
             for (int i0 = g; i0 < nv; i0 += 8 * G) {
                 float4 q[8];
 #pragma unroll
-                for (int u = 0; u < 8; u++) q[u] = ld4(vert + (int64_t)vl[min(i0 + u * G, iclamp)] * vd + chc);
+                for (int u = 0; u < 8; u++) q[u] = ld4(a.vert + (int64_t)vl[min(i0 + u * G, iclamp)] * vd + chc);
 #pragma unroll
                 for (int u = 0; u < 8; u++)
                     if (chok && i0 + u * G < nv) st4(rows + (i0 + u * G) * SL + l * 4, q[u]);
             }
+            __syncthreads();
         }
-        __syncthreads();
         const char *rbase = reinterpret_cast<const char *>(rows) + l * 16;
+        const float *gbase = a.vert + chc;
+        auto row = [&](unsigned x) -> float4 {
+            if (DIRECT) return ld4(gbase + (int64_t)x * vd);
+            return *reinterpret_cast<const float4 *>(rbase + x);
+        };
         for (int k = g; k < cnt; k += G) {
             const uint2 *ek = ent + k * dp1;
             float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
             int r = 0;
             for (; r + 3 <= dp1; r += 3) {
                 const uint2 e0 = ek[r], e1 = ek[r + 1], e2 = ek[r + 2];
-                const float4 q0 = *reinterpret_cast<const float4 *>(rbase + e0.x);
-                const float4 q1 = *reinterpret_cast<const float4 *>(rbase + e1.x);
-                const float4 q2 = *reinterpret_cast<const float4 *>(rbase + e2.x);
+                const float4 q0 = row(e0.x), q1 = row(e1.x), q2 = row(e2.x);
                 if (EXACT) {
-                    acc = term4(acc, __uint_as_float(e0.y), q0, cdiv, rcdiv);
-                    acc = term4(acc, __uint_as_float(e1.y), q1, cdiv, rcdiv);
-                    acc = term4(acc, __uint_as_float(e2.y), q2, cdiv, rcdiv);
+                    acc = term4(acc, __uint_as_float(e0.y), q0, a.cdiv, a.rcdiv);
+                    acc = term4(acc, __uint_as_float(e1.y), q1, a.cdiv, a.rcdiv);
+                    acc = term4(acc, __uint_as_float(e2.y), q2, a.cdiv, a.rcdiv);
                 } else {
                     acc = fma4(acc, __uint_as_float(e0.y), q0);
                     acc = fma4(acc, __uint_as_float(e1.y), q1);
@@ -796,22 +791,91 @@ __global__ __launch_bounds__(TPB) void k_slice_tiled(const float *__restrict__ v
             }
             for (; r < dp1; r++) {
                 const uint2 e0 = ek[r];
-                const float4 q0 = *reinterpret_cast<const float4 *>(rbase + e0.x);
-                if (EXACT) acc = term4(acc, __uint_as_float(e0.y), q0, cdiv, rcdiv);
+                const float4 q0 = row(e0.x);
+                if (EXACT) acc = term4(acc, __uint_as_float(e0.y), q0, a.cdiv, a.rcdiv);
                 else acc = fma4(acc, __uint_as_float(e0.y), q0);
             }
             if (chok) {
                 const int p = pixl[k];
-                if (!EXACT) acc = make_float4(acc.x * rcdiv, acc.y * rcdiv, acc.z * rcdiv, acc.w * rcdiv);
-                if (sub_src) {
-                    const float4 s = ld4(sub_src + (int64_t)p * sub_rs + ch);
+                if (!EXACT) acc = make_float4(acc.x * a.rcdiv, acc.y * a.rcdiv, acc.z * a.rcdiv, acc.w * a.rcdiv);
+                if (a.sub_src) {
+                    const float4 s = ld4(a.sub_src + (int64_t)p * a.sub_rs + ch);
                     acc = make_float4(acc.x - s.x, acc.y - s.y, acc.z - s.z, acc.w - s.w);
                 }
-                st4(out + (int64_t)p * out_rs + ch, acc);
+                st4(a.out + (int64_t)p * a.out_rs + ch, acc);
             }
         }
-        __syncthreads();
+        if (!DIRECT) __syncthreads();
     }
+}
+
+template <bool EXACT>
+__global__ __launch_bounds__(TPB) void k_slice_tiled(const float *__restrict__ vert, int vd, int n, int P, int dp1,
+                                                     int lsh_max, int lds_bytes, const int *__restrict__ pix_order,
+                                                     const int *__restrict__ vptr, const int *__restrict__ slot_vert,
+                                                     const unsigned short *__restrict__ lidx,
+                                                     const phl_replay_t *__restrict__ replay, float *__restrict__ out,
+                                                     int64_t out_rs, const float *__restrict__ sub_src, int64_t sub_rs,
+                                                     float cdiv, float rcdiv, int nchunks, int xcd_chunk)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    // XCD-aware chunk order (see k_blur): neighbouring chunks share boundary vertices
+    const int c = xcd_chunk > 0 ? (int)(blockIdx.x & 7) * xcd_chunk + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    if (c >= nchunks) return;
+    const int base = c * P;
+    const int cnt = min(P, n - base);
+    const int E = cnt * dp1;
+    const int64_t ebase = (int64_t)base * dp1;
+    const int vbase = vptr[c], nv = vptr[c + 1] - vbase;
+    // index data first (its size does not depend on the slab width), rows behind it
+    uint2 *ent = reinterpret_cast<uint2 *>(lds);                    // [P*dp1] {row offset or vertex id, weight}
+    int *pixl = reinterpret_cast<int *>(ent + P * dp1);             // [P]
+    int *vl = pixl + P;                                             // [nv]
+    const int fixed = (P * dp1 * 8 + P * 4 + nv * 4 + 15) & ~15;
+    float *rows = reinterpret_cast<float *>(reinterpret_cast<char *>(lds) + fixed);
+    int lsh = lsh_max;                                              // workgroup-uniform
+    while (lsh > 2 && fixed + (int64_t)nv * (16 << lsh) > lds_bytes) lsh--;
+    const bool direct = fixed + (int64_t)nv * (16 << lsh) > lds_bytes;
+    if (direct) lsh = lsh_max;
+    for (int k = threadIdx.x; k < cnt; k += TPB) pixl[k] = pix_order[base + k];
+    if (!direct)
+        for (int i = threadIdx.x; i < nv; i += TPB) vl[i] = slot_vert[vbase + i] & 0x7FFFFFFF;
+    for (int e = threadIdx.x; e < E; e += TPB) {
+        const int k = e / dp1, r = e - k * dp1;
+        const int p = pix_order[base + k];
+        const unsigned li = lidx[ebase + e];
+        // staged: byte offset of the local vertex's LDS row; direct: the vertex id itself
+        ent[e] = make_uint2(direct ? (unsigned)(slot_vert[vbase + li] & 0x7FFFFFFF) : li << (lsh + 4),
+                            __float_as_uint(replay[(int64_t)p * dp1 + r].w));
+    }
+    __syncthreads();
+    slice_args a;
+    a.vert = vert; a.vd = vd; a.dp1 = dp1; a.cnt = cnt; a.nv = nv;
+    a.out = out; a.out_rs = out_rs; a.sub_src = sub_src; a.sub_rs = sub_rs; a.cdiv = cdiv; a.rcdiv = rcdiv;
+    if (direct) {
+        switch (lsh) {
+            case 6: slice_chunk<6, EXACT, true>(a, ent, pixl, vl, rows); break;
+            case 5: slice_chunk<5, EXACT, true>(a, ent, pixl, vl, rows); break;
+            case 4: slice_chunk<4, EXACT, true>(a, ent, pixl, vl, rows); break;
+            case 3: slice_chunk<3, EXACT, true>(a, ent, pixl, vl, rows); break;
+            default: slice_chunk<2, EXACT, true>(a, ent, pixl, vl, rows); break;
+        }
+    } else {
+        switch (lsh) {
+            case 6: slice_chunk<6, EXACT, false>(a, ent, pixl, vl, rows); break;
+            case 5: slice_chunk<5, EXACT, false>(a, ent, pixl, vl, rows); break;
+            case 4: slice_chunk<4, EXACT, false>(a, ent, pixl, vl, rows); break;
+            case 3: slice_chunk<3, EXACT, false>(a, ent, pixl, vl, rows); break;
+            default: slice_chunk<2, EXACT, false>(a, ent, pixl, vl, rows); break;
+        }
+    }
+}
+
+// vs[e].w <- partial-buffer row of the slot (bit pattern of an int): saves the reduce kernels one dependent load
+__global__ __launch_bounds__(256) void k_fill_vs_rows(phl_contrib_t *__restrict__ vs, int S, const int *__restrict__ slot_pidx)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < S) vs[e].w = __int_as_float(slot_pidx[vs[e].pixel]);
 }
 
 __global__ __launch_bounds__(256) void k_flag_long(const int *__restrict__ vs_ptr, int M, int long_list, int *__restrict__ flag)
@@ -878,7 +942,7 @@ int lds_budget()
 }
 
 // bytes of index data staged next to the rows (entries, pixel ids, local pointers)
-inline int64_t lds_extra(int P, int dp1, int nv_max) { return (int64_t)P * dp1 * 8 + (int64_t)P * 4 + ((int64_t)nv_max + 1) * 16 + 16 + 256; }
+inline int64_t lds_extra(int P, int dp1, int nv_max) { return (int64_t)P * dp1 * 8 + (int64_t)P * 4 + ((int64_t)nv_max + 2) * 8 + 16 + 256; }
 // k_slice_tiled keeps less: entries, pixel ids, one vertex id per local vertex
 inline int64_t lds_extra_slice(int P, int dp1, int nv_max) { return (int64_t)P * dp1 * 8 + (int64_t)P * 4 + ((int64_t)nv_max + 4) * 4; }
 
@@ -935,42 +999,104 @@ inline tile_cfg pick_cfg(const phl_lattice *lat, int vd, bool for_slice, int nv)
 // Chunk classes.  A launch's LDS layout is sized by the most local vertices a chunk of it may have.  Sizing every
 // chunk for the worst one (round 2) lets a single textured 16x16 tile narrow the slabs of the whole image: natural
 // images at M/n ~ 0.01 have 30 vertices in a typical chunk and 300 in the worst (0.3 % of the chunks above 158).
-// So the chunks are cut into at most two classes by their vertex count: LIGHT = the preferred configuration that
-// holds at least 3/4 of the chunks, run over the whole grid (the few others exit at once); HEAVY = the rest, a
-// short list (chunks sorted by descending vertex count, built with the lattice) run with the first configuration
-// that holds the worst chunk.
-struct tile_plan {
-    tile_cfg light, heavy;
-    int n_heavy = 0;    // 0: one launch (light) covers everything
+// So the chunks are cut into classes by their vertex count, one launch per class: walking the candidate
+// configurations in order of preference, each one takes the chunks it can hold that no better one took (a class of
+// fewer than MIN_CLASS chunks is left to the next candidate).  The largest class runs over the whole grid in
+// chunk order (chunks of other classes exit at once); the others are contiguous ranges of `chunk_by_nv` (chunk
+// ids by descending vertex count, built with the lattice).
+struct tile_class {
+    tile_cfg cfg;
+    int lo, hi;         // chunks with lo < nv <= hi
+    int begin, count;   // range of chunk_by_nv
+    bool full_grid;
 };
+struct tile_plan {
+    tile_class cls[12];
+    int n = 0;
+};
+constexpr int MIN_CLASS = 64;
+// chunks with more than nv local vertices
 inline int chunks_above(const phl_lattice *lat, int nv) { return nv >= lat->nv_max ? 0 : lat->nchunks - lat->nv_cum[nv < 0 ? 0 : nv]; }
 
 inline tile_plan plan_tiles(const phl_lattice *lat, int vd, bool for_slice)
 {
     tile_plan p;
     const tile_cfg all = pick_cfg(lat, vd, for_slice, lat->nv_max);
-    p.light = all;
+    if (all.lprs < 0) return p;
     static const bool classes = !(getenv("PHL_CLASSES") && atoi(getenv("PHL_CLASSES")) == 0);
-    if (all.lprs < 0 || !classes || !lat->nv_cum || !lat->chunk_by_nv) return p;
     const int P = lat->P, dp1 = lat->d + 1;
-    int lprs;
-    int64_t budget;
-    for (int k = 0; cfg_candidate(vd, for_slice, k, &lprs, &budget); k++) {
-        const int64_t base = for_slice ? slice_lds(P, dp1, lprs, 0) : splat_lds(P, dp1, lprs, 0);
-        if (base > budget) continue;
-        const int64_t per_v = for_slice ? (int64_t)lprs * 16 + 4 : 16;
-        const int cap = (int)((budget - base) / per_v);
-        if (cap >= lat->nv_max) break;                        // this candidate is `all`: one launch does it
-        const int above = chunks_above(lat, cap);
-        if ((int64_t)above * 4 > lat->nchunks) continue;      // holds fewer than 3/4 of the chunks: try the next one
-        p.light.lprs = lprs;
-        p.light.cap = cap;
-        p.light.lds = (size_t)(for_slice ? slice_lds(P, dp1, lprs, cap) : splat_lds(P, dp1, lprs, cap));
-        p.heavy = all;
-        p.n_heavy = above;
-        return p;
+    int covered = -1;                                         // chunks with nv <= covered are taken
+    if (classes && lat->nv_cum && lat->chunk_by_nv) {
+        int lprs;
+        int64_t budget;
+        for (int k = 0; covered < lat->nv_max && cfg_candidate(vd, for_slice, k, &lprs, &budget); k++) {
+            const int64_t base = for_slice ? slice_lds(P, dp1, lprs, 0) : splat_lds(P, dp1, lprs, 0);
+            if (base > budget) continue;
+            const int64_t per_v = for_slice ? (int64_t)lprs * 16 + 4 : 8;
+            int cap = (int)((budget - base) / per_v);
+            if (cap > lat->nv_max) cap = lat->nv_max;
+            if (cap <= covered) continue;
+            const int count = chunks_above(lat, covered) - chunks_above(lat, cap);
+            if (cap < lat->nv_max && count < MIN_CLASS) continue;
+            if (count == 0) { covered = cap; continue; }
+            tile_class &c = p.cls[p.n++];
+            c.cfg.lprs = lprs;
+            c.cfg.cap = cap;
+            c.cfg.lds = (size_t)(for_slice ? slice_lds(P, dp1, lprs, cap) : splat_lds(P, dp1, lprs, cap));
+            c.lo = covered;
+            c.hi = cap;
+            c.begin = chunks_above(lat, cap);
+            c.count = count;
+            c.full_grid = false;
+            covered = cap;
+            if (p.n == 11) break;
+        }
     }
+    if (covered < lat->nv_max) {                              // no classes, or candidates exhausted: `all` takes the rest
+        tile_class &c = p.cls[p.n++];
+        c.cfg = all;
+        c.lo = covered;
+        c.hi = 0x7FFFFFFF;
+        c.begin = 0;
+        c.count = chunks_above(lat, covered);
+        c.full_grid = false;
+    }
+    int big = 0;
+    for (int i = 1; i < p.n; i++)
+        if (p.cls[i].count > p.cls[big].count) big = i;
+    p.cls[big].full_grid = true;
+    if (p.n == 1) { p.cls[0].lo = -1; p.cls[0].hi = 0x7FFFFFFF; }
+    static const bool dbg = getenv("PHL_DEBUG") != nullptr;
+    if (dbg)
+        for (int i = 0; i < p.n; i++)
+            fprintf(stderr, "[phl] %s vd=%d class %d/%d: %d < nv <= %d, %d chunks, %d lanes, %zu B LDS%s\n", for_slice ? "slice" : "splat",
+                    vd, i, p.n, p.cls[i].lo, p.cls[i].hi, p.cls[i].count, p.cls[i].cfg.lprs, p.cls[i].cfg.lds,
+                    p.cls[i].full_grid ? " (whole grid)" : "");
     return p;
+}
+
+// The slice picks its slab width per workgroup (k_slice_tiled); the launch only fixes the widest slab worth
+// having (as wide as vd) and the LDS per workgroup: what the worst chunk needs at that width, at most the budget
+// of two workgroups per CU (the index data alone, P*(8(d+1)+4) bytes, is always below it).
+struct slice_cfg {
+    int lsh_max;
+    size_t lds;
+};
+inline slice_cfg plan_slice(const phl_lattice *lat, int vd)
+{
+    const int need = (vd + 3) / 4;
+    int lsh = 2;
+    while (lsh < 6 && (1 << lsh) < need) lsh++;
+    static const int max_w = getenv("PHL_MAX_LPRS_SLICE") ? atoi(getenv("PHL_MAX_LPRS_SLICE")) : 64;   // experiments
+    while (lsh > 2 && (1 << lsh) > max_w) lsh--;
+    const int P = lat->P, dp1 = lat->d + 1;
+    const int64_t fixed = (((int64_t)P * dp1 * 8 + (int64_t)P * 4 + (int64_t)lat->nv_max * 4 + 15) & ~(int64_t)15);
+    int64_t lds = fixed + (int64_t)lat->nv_max * (16 << lsh);
+    if (lds > lds_budget()) lds = lds_budget();     // chunks that do not fit take narrower slabs, or go direct
+    slice_cfg c;
+    c.lsh_max = lsh;
+    c.lds = (size_t)lds;
+    return c;
 }
 
 template <typename K>
@@ -1087,6 +1213,8 @@ int phl_tiles_link_vertices(phl_lattice *lat, hipStream_t st)
     PHL_HIP(hipGetLastError());
     rc = exclusive_scan(multi, lat->slot_pidx, S, tile_sums, st);
     if (rc) return rc;
+    hipLaunchKernelGGL(k_fill_vs_rows, dim3(gS), dim3(256), 0, st, lat->vs, S, lat->slot_pidx);
+    PHL_HIP(hipGetLastError());
     int s_multi = 0;
     PHL_HIP(hipMemcpyAsync(&s_multi, lat->slot_pidx + S, sizeof(int), hipMemcpyDeviceToHost, st));
     // vertices with long slot lists (k_splat_reduce_long): flag, scan, compact
@@ -1339,7 +1467,8 @@ int phl_tiles_build(phl_lattice *lat, const float *ref, int64_t rs, int64_t cs, 
 int phl_tiles_lprs(const phl_lattice *lat, int vd, int for_slice)
 {
     if (lat->nchunks == 0 || vd % 4 != 0) return -1;
-    return pick_cfg(lat, vd, for_slice != 0, lat->nv_max).lprs;
+    if (for_slice) return 1 << plan_slice(lat, vd).lsh_max;      // any chunk: the workgroup picks its own slab width
+    return pick_cfg(lat, vd, false, lat->nv_max).lprs;
 }
 
 // which chunks hold a slot of any of the listed vertex rows
@@ -1387,48 +1516,42 @@ int phl_launch_splat_tiled(phl_lattice *lat, const float *src, int64_t src_rs, i
     const int M = subset ? (int)nvl : (int)lat->M;
     if (lat->M == 0 || vd == 0) return PHL_OK;
     const tile_plan plan = plan_tiles(lat, vd, false);
-    if (plan.light.lprs < 0) {
+    if (plan.n == 0) {
         phl_set_error("tiled splat: chunk does not fit LDS");
         return PHL_ERR_UNSUPPORTED;
     }
     int rc = PHL_OK;
-    unsigned cgrid;
-    int xcd_chunk;
     const int nrun = subset ? nlist : lat->nchunks;
-    chunk_grid(nrun, &cgrid, &xcd_chunk);
-    static const char *tl_path = getenv("PHL_TIMELINE");     // debug: dump per-workgroup time stamps of this launch
+    static const char *tl_path = getenv("PHL_TIMELINE");     // debug: dump per-workgroup time stamps of the main launch
     unsigned long long *tl = nullptr;
-    const size_t tl_n = (size_t)cgrid * 8;
-    if (tl_path) {
-        PHL_HIP(phl_dev_malloc((void **)&tl, tl_n * 8));
-        PHL_HIP(hipMemsetAsync(tl, 0, tl_n * 8, st));
-    }
-    // light class (or everything): the caller's chunk list / the whole grid; chunks of the other class exit at once
-    const int split = plan.n_heavy > 0 ? plan.light.cap : 0x7FFFFFFF;
-    if (nrun > 0) dispatch_lprs(plan.light.lprs, [&](auto L) {
-        constexpr int LPRS = decltype(L)::value;
-        if ((rc = allow_lds(k_splat_tiled<LPRS>, plan.light.lds)) != PHL_OK) return;
-        k_splat_tiled<LPRS><<<dim3(cgrid), dim3(TPB_S), plan.light.lds, st>>>(
-            src, src_rs, vd, (int)lat->n, lat->P, lat->d + 1, plan.light.cap, lat->pix_order, lat->chunk_vptr, lat->slot_vert,
-            lat->slot_pidx, lat->seg_rng, lat->seg, vert, partial, nrun, xcd_chunk, tl, chunk_list, -1, split, long_seg());
-    });
-    // heavy class: the short list of chunks above the split (of a subset: the same list, filtered in the kernel)
-    if (rc == PHL_OK && nrun > 0 && plan.n_heavy > 0) {
-        const int *hlist = subset ? chunk_list : lat->chunk_by_nv;
-        const int hn = subset ? nlist : plan.n_heavy;
-        unsigned hgrid;
-        int hxcd;
-        chunk_grid(hn, &hgrid, &hxcd);
-        dispatch_lprs(plan.heavy.lprs, [&](auto L) {
+    size_t tl_n = 0;
+    for (int ci = 0; ci < plan.n && rc == PHL_OK && nrun > 0; ci++) {
+        const tile_class &c = plan.cls[ci];
+        // the largest class (and every class of a caller's subset) walks the whole grid / list in chunk order and
+        // filters by vertex count in the kernel; the others run exactly their range of chunk_by_nv
+        const bool filtered = subset || c.full_grid;
+        const int *list = subset ? chunk_list : (c.full_grid ? nullptr : lat->chunk_by_nv + c.begin);
+        const int cnt = filtered ? nrun : c.count;
+        if (cnt == 0) continue;
+        unsigned cgrid;
+        int xcd_chunk;
+        chunk_grid(cnt, &cgrid, &xcd_chunk);
+        unsigned long long *tlc = nullptr;
+        if (tl_path && c.full_grid && !tl) {
+            tl_n = (size_t)cgrid * 8;
+            PHL_HIP(phl_dev_malloc((void **)&tl, tl_n * 8));
+            PHL_HIP(hipMemsetAsync(tl, 0, tl_n * 8, st));
+            tlc = tl;
+        }
+        dispatch_lprs(c.cfg.lprs, [&](auto L) {
             constexpr int LPRS = decltype(L)::value;
-            if ((rc = allow_lds(k_splat_tiled<LPRS>, plan.heavy.lds)) != PHL_OK) return;
-            k_splat_tiled<LPRS><<<dim3(hgrid), dim3(TPB_S), plan.heavy.lds, st>>>(
-                src, src_rs, vd, (int)lat->n, lat->P, lat->d + 1, plan.heavy.cap, lat->pix_order, lat->chunk_vptr,
-                lat->slot_vert, lat->slot_pidx, lat->seg_rng, lat->seg, vert, partial, hn, hxcd, nullptr, hlist, split,
-                0x7FFFFFFF, long_seg());
+            if ((rc = allow_lds(k_splat_tiled<LPRS>, c.cfg.lds)) != PHL_OK) return;
+            k_splat_tiled<LPRS><<<dim3(cgrid), dim3(TPB_S), c.cfg.lds, st>>>(
+                src, src_rs, vd, (int)lat->n, lat->P, lat->d + 1, c.cfg.cap, lat->pix_order, lat->chunk_vptr, lat->slot_vert,
+                lat->slot_pidx, lat->seg_rng, lat->seg, vert, partial, cnt, xcd_chunk, tlc, list, c.lo, c.hi, long_seg());
         });
     }
-    if (tl) {
+    if (tl) {                                                 // debug only
         std::vector<unsigned long long> h(tl_n);
         PHL_HIP(hipMemcpyAsync(h.data(), tl, tl_n * 8, hipMemcpyDeviceToHost, st));
         PHL_HIP(hipStreamSynchronize(st));
@@ -1469,37 +1592,25 @@ int phl_launch_slice_tiled(const phl_lattice *lat, const float *vert, int vd, fl
                            int64_t sub_rs, unsigned flags, hipStream_t st)
 {
     if (lat->n == 0 || vd == 0) return PHL_OK;
-    const tile_plan plan = plan_tiles(lat, vd, true);
-    if (plan.light.lprs < 0) {
-        phl_set_error("tiled slice: chunk does not fit LDS");
-        return PHL_ERR_UNSUPPORTED;
-    }
+    const slice_cfg cfg = plan_slice(lat, vd);
     const float cdiv = 1 + powf(2, -lat->d);  // permutohedral.h:480
     const float rcdiv = 1.0f / cdiv;
     const bool exact = (flags & PHL_FILTER_EXACT) != 0;
     int rc = PHL_OK;
-    const int split = plan.n_heavy > 0 ? plan.light.cap : 0x7FFFFFFF;
-    auto launch = [&](const tile_cfg &cfg, int nrun, const int *list, int lo, int hi) {
-        unsigned cgrid;
-        int xcd_chunk;
-        chunk_grid(nrun, &cgrid, &xcd_chunk);
-        dispatch_lprs(cfg.lprs, [&](auto L) {
-            constexpr int LPRS = decltype(L)::value;
-            if (exact) {
-                if ((rc = allow_lds(k_slice_tiled<LPRS, true>, cfg.lds)) != PHL_OK) return;
-                k_slice_tiled<LPRS, true><<<dim3(cgrid), dim3(TPB), cfg.lds, st>>>(
-                    vert, vd, (int)lat->n, lat->P, lat->d + 1, cfg.cap, lat->pix_order, lat->chunk_vptr, lat->slot_vert,
-                    lat->lidx, lat->replay, out, out_rs, sub, sub_rs, cdiv, rcdiv, nrun, xcd_chunk, list, lo, hi);
-            } else {
-                if ((rc = allow_lds(k_slice_tiled<LPRS, false>, cfg.lds)) != PHL_OK) return;
-                k_slice_tiled<LPRS, false><<<dim3(cgrid), dim3(TPB), cfg.lds, st>>>(
-                    vert, vd, (int)lat->n, lat->P, lat->d + 1, cfg.cap, lat->pix_order, lat->chunk_vptr, lat->slot_vert,
-                    lat->lidx, lat->replay, out, out_rs, sub, sub_rs, cdiv, rcdiv, nrun, xcd_chunk, list, lo, hi);
-            }
-        });
-    };
-    launch(plan.light, lat->nchunks, nullptr, -1, split);
-    if (rc == PHL_OK && plan.n_heavy > 0) launch(plan.heavy, plan.n_heavy, lat->chunk_by_nv, split, 0x7FFFFFFF);
+    unsigned cgrid;
+    int xcd_chunk;
+    chunk_grid(lat->nchunks, &cgrid, &xcd_chunk);
+    if (exact) {
+        if ((rc = allow_lds(k_slice_tiled<true>, cfg.lds)) != PHL_OK) return rc;
+        k_slice_tiled<true><<<dim3(cgrid), dim3(TPB), cfg.lds, st>>>(
+            vert, vd, (int)lat->n, lat->P, lat->d + 1, cfg.lsh_max, (int)cfg.lds, lat->pix_order, lat->chunk_vptr, lat->slot_vert,
+            lat->lidx, lat->replay, out, out_rs, sub, sub_rs, cdiv, rcdiv, lat->nchunks, xcd_chunk);
+    } else {
+        if ((rc = allow_lds(k_slice_tiled<false>, cfg.lds)) != PHL_OK) return rc;
+        k_slice_tiled<false><<<dim3(cgrid), dim3(TPB), cfg.lds, st>>>(
+            vert, vd, (int)lat->n, lat->P, lat->d + 1, cfg.lsh_max, (int)cfg.lds, lat->pix_order, lat->chunk_vptr, lat->slot_vert,
+            lat->lidx, lat->replay, out, out_rs, sub, sub_rs, cdiv, rcdiv, lat->nchunks, xcd_chunk);
+    }
     if (rc) return rc;
     PHL_HIP(hipGetLastError());
     return PHL_OK;

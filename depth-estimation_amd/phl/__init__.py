@@ -521,9 +521,11 @@ _cache = OrderedDict()
 _cache_lock = threading.Lock()
 
 
-# PHL_REFERENCE_TABLE=1: the drop-in ``filter(src, ref)`` builds its lattices with the reference's table
-# behaviour (Lattice(reference_table=True)) -- for users who want the reference's exact vertices above M = 16383
-_REFERENCE_TABLE = os.environ.get("PHL_REFERENCE_TABLE", "0") not in ("", "0")
+# The drop-in boundary -- ``filter(src, ref)`` and everything of ``crf.*`` that reaches it through ``lattice_for`` --
+# builds its lattices with the REFERENCE'S table behaviour (Lattice(reference_table=True): its duplicate vertices
+# above M = 16383 included), so that what replaces ``lattice.filter`` returns what ``lattice.filter`` returned at
+# any size.  PHL_REFERENCE_TABLE=0 selects the defect-free table instead (one vertex per key; a few ms less per build).
+_REFERENCE_TABLE = os.environ.get("PHL_REFERENCE_TABLE", "1") not in ("", "0")
 
 
 def _cache_key(ref, device=None):

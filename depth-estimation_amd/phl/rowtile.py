@@ -258,6 +258,7 @@ class RowTileFilter:
         self._fused = hasattr(self.band.eng, "gather_rows") and self.comm_device == self.band.device
         self._vert = self._scratch = self._sbuf = self._ops = None
         self._plan, self._edge_first = None, False
+        self._stub_exchange = False      # timing probes only: run the step without its point-to-point exchange
         if self._fused:
             M = self.band.M
             self._vert = [torch.empty((M, c1 - c0), dtype=torch.float32, device=device) for c0, c1 in self.groups]
@@ -341,7 +342,7 @@ class RowTileFilter:
                 keep.append(snd)
                 ops.append(dist.P2POp(dist.isend, snd.contiguous(), peer))
                 ops.append(dist.P2POp(dist.irecv, self._rbuf[gi][peer], peer))
-            reqs = dist.batch_isend_irecv(ops) if ops else []
+            reqs = dist.batch_isend_irecv(ops) if (ops and not self._stub_exchange) else []
             pending.append((vert, reqs, keep))
         for gi, (c0, c1) in enumerate(self.groups):
             vert, reqs, _ = pending[gi]
@@ -357,7 +358,7 @@ class RowTileFilter:
         vert, sbuf = self._vert[0], self._sbuf[0]
         eng.splat_part(src, vert, pl["partial"], pl["edge"], pl["send_rows"])        # boundary rows complete
         eng.gather_rows(vert, band._send_all, out=sbuf)
-        reqs = dist.batch_isend_irecv(self._ops[0]) if self._ops[0] else []          # ... and on their way
+        reqs = dist.batch_isend_irecv(self._ops[0]) if (self._ops[0] and not self._stub_exchange) else []   # ... and on their way
         eng.splat_part(src, vert, pl["partial"], pl["interior"], pl["other_rows"])   # the rest, under the exchange
         for req in reqs:
             req.wait()
@@ -372,12 +373,66 @@ class RowTileFilter:
         reqs = []
         for gi, (c0, c1) in enumerate(self.groups):
             band.splat_outbox(src[:, c0:c1], vert=self._vert[gi], sendbuf=self._sbuf[gi])
-            reqs.append(dist.batch_isend_irecv(self._ops[gi]) if self._ops[gi] else [])
+            reqs.append(dist.batch_isend_irecv(self._ops[gi]) if (self._ops[gi] and not self._stub_exchange) else [])
         for gi, (c0, c1) in enumerate(self.groups):
             for req in reqs[gi]:
                 req.wait()
             band.finish(self._vert[gi], self._rbuf[gi], out=out[:, c0:c1], packed=self._rpack[gi], scratch=self._scratch[gi])
         return out
+
+    def exchange_probe(self, src, out, reps=10):
+        """Where the exchange stands in a step, measured on this rank (wall clock around synchronised loops, so it
+        reads the same under RCCL and under gloo's host staging):
+          exchange_ms            one step's point-to-point exchange alone, nothing overlapping it;
+          step_ms                the whole step;
+          step_no_exchange_ms    the same step with the exchange left out (stale boundary rows: timing only);
+          overlap_hidden_frac    1 - (step - step_no_exchange) / exchange: the share of the exchange that the
+                                 schedule hides behind compute (1 = free, 0 = fully exposed).
+        Every rank must call it (the exchange is collective among neighbours)."""
+        dist, dev = self.dist, self.band.device
+
+        def sync():
+            if dev.type == "cuda":
+                torch.cuda.synchronize(dev)
+            dist.barrier()
+
+        def timed(fn):
+            fn()
+            sync()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            if dev.type == "cuda":
+                torch.cuda.synchronize(dev)
+            dt = (time.perf_counter() - t0) / reps * 1e3
+            dist.barrier()
+            return dt
+
+        def exchange_only():
+            for gi in range(len(self.groups)):
+                if self._fused:
+                    ops = self._ops[gi]
+                else:
+                    ops = []
+                    for peer in sorted(self.band.sides):
+                        a, b = self.band._send_rng[peer]
+                        snd = torch.zeros((b - a, self.groups[gi][1] - self.groups[gi][0]), dtype=torch.float32, device=self.comm_device)
+                        ops.append(dist.P2POp(dist.isend, snd, peer))
+                        ops.append(dist.P2POp(dist.irecv, self._rbuf[gi][peer], peer))
+                for req in (dist.batch_isend_irecv(ops) if ops else []):
+                    req.wait()
+
+        step_ms = timed(lambda: self.filter(src, out=out))
+        self._stub_exchange = True
+        try:
+            noex_ms = timed(lambda: self.filter(src, out=out))
+        finally:
+            self._stub_exchange = False
+        ex_ms = timed(exchange_only)
+        self.filter(src, out=out)        # leave `out` holding a real result
+        hidden = 1.0 - max(0.0, step_ms - noex_ms) / ex_ms if ex_ms > 0 else 1.0
+        return {"exchange_ms": round(ex_ms, 4), "step_ms": round(step_ms, 4), "step_no_exchange_ms": round(noex_ms, 4),
+                "overlap_hidden_frac": round(max(0.0, min(1.0, hidden)), 3)}
 
     def describe(self):
         b = self.band

@@ -461,3 +461,28 @@ def test_mean_field_gradient_through_the_lattice_operator():
     with torch.no_grad():
         Qc = mean_field_infer(E0, LatticeGaussian(ref0), Mu, 2)
     assert not Qc.requires_grad and float((Qc - Qb).abs().max()) <= 1e-5
+
+
+def test_compat_softmax_repeatable_under_background_traffic():
+    """Race hunt for k_compat_softmax's LDS rings and counted vmcnt waits (tools/compat_stress.py as a test): 30
+    launches of one C2-sized shape beside memory traffic on a second stream, every result bit-equal to the first."""
+    import phl
+
+    g = torch.Generator(device="cuda").manual_seed(1)
+    n, L = 128 * 4001 + 3, 224
+    E0 = torch.rand((n, L), device="cuda", generator=g) * 20
+    X = torch.rand((n, L), device="cuda", generator=g)
+    Mu = torch.rand((L, L), device="cuda", generator=g) * 2
+    first = phl.compat_softmax(E0, X, Mu).clone()
+    want = torch.softmax(-(E0.double() + X.double() @ Mu.double()), dim=1)
+    assert float((first.double() - want).abs().max()) <= 2e-4
+    out = torch.empty_like(first)
+    side = torch.cuda.Stream()
+    junk = torch.empty(256 << 20, device="cuda", dtype=torch.uint8)
+    for it in range(30):
+        if it % 3 == 0:
+            with torch.cuda.stream(side):
+                junk.add_(1)
+        phl.compat_softmax(E0, X, Mu, out=out)
+        assert torch.equal(out, first), f"launch {it} differs from the first"
+    torch.cuda.synchronize()

@@ -317,3 +317,31 @@ def test_rccl_shaped_path_random_shapes():
         assert rel(got, want) <= RTOL, (trial, world, H, W, L, groups)
         seen.add(any(outs[r][1] for r in range(world)))
     assert seen == {True, False}, seen          # both schedules were exercised
+
+
+@pytest.mark.parametrize("workload", ["band8", "c5"])
+def test_bench_two_ranks_validates_itself(workload):
+    """`python bench.py --gpus 2`: the launcher starts two rank processes; on this one-GPU box they share the card
+    and talk over gloo (the driver's 8-GPU node runs the same code over RCCL).  The JSON line must carry the run's
+    own correctness check -- row bands against a single-lattice filter of the whole volume, independent volumes
+    against the gather kernels -- and, for row bands, the exchange timing keys."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--workload", workload, "--steps", "3",
+                        "--warmup", "1"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    line = json.loads([l for l in r.stdout.decode().splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["value"] > 0
+    chk = line["check"]
+    assert chk["ok"] and chk["check_max_rel"] <= 1e-4
+    if workload == "band8":
+        assert line["scaling"] == "strong" and line["config"]["table"] == "clean"
+        for k in ("exchange_ms", "step_ms", "step_no_exchange_ms", "overlap_hidden_frac"):
+            assert k in chk
+    else:
+        assert line["scaling"] == "weak" and chk["repeatable"]

@@ -194,7 +194,12 @@ def _worker(rank, world, port, H, W, L, q):
     out1 = job.filter(mine)
     out2 = job.filter(mine)          # second call: buffers are reused
     assert torch.equal(out1, out2)
-    q.put((rank, job.row0, out1.numpy(), job.describe()))
+    probe = job.exchange_probe(mine, torch.empty_like(out1), reps=2)     # bench.py's N > 1 exchange timing (collective)
+    out3 = job.filter(mine)
+    assert torch.equal(out1, out3), "the stubbed-exchange timing pass must leave no trace"
+    info = job.describe()
+    info["probe"] = probe
+    q.put((rank, job.row0, out1.numpy(), info))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -222,3 +227,6 @@ def test_two_ranks_over_gloo():
     assert rel(got, want) <= RTOL
     info = res[0][3]["rowtile"]
     assert info["strip_rows"] == 9 and info["exchange_bytes_per_step_per_rank"] > 0 and info["channel_groups"] == 2
+    pr = res[0][3]["probe"]
+    assert set(pr) == {"exchange_ms", "step_ms", "step_no_exchange_ms", "overlap_hidden_frac"}
+    assert pr["exchange_ms"] > 0 and pr["step_ms"] > 0 and 0.0 <= pr["overlap_hidden_frac"] <= 1.0
