@@ -513,7 +513,7 @@ int64_t need_partial(const phl_lattice *lat, int vd, unsigned flags)
 {
     if (flags & (PHL_FILTER_EXACT | PHL_FILTER_NO_TILES)) return 0;
     if (phl_tiles_lprs(lat, vd, 0) < 0 || lat->S_multi > 2 * lat->n) return 0;
-    return lat->S_multi * (int64_t)vd + (phl_splat_fused() ? ((lat->M + 3) & ~(int64_t)3) : 0);   // + arrival counters
+    return lat->S_multi * (int64_t)vd;
 }
 }  // namespace
 

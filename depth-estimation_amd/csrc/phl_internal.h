@@ -156,7 +156,6 @@ int phl_tiles_build(phl_lattice *lat, const float *ref, int64_t rs, int64_t cs, 
 int phl_tiles_link_vertices(phl_lattice *lat, hipStream_t st);
 int phl_tiles_free(phl_lattice *lat);
 int phl_tiles_lprs(const phl_lattice *lat, int vd, int for_slice);  // -1: LDS-staged path unavailable
-bool phl_splat_fused();   // PHL_SPLAT_FUSED=1: experimental in-kernel reduction of the partial rows (needs M ints behind them)
 int phl_launch_splat_tiled(phl_lattice *lat, const float *src, int64_t src_rs, int vd, float *vert, float *partial,
                            hipStream_t st, bool subset = false, const int *chunk_list = nullptr, int nlist = 0,
                            const int *vlist = nullptr, int64_t nvl = 0);

@@ -418,26 +418,7 @@ inline int long_seg()
 constexpr int TPB = 512;     // slice workgroup
 constexpr int TPB_S = 512;   // splat workgroup (1024 threads and 1 workgroup per CU measured no better)
 
-// sc1 (write-through) 16-byte store / load: the partial rows of the experimental in-kernel reduction (FUSED) are
-// handed from workgroup to workgroup inside the launch; see the end of k_splat_tiled.
-typedef float phl_v4f __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void st4_sc1(float *p, float4 v)
-{
-    const phl_v4f x = {v.x, v.y, v.z, v.w};
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(x) : "memory");
-}
-__device__ __forceinline__ phl_v4f ld4_sc1_issue(const float *p)
-{
-    phl_v4f r;
-    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(r) : "v"(p) : "memory");
-    return r;      // NOT valid until ld4_sc1_wait has run on it
-}
-__device__ __forceinline__ void ld4_sc1_wait(phl_v4f &a, phl_v4f &b, phl_v4f &c, phl_v4f &d)
-{
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)::"memory");
-}
-
-template <int LPRS, bool FUSED>
+template <int LPRS>
 __global__ __launch_bounds__(TPB_S) void k_splat_tiled(const float *__restrict__ src, int64_t src_rs, int vd, int n, int P,
                                                      int dp1, int nv_cap, const int *__restrict__ pix_order,
                                                      const int *__restrict__ vptr, const int *__restrict__ slot_vert,
@@ -445,9 +426,7 @@ __global__ __launch_bounds__(TPB_S) void k_splat_tiled(const float *__restrict__
                                                      const phl_contrib_t *__restrict__ seg, float *__restrict__ vert,
                                                      float *__restrict__ partial, int nchunks, int xcd_chunk,
                                                      unsigned long long *__restrict__ tl, const int *__restrict__ chunk_list,
-                                                     int nv_lo, int nv_hi, int long_seg, int *__restrict__ arrive,
-                                                     const int *__restrict__ vs_ptr, const phl_contrib_t *__restrict__ vs,
-                                                     int long_list)
+                                                     int nv_lo, int nv_hi, int long_seg)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int SL = LPRS * 4;
@@ -642,12 +621,8 @@ __global__ __launch_bounds__(TPB_S) void k_splat_tiled(const float *__restrict__
             }
             }
             if (i < nv && chok && !(coop && q != 0)) {
-                if (FUSED && m.y >= 0) {
-                    st4_sc1(partial + (int64_t)m.y * vd + ch, acc);     // write-through: another workgroup may sum it
-                } else {
-                    float *dst = m.y < 0 ? vert + (int64_t)(m.y & 0x7FFFFFFF) * vd : partial + (int64_t)m.y * vd;
-                    st4(dst + ch, acc);
-                }
+                float *dst = m.y < 0 ? vert + (int64_t)(m.y & 0x7FFFFFFF) * vd : partial + (int64_t)m.y * vd;
+                st4(dst + ch, acc);
             }
             gi = __builtin_amdgcn_readfirstlane(nxt);
         }
@@ -664,48 +639,6 @@ __global__ __launch_bounds__(TPB_S) void k_splat_tiled(const float *__restrict__
 #pragma unroll
                 for (int u = 0; u < PF; u++)
                     if (chnok && k0 + u * G < cnt) st4(rows + (k0 + u * G) * SL + l * 4, pf[u]);
-            }
-        }
-    }
-    if constexpr (FUSED) {
-        // EXPERIMENT (PHL_SPLAT_FUSED=1): the workgroup that arrives LAST on a vertex adds up the
-        // vertex's partial rows itself instead of a separate k_splat_reduce launch.  Hand-off in the write-through
-        // form (MI355X_MICROARCH.md, visibility, Valid forms, first table row): every partial row was stored `sc1`;
-        // every wave drains its stores; workgroup barrier; ONE agent-scope atomic add per shared vertex on that
-        // vertex's arrival counter; the workgroup whose add returned K-1 reads all K rows with `sc1` loads -- after
-        // a workgroup barrier -- in ascending chunk order (the order k_splat_reduce uses: same bits).  No
-        // __threadfence, no buffer_wbl2.  Vertices with more than long_list rows stay with k_splat_reduce_long.
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        int *fin = reinterpret_cast<int *>(ent);          // entries are no longer needed: list of vertices to finish
-        if (threadIdx.x == 0) ctr[0] = 0;
-        __syncthreads();
-        for (int i = threadIdx.x; i < nv; i += TPB_S) {
-            if (meta[i].y < 0) continue;
-            const int v = slot_vert[vbase + i] & 0x7FFFFFFF;
-            const int K = vs_ptr[v + 1] - vs_ptr[v];
-            if (K > long_list) continue;
-            const int old = __hip_atomic_fetch_add(arrive + v, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (old == K - 1) fin[atomicAdd(&ctr[0], 1)] = v;
-        }
-        __syncthreads();
-        const int nfin = ctr[0];
-        for (int k = wave; k < nfin; k += NW) {
-            const int v = fin[k];
-            const int beg = vs_ptr[v], end = vs_ptr[v + 1];
-            for (int c0 = lane * 4; c0 < vd; c0 += 256) {
-                float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-                for (int e = beg; e < end; e += 4) {
-                    phl_v4f q[4];
-#pragma unroll
-                    for (int u = 0; u < 4; u++)
-                        q[u] = ld4_sc1_issue(partial + (int64_t)__float_as_int(vs[min(e + u, end - 1)].w) * vd + c0);
-                    ld4_sc1_wait(q[0], q[1], q[2], q[3]);
-#pragma unroll
-                    for (int u = 0; u < 4; u++)
-                        if (e + u < end) acc = make_float4(acc.x + q[u].x, acc.y + q[u].y, acc.z + q[u].z, acc.w + q[u].w);
-                }
-                st4(vert + (int64_t)v * vd + c0, acc);
             }
         }
     }
@@ -998,13 +931,6 @@ inline void dispatch_lprs(int lprs, F &&f)
 }
 
 // LDS per workgroup: default 80 KiB -> two workgroups per CU (160 KiB LDS per CU on gfx950)
-}  // namespace
-bool phl_splat_fused()
-{
-    const char *e = getenv("PHL_SPLAT_FUSED");      // read per call: tools/fused_check.py toggles it inside one process
-    return e && atoi(e) != 0;
-}
-namespace {
 int lds_budget()
 {
     static int b = [] {
@@ -1596,10 +1522,6 @@ int phl_launch_splat_tiled(phl_lattice *lat, const float *src, int64_t src_rs, i
     }
     int rc = PHL_OK;
     const int nrun = subset ? nlist : lat->nchunks;
-    // experimental in-kernel reduction (see the end of k_splat_tiled): arrival counters live behind the partial rows
-    const bool fused = phl_splat_fused() && !subset && partial && lat->S_multi > 0;
-    int *arrive = fused ? reinterpret_cast<int *>(partial + lat->S_multi * (int64_t)vd) : nullptr;
-    if (fused) PHL_HIP(hipMemsetAsync(arrive, 0, sizeof(int) * (size_t)lat->M, st));
     static const char *tl_path = getenv("PHL_TIMELINE");     // debug: dump per-workgroup time stamps of the main launch
     unsigned long long *tl = nullptr;
     size_t tl_n = 0;
@@ -1623,19 +1545,10 @@ int phl_launch_splat_tiled(phl_lattice *lat, const float *src, int64_t src_rs, i
         }
         dispatch_lprs(c.cfg.lprs, [&](auto L) {
             constexpr int LPRS = decltype(L)::value;
-            if (fused) {
-                if ((rc = allow_lds(k_splat_tiled<LPRS, true>, c.cfg.lds)) != PHL_OK) return;
-                k_splat_tiled<LPRS, true><<<dim3(cgrid), dim3(TPB_S), c.cfg.lds, st>>>(
-                    src, src_rs, vd, (int)lat->n, lat->P, lat->d + 1, c.cfg.cap, lat->pix_order, lat->chunk_vptr, lat->slot_vert,
-                    lat->slot_pidx, lat->seg_rng, lat->seg, vert, partial, cnt, xcd_chunk, tlc, list, c.lo, c.hi, long_seg(),
-                    arrive, lat->vs_ptr, lat->vs, LONG_LIST);
-                return;
-            }
-            if ((rc = allow_lds(k_splat_tiled<LPRS, false>, c.cfg.lds)) != PHL_OK) return;
-            k_splat_tiled<LPRS, false><<<dim3(cgrid), dim3(TPB_S), c.cfg.lds, st>>>(
+            if ((rc = allow_lds(k_splat_tiled<LPRS>, c.cfg.lds)) != PHL_OK) return;
+            k_splat_tiled<LPRS><<<dim3(cgrid), dim3(TPB_S), c.cfg.lds, st>>>(
                 src, src_rs, vd, (int)lat->n, lat->P, lat->d + 1, c.cfg.cap, lat->pix_order, lat->chunk_vptr, lat->slot_vert,
-                lat->slot_pidx, lat->seg_rng, lat->seg, vert, partial, cnt, xcd_chunk, tlc, list, c.lo, c.hi, long_seg(),
-                nullptr, nullptr, nullptr, 0);
+                lat->slot_pidx, lat->seg_rng, lat->seg, vert, partial, cnt, xcd_chunk, tlc, list, c.lo, c.hi, long_seg());
         });
     }
     if (tl) {                                                 // debug only
@@ -1658,10 +1571,9 @@ int phl_launch_splat_tiled(phl_lattice *lat, const float *src, int64_t src_rs, i
     const int *llist = subset ? vlist : lat->vlong;
     const int64_t nl = subset ? nvl : lat->n_long;
     const int long_list = llist ? LONG_LIST : 0x7FFFFFFF;
-    const int short_list = fused ? 0 : long_list;          // fused: only vertices without any chunk (ghosts: zeros) remain
 #define PHL_RED(LPR_)                                                                                                  \
     k_splat_reduce<LPR_><<<dim3((unsigned)blocks), dim3(256), 0, st>>>(partial, lat->vs_ptr, lat->vs, lat->slot_pidx, \
-                                                                       M, vd, vert, vlist, short_list);              \
+                                                                       M, vd, vert, vlist, long_list);               \
     if (llist && nl > 0)                                                                                               \
         k_splat_reduce_long<LPR_><<<dim3((unsigned)nl), dim3(256), 0, st>>>(partial, lat->vs_ptr, lat->vs,            \
                                                                             lat->slot_pidx, vd, vert, llist, long_list)
