@@ -619,7 +619,9 @@ def main():
         kname = {"splat": "k_splat_tiled+k_splat_reduce" if staged else "k_splat",
                  "blur": f"{(d + 1) // 2}*k_blur2" + ("+k_blur" if (d + 1) % 2 else ""),
                  "slice": "k_slice_tiled" if staged_sl else "k_slice"}
-        traffic, traffic_src = pmc_traffic(kname[dom], args.workload) if not rowtiled else (None, None)
+        # (the committed counters were taken on the default features with the reference-table lattice)
+        default_feat = tsu is None and not args.iid and args.sigma_xy == SIGMA_XY and args.sigma_c == SIGMA_C
+        traffic, traffic_src = pmc_traffic(kname[dom], args.workload) if (not rowtiled and default_feat) else (None, None)
         # measured streaming ceiling on this box: device copy of the value volume, R+W bytes
         e0, e1 = ev(), ev()
         phl.stream_copy(out, src)

@@ -53,3 +53,27 @@ for k, v in pm.items():
 shutil.copy('gpurun_out/bench_final.log', f'profiles/{tag}_bench_c3.log')
 shutil.copy('gpurun_out/bench_final_prof.log', f'profiles/{tag}_bench_c3_under_rocprof.log')
 open(f'profiles/{tag}_bench_c3_exact.log', 'w').write(''.join(l for l in open('gpurun_out/bench_final_exact.log') if l.startswith('{')))
+
+# mean-field iteration (k_compat_softmax): kernel stats + HBM traffic of the fused compatibility kernel
+import os
+if glob.glob(f'gpurun_out/prof_{tag}_mf/*/*kernel_stats.csv'):
+    for x in stats(f'prof_{tag}_mf', f'profiles/{tag}_meanfield_kernel_stats.csv')[:4]:
+        print('mean-field', short(x['Name']), x['Calls'], round(float(x['AverageNs']) / 1e3, 1), 'us')
+    mf = collections.defaultdict(lambda: collections.defaultdict(list))
+    for d in ('FETCH_SIZE', 'WRITE_SIZE'):
+        for f in glob.glob(f'gpurun_out/pmc_{tag}_mf_{d}/*/*counter_collection.csv'):
+            for row in csv.DictReader(open(f)):
+                n = short(row['Kernel_Name'])
+                if n.startswith('k_compat'):
+                    mf[n][row['Counter_Name']].append(float(row['Counter_Value']))
+    out = {}
+    for k, v in mf.items():
+        m = {c: sum(x) / len(x) for c, x in v.items()}
+        fk, wk = m.get('FETCH_SIZE', 0), m.get('WRITE_SIZE', 0)
+        out[k] = {'dispatches_sampled': len(v['FETCH_SIZE']), 'fetch_bytes_corrected_x2': int(fk * 2048), 'write_bytes': int(wk * 1024),
+                  'hbm_bytes_per_launch': int(fk * 2048 + wk * 1024)}
+    json.dump({'note': 'rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (separate passes), bench.py c3 mean-field extras; FETCH_SIZE doubled (gfx950)',
+               'kernels': out}, open(f'profiles/{tag}_meanfield_pmc_traffic.json', 'w'), indent=1)
+    open(f'profiles/{tag}_bench_c3_mean_field.log', 'w').write(''.join(l for l in open('gpurun_out/bench_final_mf.log') if l.startswith('{')))
+if os.path.exists(f'gpurun_out/regimes_{tag}.json'):
+    shutil.copy(f'gpurun_out/regimes_{tag}.json', f'profiles/{tag}_regimes.json')
