@@ -47,6 +47,25 @@ def _ref_gradient(src, ref, g, wall):
     return -2 * inner.sum(-2)
 
 
+def _fused_grad(src, ref, g, need_src):
+    """(grad_src | None, grad_ref) through phl_filter_grad: the products with ``ref`` are formed on the splat
+    weights and the contraction happens inside the slice, so the 2L(1+d)-channel operand and result of :450-463
+    (19 GB each at 1390x1110x256) never exist.  None when the fused path does not take the shape (then the caller
+    filters the wide operand, as the reference does)."""
+    if not (src.dim() == 2 and ref.dim() == 2 and g.shape == src.shape and src.shape[1] % 4 == 0 and ref.shape[1] <= 7
+            and torch.cuda.is_available() and src.dtype == torch.float32 and ref.dtype == torch.float32):
+        return None
+    lat = phl.lattice_for(ref.detach())
+    try:
+        gs, gr = lat.filter_grad(src, g, ref, need_src=need_src)
+    except phl.PhlError as e:
+        if e.status != 7:          # PHL_ERR_UNSUPPORTED: shape outside the fused path
+            raise
+        return None
+    dev = src.device
+    return (gs.to(dev) if gs is not None else None), gr.to(ref.device)
+
+
 def _wide_operand(src, ref, g):
     L, d = src.shape[-1], ref.shape[-1]
     gf = (g.unsqueeze(-1) * ref.unsqueeze(-2)).reshape(g.shape[:-1] + (L * d,))
@@ -76,10 +95,14 @@ class LatticeFilter(Function):
         with torch.no_grad():
             g = grad_output.contiguous()
             if need_ref:
-                wall = latticefilter(_wide_operand(src, ref, g), ref)
-                grad_reference = _ref_gradient(src, ref, g, wall)
-                if need_src:
-                    grad_source = wall[..., :src.shape[-1]]
+                fused = _fused_grad(src, ref, g, need_src)
+                if fused is not None:
+                    grad_source, grad_reference = fused
+                else:
+                    wall = latticefilter(_wide_operand(src, ref, g), ref)
+                    grad_reference = _ref_gradient(src, ref, g, wall)
+                    if need_src:
+                        grad_source = wall[..., :src.shape[-1]]
             elif need_src:
                 grad_source = latticefilter(g, ref)
         return grad_source, grad_reference

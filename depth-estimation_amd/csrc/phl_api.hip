@@ -701,6 +701,49 @@ int phl_filter(phl_lattice *lat, const float *src, int vd, int64_t src_rs, int64
     return rc;
 }
 
+int phl_filter_grad(phl_lattice *lat, const float *src, int64_t src_rs, const float *g, int64_t g_rs, int L, const float *ref,
+                    int64_t ref_rs, int64_t ref_cs, float *grad_ref, float *grad_src, int64_t grad_src_rs, phl_stream stream)
+{
+    if (!lat || L < 0 || !grad_ref) { phl_set_error("phl_filter_grad: bad arguments"); return PHL_ERR_INVALID; }
+    const int64_t n = lat->n;
+    const int d = lat->d;
+    if (n == 0) return PHL_OK;
+    if (!src || !g || !ref) { phl_set_error("phl_filter_grad: NULL src / g / ref"); return PHL_ERR_INVALID; }
+    hipStream_t st = (hipStream_t)stream;
+    device_guard guard(lat->device);
+    if (L == 0) {
+        PHL_HIP(hipMemsetAsync(grad_ref, 0, sizeof(float) * (size_t)n * d, st));
+        return PHL_OK;
+    }
+    const int64_t vdw = (int64_t)L * (d + 1);
+    if (d > 7 || L % 4 != 0 || !use_tiled_splat(lat, L, 0, src, g, src_rs) || g_rs % 4 || vdw > (1 << 20) ||
+        (grad_src && ((reinterpret_cast<uintptr_t>(grad_src) & 15) || grad_src_rs % 4))) {
+        phl_set_error("phl_filter_grad: shape not covered by the fused path (d <= 7, L %% 4 == 0, 16-byte aligned pixel-major rows, "
+                      "chunk splat available); filter the 2L(1+d)-channel operand instead");
+        return PHL_ERR_UNSUPPORTED;
+    }
+    phl_workspace *w = nullptr;
+    int rc = phl_ws_acquire(lat, st, lat->M * vdw, lat->S_multi * vdw, 0, &w);
+    if (rc) return rc;
+    // Two passes of the same three stages, each over (1+d) L channels instead of the reference's 2 (1+d) L at once:
+    //   pass 1  x = g,   y = src:  T  = -2 sum_l src (f Wg - W(g f))      (+ Wg itself = the gradient w.r.t. src)
+    //   pass 2  x = src, y = g:    T += -2 sum_l g   (f Ws - W(s f))
+    const float *xs[2] = {g, src}, *ys[2] = {src, g};
+    const int64_t xrs[2] = {g_rs, src_rs}, yrs[2] = {src_rs, g_rs};
+    for (int pass = 0; pass < 2 && rc == PHL_OK; pass++) {
+        phl_splat_wide wide = {d + 1, ref, ref_rs, ref_cs};
+        rc = phl_launch_splat_tiled(lat, xs[pass], xrs[pass], L, w->buf[0], w->partial, st, false, nullptr, 0, nullptr, 0, &wide);
+        if (rc) break;
+        int cur = 0;
+        rc = blur_all(lat, w->buf, (int)vdw, st, &cur);
+        if (rc) break;
+        rc = phl_launch_slice_grad(lat, w->buf[cur], L, ys[pass], yrs[pass], ref, ref_rs, ref_cs, grad_ref, pass,
+                                   pass == 0 ? grad_src : nullptr, grad_src_rs, st);
+    }
+    phl_ws_release(lat, w, st, false);
+    return rc;
+}
+
 int phl_filter_once(const float *src, int vd, int64_t src_rs, int64_t src_cs, const float *ref, int d, int64_t ref_rs,
                     int64_t ref_cs, int64_t n, float *out, int64_t out_rs, int64_t out_cs, unsigned flags, int device,
                     phl_stream stream)

@@ -156,9 +156,19 @@ int phl_tiles_build(phl_lattice *lat, const float *ref, int64_t rs, int64_t cs, 
 int phl_tiles_link_vertices(phl_lattice *lat, hipStream_t st);
 int phl_tiles_free(phl_lattice *lat);
 int phl_tiles_lprs(const phl_lattice *lat, int vd, int for_slice);  // -1: LDS-staged path unavailable
+// wide splat (phl_filter_grad): block 0 = splat(src), block 1+k = splat(src (x) fref[:, k]); rows of nsets * vd floats
+struct phl_splat_wide {
+    int nsets;
+    const float *fref;
+    int64_t rs, cs;
+};
 int phl_launch_splat_tiled(phl_lattice *lat, const float *src, int64_t src_rs, int vd, float *vert, float *partial,
                            hipStream_t st, bool subset = false, const int *chunk_list = nullptr, int nlist = 0,
-                           const int *vlist = nullptr, int64_t nvl = 0);
+                           const int *vlist = nullptr, int64_t nvl = 0, const phl_splat_wide *wide = nullptr);
+// slice of a wide vertex buffer contracted to the feature gradient (phl_tiles.hip, k_slice_grad)
+int phl_launch_slice_grad(const phl_lattice *lat, const float *vertw, int L, const float *y, int64_t y_rs, const float *ref,
+                          int64_t ref_rs, int64_t ref_cs, float *grad_ref, int accumulate, float *wx_out, int64_t wx_rs,
+                          hipStream_t st);
 int phl_tiles_chunks_touching(phl_lattice *lat, const int64_t *rows_dev, int64_t k, int32_t *mask_host, hipStream_t st);
 int phl_launch_slice_tiled(const phl_lattice *lat, const float *vert, int vd, float *out, int64_t out_rs, const float *sub,
                            int64_t sub_rs, unsigned flags, hipStream_t st);

@@ -426,8 +426,14 @@ __global__ __launch_bounds__(TPB_S) void k_splat_tiled(const float *__restrict__
                                                      const phl_contrib_t *__restrict__ seg, float *__restrict__ vert,
                                                      float *__restrict__ partial, int nchunks, int xcd_chunk,
                                                      unsigned long long *__restrict__ tl, const int *__restrict__ chunk_list,
-                                                     int nv_lo, int nv_hi, int long_seg)
+                                                     int nv_lo, int nv_hi, int long_seg, int nsets,
+                                                     const float *__restrict__ fref, int64_t fref_rs, int64_t fref_cs,
+                                                     int64_t out_rs)
 {
+    // nsets > 1 (the wide splat of the gradient w.r.t. the features, phl_filter_grad): every staged slab is summed
+    // nsets times, set 0 with the barycentric weights w and set 1+k with w * fref[pixel][k] -- the splat of
+    // src (x) ref[:, k] without ever forming that product in memory -- into channel block `set` of rows that are
+    // out_rs = nsets * vd floats long.  nsets == 1: the plain splat (fref unused, out_rs = vd).
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int SL = LPRS * 4;
     constexpr int G = TPB_S / LPRS;          // row groups of the workgroup (staging)
@@ -521,7 +527,6 @@ __global__ __launch_bounds__(TPB_S) void k_splat_tiled(const float *__restrict__
         __syncthreads();                   // rows of this slab are in LDS
         const int slab = c0 / SL;
         if (tlb && threadIdx.x == 0 && slab < 2) tlb[1 + 2 * slab] = wall_clock64();
-        if (threadIdx.x == 0) ctr[(slab + 1) & 1] = NW;   // re-arm the other counter for the next slab
         const int chn = ch + SL;
         const bool more = c0 + SL < vd;    // wave-uniform
         const bool chnok = more && chn < vd;
@@ -535,7 +540,19 @@ __global__ __launch_bounds__(TPB_S) void k_splat_tiled(const float *__restrict__
         // (k_chunk_sort), so the Q vertices of a group have nearly equal loops, and the waves take
         // groups longest-first from a shared counter: no cross-lane combine, no padding, and the
         // per-vertex bookkeeping is paid once per Q vertices.
-        int *slab_ctr = ctr + (slab & 1);
+        for (int set = 0; set < nsets; set++) {
+        const int phase = slab * nsets + set;
+        if (nsets > 1) {
+            if (set > 0) __syncthreads();                 // the previous set's sums are done with the entry weights
+            for (int e = threadIdx.x; e < E; e += TPB_S) {
+                const phl_contrib_t sg = seg[ebase + e];
+                const float f = set ? fref[(int64_t)pixl[sg.pixel] * fref_rs + (int64_t)(set - 1) * fref_cs] : 1.f;
+                ent[e].y = __float_as_uint(sg.w * f);
+            }
+        }
+        if (threadIdx.x == 0) ctr[(phase + 1) & 1] = NW;  // re-arm the other counter for the next phase
+        if (nsets > 1) __syncthreads();                   // weights of this set are in LDS
+        int *slab_ctr = ctr + (phase & 1);
         // Work items, handed out longest-first: items [0, nlong) are single LONG vertices (LPRS >= 16 only), summed
         // by all Q lane groups of the wave together -- group q takes the 16-entry batches q, q+Q, ... of the
         // segment and the Q partial sums are combined across the DPP rows in a fixed order -- so that one 256-entry
@@ -621,11 +638,12 @@ __global__ __launch_bounds__(TPB_S) void k_splat_tiled(const float *__restrict__
             }
             }
             if (i < nv && chok && !(coop && q != 0)) {
-                float *dst = m.y < 0 ? vert + (int64_t)(m.y & 0x7FFFFFFF) * vd : partial + (int64_t)m.y * vd;
-                st4(dst + ch, acc);
+                float *dst = m.y < 0 ? vert + (int64_t)(m.y & 0x7FFFFFFF) * out_rs : partial + (int64_t)m.y * out_rs;
+                st4(dst + (int64_t)set * vd + ch, acc);
             }
             gi = __builtin_amdgcn_readfirstlane(nxt);
         }
+        }   // sets
         __syncthreads();                   // everyone is done reading this slab
         if (tlb && threadIdx.x == 0 && slab < 2) tlb[2 + 2 * slab] = wall_clock64();
         if (tlb && threadIdx.x == 0 && !more) tlb[5] = wall_clock64();
@@ -869,6 +887,146 @@ __global__ __launch_bounds__(TPB) void k_slice_tiled(const float *__restrict__ v
             default: slice_chunk<2, EXACT, false>(a, ent, pixl, vl, rows); break;
         }
     }
+}
+
+// ---- gradient w.r.t. the features: slice of the WIDE vertex buffer, contracted on the fly ---------------------------
+// crf/gaussian_matrix.py:450-463 filters [g, g(x)ref, src, src(x)ref] (2L(1+d) channels) and contracts the result to
+// [n, d].  Here one pass (x, y) of phl_filter_grad holds the blurred wide vertex rows [M][NS*L] (block 0 = splat of x,
+// block 1+k = splat of x (x) ref[:, k]; NS = d+1) and this kernel evaluates, per pixel i,
+//     T_ik = -2 / (1 + 2^-d) * ( f_ik * sum_l y_il (Wx)_il  -  sum_l y_il (W(x f_k))_il )
+// without writing any sliced row: a 16-lane group owns 8 pixels of the chunk and keeps their NS running dot products
+// in registers while the chunk's vertex rows pass through LDS one (64-channel slab, block) at a time.  y is read
+// once, the vertex array about twice (chunks overlap), [n, d] is written; (Wx) itself is written on request (it is
+// the gradient w.r.t. the source when x = g).  DIRECT: chunks whose rows do not fit LDS gather them from global.
+template <int NS, bool DIRECT>
+__device__ __forceinline__ void slice_grad_chunk(const float *__restrict__ vertw, int L, int dp1, int cnt, int nv,
+                                                 const uint2 *__restrict__ ent, const int *__restrict__ pixl,
+                                                 const int *__restrict__ vl, float *__restrict__ rows,
+                                                 const float *__restrict__ y, int64_t y_rs, const float *__restrict__ ref,
+                                                 int64_t ref_rs, int64_t ref_cs, float *__restrict__ grad_ref, int accumulate,
+                                                 float *__restrict__ wx_out, int64_t wx_rs, float rcdiv)
+{
+    constexpr int LPRS = 16, SL = 64, G = TPB / LPRS, PPG = 8;
+    const int g = threadIdx.x / LPRS, l = threadIdx.x % LPRS;
+    const int64_t vdw = (int64_t)NS * L;
+    float acc[PPG][NS];
+#pragma unroll
+    for (int u = 0; u < PPG; u++)
+#pragma unroll
+        for (int t = 0; t < NS; t++) acc[u][t] = 0.f;
+    const int kclamp = cnt - 1;
+    for (int c0 = 0; c0 < L; c0 += SL) {
+        const int ch = c0 + l * 4;
+        const bool chok = ch < L;
+        const int chc = chok ? ch : 0;
+        float4 yv[PPG];
+#pragma unroll
+        for (int u = 0; u < PPG; u++) yv[u] = ld4(y + (int64_t)pixl[min(g + u * G, kclamp)] * y_rs + chc);
+#pragma unroll
+        for (int u = 0; u < PPG; u++)
+            if (!chok || g + u * G >= cnt) yv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int set = 0; set < NS; set++) {
+            const float *vb = vertw + (int64_t)set * L + chc;
+            if (!DIRECT) {
+                const int iclamp = nv - 1;
+                for (int i0 = g; i0 < nv; i0 += 8 * G) {
+                    float4 q[8];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) q[u] = ld4(vb + (int64_t)vl[min(i0 + u * G, iclamp)] * vdw);
+#pragma unroll
+                    for (int u = 0; u < 8; u++)
+                        if (i0 + u * G < nv) st4(rows + (i0 + u * G) * SL + l * 4, q[u]);
+                }
+                __syncthreads();
+            }
+            const char *rbase = reinterpret_cast<const char *>(rows) + l * 16;
+#pragma unroll
+            for (int u = 0; u < PPG; u++) {
+                const int k = min(g + u * G, kclamp);
+                const uint2 *ek = ent + k * dp1;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int r = 0; r < dp1; r++) {
+                    const uint2 e0 = ek[r];
+                    const float4 q0 = DIRECT ? ld4(vb + (int64_t)e0.x * vdw) : *reinterpret_cast<const float4 *>(rbase + e0.x);
+                    v = fma4(v, __uint_as_float(e0.y), q0);
+                }
+                acc[u][set] += yv[u].x * v.x + yv[u].y * v.y + yv[u].z * v.z + yv[u].w * v.w;
+                if (set == 0 && wx_out && chok && g + u * G < cnt)
+                    st4(wx_out + (int64_t)pixl[k] * wx_rs + ch, make_float4(v.x * rcdiv, v.y * rcdiv, v.z * rcdiv, v.w * rcdiv));
+            }
+            if (!DIRECT) __syncthreads();
+        }
+    }
+    // the 16 lanes of a group hold the 64 channels of a slab between them: add their dot products
+#pragma unroll
+    for (int u = 0; u < PPG; u++)
+#pragma unroll
+        for (int t = 0; t < NS; t++) {
+            float a = acc[u][t];
+            a += __shfl_xor(a, 8, 16);
+            a += __shfl_xor(a, 4, 16);
+            a += __shfl_xor(a, 2, 16);
+            a += __shfl_xor(a, 1, 16);
+            acc[u][t] = a;
+        }
+    if (l == 0) {
+#pragma unroll
+        for (int u = 0; u < PPG; u++) {
+            const int k = g + u * G;
+            if (k >= cnt) continue;
+            const int64_t p = pixl[k];
+#pragma unroll
+            for (int t = 1; t < NS; t++) {
+                const float f = ref[p * ref_rs + (int64_t)(t - 1) * ref_cs];
+                const float val = -2.f * rcdiv * (f * acc[u][0] - acc[u][t]);
+                float *dst = grad_ref + p * (NS - 1) + (t - 1);
+                *dst = accumulate ? *dst + val : val;
+            }
+        }
+    }
+}
+
+template <int NS>
+__global__ __launch_bounds__(TPB) void k_slice_grad(const float *__restrict__ vertw, int L, int n, int P, int dp1, int lds_bytes,
+                                                    const int *__restrict__ pix_order, const int *__restrict__ vptr,
+                                                    const int *__restrict__ slot_vert, const unsigned short *__restrict__ lidx,
+                                                    const phl_replay_t *__restrict__ replay, const float *__restrict__ y,
+                                                    int64_t y_rs, const float *__restrict__ ref, int64_t ref_rs, int64_t ref_cs,
+                                                    float *__restrict__ grad_ref, int accumulate, float *__restrict__ wx_out,
+                                                    int64_t wx_rs, float rcdiv, int nchunks, int xcd_chunk)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int c = xcd_chunk > 0 ? (int)(blockIdx.x & 7) * xcd_chunk + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    if (c >= nchunks) return;
+    const int base = c * P;
+    const int cnt = min(P, n - base);
+    const int E = cnt * dp1;
+    const int64_t ebase = (int64_t)base * dp1;
+    const int vbase = vptr[c], nv = vptr[c + 1] - vbase;
+    uint2 *ent = reinterpret_cast<uint2 *>(lds);
+    int *pixl = reinterpret_cast<int *>(ent + P * dp1);
+    int *vl = pixl + P;
+    const int fixed = (P * dp1 * 8 + P * 4 + nv * 4 + 15) & ~15;
+    float *rows = reinterpret_cast<float *>(reinterpret_cast<char *>(lds) + fixed);
+    const bool direct = fixed + (int64_t)nv * 256 > lds_bytes;       // workgroup-uniform
+    for (int k = threadIdx.x; k < cnt; k += TPB) pixl[k] = pix_order[base + k];
+    if (!direct)
+        for (int i = threadIdx.x; i < nv; i += TPB) vl[i] = slot_vert[vbase + i] & 0x7FFFFFFF;
+    for (int e = threadIdx.x; e < E; e += TPB) {
+        const int k = e / dp1, r = e - k * dp1;
+        const int p = pix_order[base + k];
+        const unsigned li = lidx[ebase + e];
+        ent[e] = make_uint2(direct ? (unsigned)(slot_vert[vbase + li] & 0x7FFFFFFF) : li * 256u,
+                            __float_as_uint(replay[(int64_t)p * dp1 + r].w));
+    }
+    __syncthreads();
+    if (direct)
+        slice_grad_chunk<NS, true>(vertw, L, dp1, cnt, nv, ent, pixl, vl, rows, y, y_rs, ref, ref_rs, ref_cs, grad_ref, accumulate,
+                                   wx_out, wx_rs, rcdiv);
+    else
+        slice_grad_chunk<NS, false>(vertw, L, dp1, cnt, nv, ent, pixl, vl, rows, y, y_rs, ref, ref_rs, ref_cs, grad_ref, accumulate,
+                                    wx_out, wx_rs, rcdiv);
 }
 
 // vs[e].w <- partial-buffer row of the slot (bit pattern of an int): saves the reduce kernels one dependent load
@@ -1510,8 +1668,11 @@ int phl_tiles_chunks_touching(phl_lattice *lat, const int64_t *rows_dev, int64_t
 }
 
 int phl_launch_splat_tiled(phl_lattice *lat, const float *src, int64_t src_rs, int vd, float *vert, float *partial,
-                           hipStream_t st, bool subset, const int *chunk_list, int nlist, const int *vlist, int64_t nvl)
+                           hipStream_t st, bool subset, const int *chunk_list, int nlist, const int *vlist, int64_t nvl,
+                           const phl_splat_wide *wide)
 {
+    // wide: vertex / partial rows of wide->nsets * vd floats, block k+1 = splat of src (x) fref[:, k] (k_splat_tiled)
+    const int64_t out_rs = (int64_t)vd * (wide ? wide->nsets : 1);
     // subset: run only the listed chunks, then complete only the listed vertex rows (either list may be empty)
     const int M = subset ? (int)nvl : (int)lat->M;
     if (lat->M == 0 || vd == 0) return PHL_OK;
@@ -1548,7 +1709,8 @@ int phl_launch_splat_tiled(phl_lattice *lat, const float *src, int64_t src_rs, i
             if ((rc = allow_lds(k_splat_tiled<LPRS>, c.cfg.lds)) != PHL_OK) return;
             k_splat_tiled<LPRS><<<dim3(cgrid), dim3(TPB_S), c.cfg.lds, st>>>(
                 src, src_rs, vd, (int)lat->n, lat->P, lat->d + 1, c.cfg.cap, lat->pix_order, lat->chunk_vptr, lat->slot_vert,
-                lat->slot_pidx, lat->seg_rng, lat->seg, vert, partial, cnt, xcd_chunk, tlc, list, c.lo, c.hi, long_seg());
+                lat->slot_pidx, lat->seg_rng, lat->seg, vert, partial, cnt, xcd_chunk, tlc, list, c.lo, c.hi, long_seg(),
+                wide ? wide->nsets : 1, wide ? wide->fref : nullptr, wide ? wide->rs : 0, wide ? wide->cs : 0, out_rs);
         });
     }
     if (tl) {                                                 // debug only
@@ -1563,7 +1725,7 @@ int phl_launch_splat_tiled(phl_lattice *lat, const float *src, int64_t src_rs, i
     }
     if (rc) return rc;
     if (M == 0) return PHL_OK;
-    const int lpr = pick_lpr_row(vd);
+    const int lpr = pick_lpr_row((int)out_rs);
     int64_t waves = ((int64_t)M + (64 / lpr) - 1) / (64 / lpr);
     int64_t blocks = (waves + 3) / 4;
     if (blocks > 2048) blocks = 2048;
@@ -1573,10 +1735,10 @@ int phl_launch_splat_tiled(phl_lattice *lat, const float *src, int64_t src_rs, i
     const int long_list = llist ? LONG_LIST : 0x7FFFFFFF;
 #define PHL_RED(LPR_)                                                                                                  \
     k_splat_reduce<LPR_><<<dim3((unsigned)blocks), dim3(256), 0, st>>>(partial, lat->vs_ptr, lat->vs, lat->slot_pidx, \
-                                                                       M, vd, vert, vlist, long_list);               \
+                                                                       M, (int)out_rs, vert, vlist, long_list);      \
     if (llist && nl > 0)                                                                                               \
         k_splat_reduce_long<LPR_><<<dim3((unsigned)nl), dim3(256), 0, st>>>(partial, lat->vs_ptr, lat->vs,            \
-                                                                            lat->slot_pidx, vd, vert, llist, long_list)
+                                                                            lat->slot_pidx, (int)out_rs, vert, llist, long_list)
     switch (lpr) {
         case 64: PHL_RED(64); break;
         case 16: PHL_RED(16); break;
@@ -1612,6 +1774,40 @@ int phl_launch_slice_tiled(const phl_lattice *lat, const float *vert, int vd, fl
             lat->lidx, lat->replay, out, out_rs, sub, sub_rs, cdiv, rcdiv, lat->nchunks, xcd_chunk);
     }
     if (rc) return rc;
+    PHL_HIP(hipGetLastError());
+    return PHL_OK;
+}
+
+// phl_filter_grad's last stage (see k_slice_grad).  d <= 7; P <= 256 (eight pixels per 16-lane group).
+int phl_launch_slice_grad(const phl_lattice *lat, const float *vertw, int L, const float *y, int64_t y_rs, const float *ref,
+                          int64_t ref_rs, int64_t ref_cs, float *grad_ref, int accumulate, float *wx_out, int64_t wx_rs,
+                          hipStream_t st)
+{
+    if (lat->n == 0 || L == 0) return PHL_OK;
+    const int dp1 = lat->d + 1;
+    if (dp1 < 2 || dp1 > 8 || lat->P > 256 || lat->nchunks == 0) {
+        phl_set_error("fused feature gradient: d = %d not supported (1..7)", lat->d);
+        return PHL_ERR_UNSUPPORTED;
+    }
+    const int64_t fixed = (((int64_t)lat->P * dp1 * 8 + (int64_t)lat->P * 4 + (int64_t)lat->nv_max * 4 + 15) & ~(int64_t)15);
+    int64_t lds = fixed + (int64_t)lat->nv_max * 256;
+    if (lds > lds_budget()) lds = lds_budget();
+    const float rcdiv = 1.0f / (1 + powf(2, -lat->d));      // permutohedral.h:480
+    unsigned cgrid;
+    int xcd_chunk;
+    chunk_grid(lat->nchunks, &cgrid, &xcd_chunk);
+    int rc = PHL_OK;
+#define PHL_SG(NS_)                                                                                                          \
+    case NS_:                                                                                                                \
+        if ((rc = allow_lds(k_slice_grad<NS_>, (size_t)lds)) != PHL_OK) return rc;                                           \
+        k_slice_grad<NS_><<<dim3(cgrid), dim3(TPB), (size_t)lds, st>>>(vertw, L, (int)lat->n, lat->P, dp1, (int)lds,         \
+            lat->pix_order, lat->chunk_vptr, lat->slot_vert, lat->lidx, lat->replay, y, y_rs, ref, ref_rs, ref_cs, grad_ref, \
+            accumulate, wx_out, wx_rs, rcdiv, lat->nchunks, xcd_chunk);                                                      \
+        break;
+    switch (dp1) {
+        PHL_SG(2) PHL_SG(3) PHL_SG(4) PHL_SG(5) PHL_SG(6) PHL_SG(7) PHL_SG(8)
+    }
+#undef PHL_SG
     PHL_HIP(hipGetLastError());
     return PHL_OK;
 }

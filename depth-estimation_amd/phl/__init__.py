@@ -67,6 +67,7 @@ def load_library():
             getattr(lib, name).argtypes = [vp]
         lib.phl_num_dims.argtypes = [vp]
         lib.phl_device.argtypes = [vp]
+        lib.phl_filter_grad.argtypes = [vp, vp, i64, vp, i64, i32, vp, i64, i64, vp, vp, i64, vp]
         lib.phl_reserve.argtypes = [vp, i32]
         lib.phl_reserve_ex.argtypes = [vp, i32, u32]
         lib.phl_add_vertices.argtypes = [vp, vp, i64, vp, vp]
@@ -297,6 +298,26 @@ class Lattice:
                                             (EXACT if exact else 0) | (NO_TILES if no_tiles else 0),
                                             _stream(self.device)))
         return out
+
+    def filter_grad(self, src, g, ref, need_src=True):
+        """Gradients of ``sum(g * filter(src, ref))``: returns (grad_src or None, grad_ref [n, d]) -- the body of
+        LatticeFilter.backward (crf/gaussian_matrix.py:435-468) in two fused passes (phl_filter_grad in
+        include/phl.h).  Raises PhlError(status UNSUPPORTED) for shapes the fused path does not take."""
+        src_d = _as_device(src.detach(), self.device).contiguous()
+        g_d = _as_device(g.detach(), self.device).contiguous()
+        ref_d = _as_device(ref.detach(), self.device)
+        assert src_d.shape == g_d.shape and src_d.shape[0] == self.n and ref_d.shape == (self.n, self.d)
+        L = int(src_d.shape[1])
+        grad_ref = torch.empty((self.n, self.d), dtype=torch.float32, device=self.device)
+        grad_src = torch.empty((self.n, L), dtype=torch.float32, device=self.device) if need_src else None
+        with torch.cuda.device(self.device):
+            _check(load_library().phl_filter_grad(self._h, C.c_void_p(src_d.data_ptr()), src_d.stride(0),
+                                                  C.c_void_p(g_d.data_ptr()), g_d.stride(0), L,
+                                                  C.c_void_p(ref_d.data_ptr()), ref_d.stride(0), ref_d.stride(1),
+                                                  C.c_void_p(grad_ref.data_ptr()),
+                                                  C.c_void_p(grad_src.data_ptr()) if need_src else None, L,
+                                                  _stream(self.device)))
+        return grad_src, grad_ref
 
     def tile_stats(self, vd):
         """Chunk statistics of the LDS-staged path (see phl_tile_stats in include/phl.h)."""

@@ -156,6 +156,20 @@ int phl_filter_once(const float *src_dev, int vd, int64_t src_row_stride, int64_
                     int64_t n, float *out_dev, int64_t out_row_stride, int64_t out_col_stride,
                     unsigned flags, int device, phl_stream stream);
 
+/* Backward of one filter call w.r.t. the FEATURES (and the source), replacing the body of
+ * LatticeFilter.backward, crf/gaussian_matrix.py:435-468: for out = filter(src, ref) and an incoming gradient g [n][L],
+ *     grad_ref[i][k] = -2 sum_l ( src_il f_ik (Wg)_il - src_il (W(g f_k))_il + g_il f_ik (Ws)_il - g_il (W(s f_k))_il )
+ * (:463; W = this lattice's splat-blur-slice, f = ref) and, if grad_src != NULL, grad_src = W g (:446 -- the
+ * operator is symmetric).  The reference materialises the 2L(1+d)-channel operand [g, g(x)ref, src, src(x)ref],
+ * filters it and contracts the 2L(1+d)-channel result; here the products are formed on the weights inside the
+ * splat and the contraction inside the slice, so HBM sees src and g twice, the wide vertex buffer
+ * [M][(1+d)L] (two passes) and [n][d] -- never a wide per-pixel tensor.  ref must be the array the lattice was
+ * built from.  src, g, grad_src: pixel-major rows (unit channel stride), 16-byte aligned, L % 4 == 0; d <= 7.
+ * grad_ref: dense [n][d].  PHL_ERR_UNSUPPORTED for shapes outside that (callers then filter the wide operand). */
+int phl_filter_grad(phl_lattice *lat, const float *src_dev, int64_t src_row_stride, const float *g_dev,
+                    int64_t g_row_stride, int L, const float *ref_dev, int64_t ref_row_stride, int64_t ref_col_stride,
+                    float *grad_ref_dev, float *grad_src_dev, int64_t grad_src_row_stride, phl_stream stream);
+
 /* ---- stage-level entry points (profiling, roofline measurement, parity of intermediates) --
  * vert buffers are dense [M][vd] fp32 device arrays owned by the caller. */
 /* value half of splat(): vert[v] = sum over (pixel,weight) of w*src[pixel]   (:454-455) */
