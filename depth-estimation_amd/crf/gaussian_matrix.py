@@ -11,6 +11,8 @@ The guided-filter siblings (GuidedFilter, FastGuidedFilter, BatchedGuidedAdjacen
 GuidedAdjacency; :161-287) are a different, dense-torch kernel outside the lattice hot path;
 they are provided in crf.guided as plain torch ops for API completeness.
 """
+import os
+
 import torch
 import torch.nn as nn
 from torch.autograd import Function
@@ -52,6 +54,8 @@ def _fused_grad(src, ref, g, need_src):
     weights and the contraction happens inside the slice, so the 2L(1+d)-channel operand and result of :450-463
     (19 GB each at 1390x1110x256) never exist.  None when the fused path does not take the shape (then the caller
     filters the wide operand, as the reference does)."""
+    if os.environ.get("PHL_FUSED_GRAD", "1") == "0":         # A/B switch: the reference's formulation
+        return None
     if not (src.dim() == 2 and ref.dim() == 2 and g.shape == src.shape and src.shape[1] % 4 == 0 and ref.shape[1] <= 7
             and torch.cuda.is_available() and src.dtype == torch.float32 and ref.dtype == torch.float32):
         return None

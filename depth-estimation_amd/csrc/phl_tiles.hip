@@ -894,20 +894,26 @@ __global__ __launch_bounds__(TPB) void k_slice_tiled(const float *__restrict__ v
 // [n, d].  Here one pass (x, y) of phl_filter_grad holds the blurred wide vertex rows [M][NS*L] (block 0 = splat of x,
 // block 1+k = splat of x (x) ref[:, k]; NS = d+1) and this kernel evaluates, per pixel i,
 //     T_ik = -2 / (1 + 2^-d) * ( f_ik * sum_l y_il (Wx)_il  -  sum_l y_il (W(x f_k))_il )
-// without writing any sliced row: a 16-lane group owns 8 pixels of the chunk and keeps their NS running dot products
-// in registers while the chunk's vertex rows pass through LDS one (64-channel slab, block) at a time.  y is read
-// once, the vertex array about twice (chunks overlap), [n, d] is written; (Wx) itself is written on request (it is
-// the gradient w.r.t. the source when x = g).  DIRECT: chunks whose rows do not fit LDS gather them from global.
-template <int NS, bool DIRECT>
-__device__ __forceinline__ void slice_grad_chunk(const float *__restrict__ vertw, int L, int dp1, int cnt, int nv,
-                                                 const uint2 *__restrict__ ent, const int *__restrict__ pixl,
-                                                 const int *__restrict__ vl, float *__restrict__ rows,
+// without writing any sliced row.  Per slab of 4*LG channels the chunk's vertex rows are staged for ALL NS blocks at
+// once ([nv][NS][4*LG] floats), so a chunk passes L / (4 LG) barriers-bounded phases, not NS times as many; an
+// LG-lane group owns 256 / (512 / LG) pixels and keeps their NS running dot products in registers.  y is read once,
+// the vertex array about twice (chunks overlap), [n, d] is written; (Wx) itself is written on request (it is the
+// gradient w.r.t. the source when x = g).  The workgroup picks LG = 8 (32-channel slabs) if its rows fit the LDS it
+// was given, else 4; DIRECT: chunks that fit neither gather their rows from global memory.
+template <int NS, int LG, bool DIRECT>
+__device__ __forceinline__ void slice_grad_chunk(const float *__restrict__ vertw, int L, int cnt, int nv,
+                                                 const uint2 *ent, const int *pixl, const int *vl, float *rows,   // (one LDS block:
+                                                 // NOT restrict -- with it the compiler hoists every pixel's entries and
+                                                 // all NS*NS row addresses out of the slab loop and spills 800 bytes per lane)
                                                  const float *__restrict__ y, int64_t y_rs, const float *__restrict__ ref,
                                                  int64_t ref_rs, int64_t ref_cs, float *__restrict__ grad_ref, int accumulate,
                                                  float *__restrict__ wx_out, int64_t wx_rs, float rcdiv)
 {
-    constexpr int LPRS = 16, SL = 64, G = TPB / LPRS, PPG = 8;
-    const int g = threadIdx.x / LPRS, l = threadIdx.x % LPRS;
+    constexpr int SLG = LG * 4;              // channels per slab
+    constexpr int G = TPB / LG;              // lane groups
+    constexpr int PPG = 256 / G;             // pixels per group (P <= 256)
+    constexpr int PITCH = NS * SLG;          // floats per staged local vertex
+    const int g = threadIdx.x / LG, l = threadIdx.x % LG;
     const int64_t vdw = (int64_t)NS * L;
     float acc[PPG][NS];
 #pragma unroll
@@ -915,59 +921,74 @@ __device__ __forceinline__ void slice_grad_chunk(const float *__restrict__ vertw
 #pragma unroll
         for (int t = 0; t < NS; t++) acc[u][t] = 0.f;
     const int kclamp = cnt - 1;
-    for (int c0 = 0; c0 < L; c0 += SL) {
+    for (int c0 = 0; c0 < L; c0 += SLG) {
         const int ch = c0 + l * 4;
         const bool chok = ch < L;
         const int chc = chok ? ch : 0;
         float4 yv[PPG];
 #pragma unroll
         for (int u = 0; u < PPG; u++) yv[u] = ld4(y + (int64_t)pixl[min(g + u * G, kclamp)] * y_rs + chc);
+        if (!DIRECT) {
+            // [nv][NS][LG] 16-byte pieces, LG consecutive threads on LG consecutive pieces of one (vertex, block)
+            const int total = nv * NS * LG;
+            for (int i0 = threadIdx.x; i0 < total; i0 += 4 * TPB) {
+                float4 q[4];
+                int dsto[4];
 #pragma unroll
-        for (int u = 0; u < PPG; u++)
-            if (!chok || g + u * G >= cnt) yv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-        for (int set = 0; set < NS; set++) {
-            const float *vb = vertw + (int64_t)set * L + chc;
-            if (!DIRECT) {
-                const int iclamp = nv - 1;
-                for (int i0 = g; i0 < nv; i0 += 8 * G) {
-                    float4 q[8];
-#pragma unroll
-                    for (int u = 0; u < 8; u++) q[u] = ld4(vb + (int64_t)vl[min(i0 + u * G, iclamp)] * vdw);
-#pragma unroll
-                    for (int u = 0; u < 8; u++)
-                        if (i0 + u * G < nv) st4(rows + (i0 + u * G) * SL + l * 4, q[u]);
+                for (int u = 0; u < 4; u++) {
+                    const int idx = min(i0 + u * TPB, total - 1);
+                    const int i = idx / (NS * LG), rem = idx - i * (NS * LG);
+                    const int set = rem / LG, ll = rem - set * LG;
+                    const int cc = c0 + ll * 4 < L ? c0 + ll * 4 : 0;
+                    q[u] = ld4(vertw + (int64_t)vl[i] * vdw + (int64_t)set * L + cc);
+                    dsto[u] = i * PITCH + set * SLG + ll * 4;
                 }
-                __syncthreads();
-            }
-            const char *rbase = reinterpret_cast<const char *>(rows) + l * 16;
 #pragma unroll
-            for (int u = 0; u < PPG; u++) {
-                const int k = min(g + u * G, kclamp);
-                const uint2 *ek = ent + k * dp1;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                for (int r = 0; r < dp1; r++) {
-                    const uint2 e0 = ek[r];
-                    const float4 q0 = DIRECT ? ld4(vb + (int64_t)e0.x * vdw) : *reinterpret_cast<const float4 *>(rbase + e0.x);
-                    v = fma4(v, __uint_as_float(e0.y), q0);
-                }
-                acc[u][set] += yv[u].x * v.x + yv[u].y * v.y + yv[u].z * v.z + yv[u].w * v.w;
-                if (set == 0 && wx_out && chok && g + u * G < cnt)
-                    st4(wx_out + (int64_t)pixl[k] * wx_rs + ch, make_float4(v.x * rcdiv, v.y * rcdiv, v.z * rcdiv, v.w * rcdiv));
+                for (int u = 0; u < 4; u++)
+                    if (i0 + u * TPB < total) st4(rows + dsto[u], q[u]);
             }
-            if (!DIRECT) __syncthreads();
+            __syncthreads();
         }
+        const char *rbase = reinterpret_cast<const char *>(rows) + l * 16;
+#pragma unroll
+        for (int u = 0; u < PPG; u++) {
+            const int k = min(g + u * G, kclamp);
+            const bool live = chok && g + u * G < cnt;
+            uint2 e[NS];                       // the pixel's d+1 = NS simplex vertices {row offset | vertex id, weight}
+            const char *pr[NS];
+#pragma unroll
+            for (int r = 0; r < NS; r++) {
+                e[r] = ent[k * NS + r];
+                pr[r] = rbase + e[r].x;         // block `set` of the row: a constant offset from here
+            }
+#pragma unroll
+            for (int set = 0; set < NS; set++) {
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int r = 0; r < NS; r++) {
+                    const float4 q0 = DIRECT ? ld4(vertw + (int64_t)e[r].x * vdw + (int64_t)set * L + chc)
+                                             : *reinterpret_cast<const float4 *>(pr[r] + set * (SLG * 4));
+                    v = fma4(v, __uint_as_float(e[r].y), q0);
+                }
+                const float dot = yv[u].x * v.x + yv[u].y * v.y + yv[u].z * v.z + yv[u].w * v.w;
+                acc[u][set] += live ? dot : 0.f;
+                if (set == 0 && wx_out && live)
+                    st4(wx_out + (int64_t)pixl[k] * wx_rs + ch, make_float4(v.x * rcdiv, v.y * rcdiv, v.z * rcdiv, v.w * rcdiv));
+                // one (pixel, block) at a time: left alone, the compiler issues all NS*NS row reads of a pixel first and
+                // spills them (800 bytes of scratch per lane); sched_barrier did not stop that, this does
+                asm volatile("" : "+v"(acc[u][set])::"memory");
+            }
+        }
+        if (!DIRECT) __syncthreads();
     }
-    // the 16 lanes of a group hold the 64 channels of a slab between them: add their dot products
+    // the LG lanes of a group hold a slab's channels between them: add their dot products
 #pragma unroll
     for (int u = 0; u < PPG; u++)
 #pragma unroll
         for (int t = 0; t < NS; t++) {
             float a = acc[u][t];
-            a += __shfl_xor(a, 8, 16);
-            a += __shfl_xor(a, 4, 16);
-            a += __shfl_xor(a, 2, 16);
-            a += __shfl_xor(a, 1, 16);
+#pragma unroll
+            for (int o = LG / 2; o > 0; o >>= 1) a += __shfl_xor(a, o, LG);
             acc[u][t] = a;
         }
     if (l == 0) {
@@ -988,7 +1009,7 @@ __device__ __forceinline__ void slice_grad_chunk(const float *__restrict__ vertw
 }
 
 template <int NS>
-__global__ __launch_bounds__(TPB) void k_slice_grad(const float *__restrict__ vertw, int L, int n, int P, int dp1, int lds_bytes,
+__global__ __launch_bounds__(TPB) void k_slice_grad(const float *__restrict__ vertw, int L, int n, int P, int lds_bytes,
                                                     const int *__restrict__ pix_order, const int *__restrict__ vptr,
                                                     const int *__restrict__ slot_vert, const unsigned short *__restrict__ lidx,
                                                     const phl_replay_t *__restrict__ replay, const float *__restrict__ y,
@@ -997,6 +1018,7 @@ __global__ __launch_bounds__(TPB) void k_slice_grad(const float *__restrict__ ve
                                                     int64_t wx_rs, float rcdiv, int nchunks, int xcd_chunk)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int dp1 = NS;
     const int c = xcd_chunk > 0 ? (int)(blockIdx.x & 7) * xcd_chunk + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
     if (c >= nchunks) return;
     const int base = c * P;
@@ -1009,24 +1031,29 @@ __global__ __launch_bounds__(TPB) void k_slice_grad(const float *__restrict__ ve
     int *vl = pixl + P;
     const int fixed = (P * dp1 * 8 + P * 4 + nv * 4 + 15) & ~15;
     float *rows = reinterpret_cast<float *>(reinterpret_cast<char *>(lds) + fixed);
-    const bool direct = fixed + (int64_t)nv * 256 > lds_bytes;       // workgroup-uniform
+    // workgroup-uniform choice: 32-channel slabs, 16-channel slabs, or no staging
+    const int mode = fixed + (int64_t)nv * (NS * 128) <= lds_bytes ? 8 : (fixed + (int64_t)nv * (NS * 64) <= lds_bytes ? 4 : 0);
+    const unsigned pitch_bytes = (unsigned)NS * (mode == 8 ? 128u : 64u);
     for (int k = threadIdx.x; k < cnt; k += TPB) pixl[k] = pix_order[base + k];
-    if (!direct)
+    if (mode)
         for (int i = threadIdx.x; i < nv; i += TPB) vl[i] = slot_vert[vbase + i] & 0x7FFFFFFF;
     for (int e = threadIdx.x; e < E; e += TPB) {
         const int k = e / dp1, r = e - k * dp1;
         const int p = pix_order[base + k];
         const unsigned li = lidx[ebase + e];
-        ent[e] = make_uint2(direct ? (unsigned)(slot_vert[vbase + li] & 0x7FFFFFFF) : li * 256u,
+        ent[e] = make_uint2(mode ? li * pitch_bytes : (unsigned)(slot_vert[vbase + li] & 0x7FFFFFFF),
                             __float_as_uint(replay[(int64_t)p * dp1 + r].w));
     }
     __syncthreads();
-    if (direct)
-        slice_grad_chunk<NS, true>(vertw, L, dp1, cnt, nv, ent, pixl, vl, rows, y, y_rs, ref, ref_rs, ref_cs, grad_ref, accumulate,
-                                   wx_out, wx_rs, rcdiv);
+    if (mode == 8)
+        slice_grad_chunk<NS, 8, false>(vertw, L, cnt, nv, ent, pixl, vl, rows, y, y_rs, ref, ref_rs, ref_cs, grad_ref, accumulate,
+                                       wx_out, wx_rs, rcdiv);
+    else if (mode == 4)
+        slice_grad_chunk<NS, 4, false>(vertw, L, cnt, nv, ent, pixl, vl, rows, y, y_rs, ref, ref_rs, ref_cs, grad_ref, accumulate,
+                                       wx_out, wx_rs, rcdiv);
     else
-        slice_grad_chunk<NS, false>(vertw, L, dp1, cnt, nv, ent, pixl, vl, rows, y, y_rs, ref, ref_rs, ref_cs, grad_ref, accumulate,
-                                    wx_out, wx_rs, rcdiv);
+        slice_grad_chunk<NS, 8, true>(vertw, L, cnt, nv, ent, pixl, vl, rows, y, y_rs, ref, ref_rs, ref_cs, grad_ref, accumulate,
+                                      wx_out, wx_rs, rcdiv);
 }
 
 // vs[e].w <- partial-buffer row of the slot (bit pattern of an int): saves the reduce kernels one dependent load
@@ -1790,7 +1817,7 @@ int phl_launch_slice_grad(const phl_lattice *lat, const float *vertw, int L, con
         return PHL_ERR_UNSUPPORTED;
     }
     const int64_t fixed = (((int64_t)lat->P * dp1 * 8 + (int64_t)lat->P * 4 + (int64_t)lat->nv_max * 4 + 15) & ~(int64_t)15);
-    int64_t lds = fixed + (int64_t)lat->nv_max * 256;
+    int64_t lds = fixed + (int64_t)lat->nv_max * dp1 * 128;      // every chunk on 32-channel slabs, if the budget allows
     if (lds > lds_budget()) lds = lds_budget();
     const float rcdiv = 1.0f / (1 + powf(2, -lat->d));      // permutohedral.h:480
     unsigned cgrid;
@@ -1800,7 +1827,7 @@ int phl_launch_slice_grad(const phl_lattice *lat, const float *vertw, int L, con
 #define PHL_SG(NS_)                                                                                                          \
     case NS_:                                                                                                                \
         if ((rc = allow_lds(k_slice_grad<NS_>, (size_t)lds)) != PHL_OK) return rc;                                           \
-        k_slice_grad<NS_><<<dim3(cgrid), dim3(TPB), (size_t)lds, st>>>(vertw, L, (int)lat->n, lat->P, dp1, (int)lds,         \
+        k_slice_grad<NS_><<<dim3(cgrid), dim3(TPB), (size_t)lds, st>>>(vertw, L, (int)lat->n, lat->P, (int)lds,              \
             lat->pix_order, lat->chunk_vptr, lat->slot_vert, lat->lidx, lat->replay, y, y_rs, ref, ref_rs, ref_cs, grad_ref, \
             accumulate, wx_out, wx_rs, rcdiv, lat->nchunks, xcd_chunk);                                                      \
         break;
