@@ -664,6 +664,10 @@ def main():
         check = self_check(torch, phl, dist, backend, rank, world, device, rowtiled, job if rowtiled else None,
                            lat if not rowtiled else None, feat, H, W, L, d, src, out_rt if rowtiled else out)
 
+    small = None
+    if rank == 0 and world == 1 and not rowtiled and args.mean_field and default_features:
+        small = small_image(torch, phl, device)
+
     cpu = None
     if rank == 0 and world == 1 and not rowtiled and not args.no_cpu_baseline:
         cpu = cpu_baseline(feat, H, W, L, d)
@@ -698,6 +702,8 @@ def main():
             line["mean_field_iteration"] = mean_field
         if regimes is not None:
             line["regimes"] = regimes
+        if small is not None:
+            line["c1_small_image"] = small
         if check is not None:
             line["check"] = check
         line.update(extra)
@@ -794,6 +800,56 @@ def regime_sweep(torch, phl, H, W, L, d, src, out, base_ms, base_M):
         lat.close()
         del lat
     return rows
+
+
+def small_image(torch, phl, device):
+    """BASELINE configs[0] geometry (Tsukuba 384x288x16, 5 mean-field iterations) -- the only size the reference's
+    notebook runs (DenseCrf.ipynb:95-115) -- on the GPU, eagerly and replayed from one HIP graph: the two agree, i.e.
+    at this size the chain of seven dependent few-microsecond kernels per filter is what takes the time, not the host
+    issuing them.  cpu_baseline.c1_full is the reference engine's time for ONE filter call at this size."""
+    import crf.crf_module as cm
+    from crf.gaussian_matrix import LatticeGaussian
+
+    H, W, L, _ = WORKLOADS["c1"]
+    d, niters = 5, 5
+    ref = torch.from_numpy(synthetic_features(H, W).reshape(-1, d)).to(device)
+    E0 = torch.rand((H * W, L), device=device, generator=torch.Generator(device=device).manual_seed(7)) * 10.0
+    labels = torch.arange(L, dtype=torch.float32, device=device)
+    Mu = cm.compatibility_matrix(lambda a, b: cm.charbonneir(a, b, 3.0), labels)
+    Wop = LatticeGaussian(ref)
+    lat = phl.lattice_for(ref)
+    src = torch.softmax(-E0, dim=1)
+    out = torch.empty_like(src)
+
+    def wall(fn, reps):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps * 1e3
+
+    res = {"workload": f"c1: {W}x{H}x{L}, d=5, {niters} mean-field iterations", "M_over_n": round(lat.M / (H * W), 4)}
+    res["filter_ms_eager"] = round(wall(lambda: lat.filter(src, out=out), 200), 5)
+    g = torch.cuda.CUDAGraph()
+    lat.filter(src, out=out)
+    torch.cuda.synchronize()
+    with torch.cuda.graph(g):
+        lat.filter(src, out=out)
+    res["filter_ms_graph"] = round(wall(g.replay, 200), 5)
+    res["mean_field_ms_eager"] = round(wall(lambda: cm.mean_field_infer(E0, Wop, Mu, niters), 50), 4)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        cm.mean_field_infer(E0, Wop, Mu, niters)             # warm-up on the capture stream
+    torch.cuda.current_stream().wait_stream(side)
+    g2 = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g2, stream=side):
+        cm.mean_field_infer(E0, Wop, Mu, niters)
+    res["mean_field_ms_graph"] = round(wall(g2.replay, 50), 4)
+    res["Mpixel_labels_per_s_per_iter_graph"] = round(H * W * L * niters / (res["mean_field_ms_graph"] * 1e-3) / 1e6, 1)
+    return res
 
 
 def mean_field_iteration(torch, phl, lat, Q, L, device):

@@ -165,28 +165,62 @@ def _mean_field_nchw(E0, message, niters):
     return E
 
 
+_nchw_streams = {}
+
+
 def _mean_field_nchw_fused(E0, refs, M, niters):
     """The same iteration for a lattice W, without autograd, the way the device wants it: one transpose to
     pixel-major [n, L] per image on entry, then per iteration ONE lattice filter with the ``- Q`` fused
     (phl_filter) and ONE fused compatibility-product + softmax kernel (phl_compat_softmax), and one transpose
     back at the end -- Q, G and E never make extra passes over HBM.  The reference evaluates
-    W(Mu(Q)); here (W Q) Mu: W acts on pixels, Mu on labels, so they commute (fp32 rounding differs)."""
+    W(Mu(Q)); here (W Q) Mu: W acts on pixels, Mu on labels, so they commute (fp32 rounding differs).
+
+    Batch items are independent (the reference hands them to a process pool, gaussian_matrix.py:370-377): they are
+    dealt over phl.batch_devices (the tensors' own GPU, or all GPUs with PHL_BATCH_DEVICES=all / CPU inputs), two
+    side streams per device, so that image b+1's lattice build and transposes run under image b's iterations; both
+    transposes go through the library's LDS-tiled phl_copy2d."""
     import phl
 
     bs, L, h, w = E0.shape
     d = refs.shape[1]
+    n = h * w
+    if niters <= 0:
+        return E0
     out = torch.empty_like(E0)
+    home = E0.device
+    devices = phl.batch_devices(E0)
+    cur = torch.cuda.current_stream(home)
+    used = []
     for b in range(bs):
-        e0 = E0[b].reshape(L, h * w).t().contiguous()                      # [n, L]
-        lat = phl.lattice_for(refs[b].detach().reshape(d, h * w).t())       # strided [n, d] view, no copy
-        Q = phl.softmax_neg_add(e0)
-        for it in range(niters):
-            X = lat.filter(Q, subtract_input=True)
-            last = it == niters - 1
-            Q = phl.compat_softmax(e0, X, M, out=Q, logits=last)
-        res = Q if niters > 0 else e0
-        out[b].reshape(L, h * w).copy_(res.t())
-    return out if niters > 0 else E0
+        dev = devices[b % len(devices)]
+        lane = (b // len(devices)) % 2
+        st = _nchw_streams.get((dev, lane))
+        if st is None:
+            st = _nchw_streams[(dev, lane)] = torch.cuda.Stream(device=dev)
+        st.wait_stream(cur)
+        with torch.cuda.device(dev), torch.cuda.stream(st):
+            e_b, r_b = E0[b], refs[b].detach()
+            if dev != home:
+                e_b, r_b = e_b.to(dev, non_blocking=True), r_b.to(dev, non_blocking=True)
+            e0 = torch.empty((n, L), dtype=torch.float32, device=dev)
+            phl.copy2d(e0, e_b.reshape(L, n).t())                         # [L, n] channel-major -> [n, L]
+            lat = phl.lattice_for(r_b.reshape(d, n).t(), device=dev)      # strided [n, d] view, no copy
+            Q = phl.softmax_neg_add(e0)
+            for it in range(niters):
+                X = lat.filter(Q, subtract_input=True)
+                Q = phl.compat_softmax(e0, X, M if M.device == dev else M.to(dev), out=Q, logits=it == niters - 1)
+            if dev == home:
+                phl.copy2d(out[b].reshape(L, n).t(), Q)
+            else:
+                back = torch.empty((L, n), dtype=torch.float32, device=dev)
+                phl.copy2d(back.t(), Q)
+                out[b].reshape(L, n).copy_(back, non_blocking=True)
+            for t in (e0, Q, e_b, r_b):
+                t.record_stream(st)
+        used.append(st)
+    for st in used:
+        cur.wait_stream(st)
+    return out
 
 
 class CRFasRNN(nn.Module):

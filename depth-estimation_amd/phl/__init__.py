@@ -92,6 +92,7 @@ def load_library():
         lib.phl_compat_softmax.argtypes = [vp, i64, vp, i64, vp, vp, i64, i64, i32, u32, vp]
         lib.phl_uniform_compat_softmax.argtypes = [vp, i64, vp, i64, C.c_float, C.c_float, vp, i64, i64, i32, u32, vp]
         lib.phl_stream_copy.argtypes = [vp, vp, i64, vp]
+        lib.phl_copy2d.argtypes = [vp, i64, i64, vp, i64, i64, i64, i32, vp]
         lib.phl_cost_volume.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, vp, i64, vp]
         lib.phl_get_keys.argtypes = [vp, vp]
         lib.phl_get_vertex_order.argtypes = [vp, vp]
@@ -520,6 +521,17 @@ def stream_copy(dst, src):
     with torch.cuda.device(src.device):
         _check(load_library().phl_stream_copy(C.c_void_p(src.data_ptr()), C.c_void_p(dst.data_ptr()), src.numel(),
                                               _stream(src.device)))
+    return dst
+
+
+def copy2d(dst, src):
+    """dst[...] = src[...] for 2-D fp32 device tensors of equal shape and ANY strides, through the library's LDS-tiled
+    transpose (phl_copy2d): the NCHW <-> pixel-major hops of the batched API."""
+    assert dst.shape == src.shape and dst.dim() == 2 and dst.is_cuda and src.device == dst.device
+    assert dst.dtype == torch.float32 and src.dtype == torch.float32
+    with torch.cuda.device(dst.device):
+        _check(load_library().phl_copy2d(C.c_void_p(src.data_ptr()), src.stride(0), src.stride(1), C.c_void_p(dst.data_ptr()),
+                                         dst.stride(0), dst.stride(1), int(dst.shape[0]), int(dst.shape[1]), _stream(dst.device)))
     return dst
 
 

@@ -258,6 +258,11 @@ int phl_cost_volume(const float *img1_dev, const float *img2_dev, int h, int w, 
 /* Plain float4 streaming copy dst <- src (n_floats % 4 == 0, 16-byte aligned): measures the
  * HBM read+write ceiling of the box that the roofline fractions are compared with. */
 int phl_stream_copy(const float *src_dev, float *dst_dev, int64_t n_floats, phl_stream stream);
+/* dst[r*dst_rs + c*dst_cs] = src[r*src_rs + c*src_cs] for rows x cols floats (LDS-tiled: both sides coalesced): the
+ * transpose between the reference's NCHW tensors (BatchedAdjacency's channel-major [n, L] views,
+ * crf/gaussian_matrix.py:345-349) and the pixel-major rows the kernels work on.  Current device, given stream. */
+int phl_copy2d(const float *src_dev, int64_t src_row_stride, int64_t src_col_stride, float *dst_dev, int64_t dst_row_stride,
+               int64_t dst_col_stride, int64_t rows, int cols, phl_stream stream);
 
 /* Chunk ("tile") statistics of the LDS-staged path: out[0]=pixels per chunk, [1]=#chunks,
  * [2]=max local vertices per chunk, [3]=(chunk,vertex) slots S, [4]=slots of vertices fed by

@@ -486,3 +486,41 @@ def test_compat_softmax_repeatable_under_background_traffic():
         phl.compat_softmax(E0, X, Mu, out=out)
         assert torch.equal(out, first), f"launch {it} differs from the first"
     torch.cuda.synchronize()
+
+
+def test_mean_field_inference_can_be_captured_into_a_graph():
+    """Tsukuba-sized inference (the only size the reference's notebook runs) captured into ONE HIP graph by the
+    caller: after a warm-up call every buffer exists, the capture allocates only from torch's graph pool, and the
+    replay equals the eager result bit for bit and follows in-place changes of E_0.  (At this size the kernels, not
+    the launches, take the time -- bench.py c1_small_image -- so mean_field_infer does not do this by itself.)"""
+    import crf.crf_module as cm
+    from crf.gaussian_matrix import LatticeGaussian
+
+    dev = torch.device("cuda")
+    rng = np.random.default_rng(2)
+    H, W, L = 96, 128, 16
+    feat = np.empty((H, W, 5), np.float32)
+    feat[..., 0] = (np.arange(W, dtype=np.float32) / 6)[None, :]
+    feat[..., 1] = (np.arange(H, dtype=np.float32) / 6)[:, None]
+    feat[..., 2:] = np.kron(rng.random((H // 8, W // 8, 3)).astype(np.float32), np.ones((8, 8, 1), np.float32)) * 4
+    ref = torch.from_numpy(feat.reshape(-1, 5)).to(dev)
+    E0 = torch.from_numpy(rng.random((H * W, L), dtype=np.float32) * 8).to(dev)
+    labels = torch.arange(L, dtype=torch.float32, device=dev)
+    Mu = cm.compatibility_matrix(lambda a, b: cm.charbonneir(a, b, 3.0), labels)
+    Wop = LatticeGaussian(ref)
+    eager = cm.mean_field_infer(E0, Wop, Mu, 5)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        cm.mean_field_infer(E0, Wop, Mu, 5)                   # warm-up on the capture stream
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        out = cm.mean_field_infer(E0, Wop, Mu, 5)
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, eager)
+    E0.mul_(0.5)
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, cm.mean_field_infer(E0, Wop, Mu, 5)) and not torch.equal(out, eager)
