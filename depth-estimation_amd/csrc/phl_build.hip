@@ -507,11 +507,12 @@ int phl_build_device(phl_lattice *lat, const float *ref, int64_t rs, int64_t cs,
     PHL_HIP(hipGetLastError());
     if (lat->vfirst) PHL_HIP(phl_dev_free(lat->vfirst));
     lat->vfirst = nullptr;
+    lat->vfirst_valid_for_M = 0;
     if (lat->build_flags & PHL_BUILD_REFERENCE_TABLE) {
         rc = phl_apply_reference_table(lat, flag, rankv, st);
         if (rc) return rc;
     }
-    if (lat->M == M && M > 0) {     // (the reference-table mode may have inserted duplicate vertices: no list then)
+    if (lat->M == M && M > 0 && lat->vfirst_valid_for_M != lat->M) {     // (duplicate vertices inserted: the replay wrote its own list)
         PHL_HIP(phl_dev_malloc((void **)&lat->vfirst, sizeof(int) * (size_t)M));
         hipLaunchKernelGGL(k_first_candidate, dim3(gN), dim3(256), 0, st, flag, rankv, N, lat->vfirst);
         PHL_HIP(hipGetLastError());

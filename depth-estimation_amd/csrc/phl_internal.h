@@ -43,6 +43,7 @@ struct phl_lattice {
     // Internal vertex numbering (phl_renumber_vertices): rows of every [M][..] array are in LOCALITY order, not in
     // first-touch order.  Both maps are null when the two coincide.  The public introspection calls translate.
     int32_t *vfirst;        // [M] first-touch candidate (pixel*(d+1)+remainder) per vertex: build-time only, may be null
+    int64_t vfirst_valid_for_M;   // the reference-table replay wrote vfirst for this many vertices (0: it did not)
     int32_t *ft_of_int;     // [M] first-touch id of internal vertex i
     int32_t *int_of_ft;     // [M] internal id (row) of first-touch vertex v
 
