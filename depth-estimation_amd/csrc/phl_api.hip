@@ -762,9 +762,10 @@ int phl_filter_once(const float *src, int vd, int64_t src_rs, int64_t src_cs, co
                     phl_stream stream)
 {
     phl_lattice *lat = nullptr;
-    int rc = phl_build(&lat, ref, n, d, ref_rs, ref_cs, device, stream);
+    int rc = phl_build_ex(&lat, ref, n, d, ref_rs, ref_cs, device, stream,
+                          (flags & PHL_FILTER_CLEAN_TABLE) ? PHL_BUILD_DEFAULT : PHL_BUILD_REFERENCE_TABLE);
     if (rc) return rc;
-    rc = phl_filter(lat, src, vd, src_rs, src_cs, out, out_rs, out_cs, flags, stream);
+    rc = phl_filter(lat, src, vd, src_rs, src_cs, out, out_rs, out_cs, flags & ~(unsigned)PHL_FILTER_CLEAN_TABLE, stream);
     if (rc == PHL_OK) {
         device_guard g(device);
         hipError_t e = hipStreamSynchronize((hipStream_t)stream);  // workspace dies with the lattice

@@ -64,7 +64,11 @@ enum phl_filter_flags {
        same algorithm, fp32 rounding differences of ~1e-7 relative, ~1.3x faster. */
     PHL_FILTER_EXACT = 4,
     /* do not use the LDS-staged chunk kernels at all (plain gather splat and slice) */
-    PHL_FILTER_NO_TILES = 8
+    PHL_FILTER_NO_TILES = 8,
+    /* phl_filter_once only (it builds its own lattice): the defect-free table, one vertex per key, instead of the
+       reference's table behaviour (PHL_BUILD_REFERENCE_TABLE), which is what the one-shot call -- the drop-in for
+       lattice.filter(src, ref) -- builds by default */
+    PHL_FILTER_CLEAN_TABLE = 16
 };
 
 enum phl_build_flags {
@@ -150,7 +154,8 @@ int phl_filter(phl_lattice *lat, const float *src_dev, int vd, int64_t src_row_s
                int64_t out_col_stride, unsigned flags, phl_stream stream);
 
 /* One-shot call with the reference's argument order (src first, ref second):
- * builds, filters, destroys -- what lattice.filter(src, ref) does on every call. */
+ * builds, filters, destroys -- what lattice.filter(src, ref) does on every call.  The lattice is built with
+ * PHL_BUILD_REFERENCE_TABLE (results are the reference's at any size) unless flags has PHL_FILTER_CLEAN_TABLE. */
 int phl_filter_once(const float *src_dev, int vd, int64_t src_row_stride, int64_t src_col_stride,
                     const float *ref_dev, int d, int64_t ref_row_stride, int64_t ref_col_stride,
                     int64_t n, float *out_dev, int64_t out_row_stride, int64_t out_col_stride,
