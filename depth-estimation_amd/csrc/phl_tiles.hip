@@ -834,17 +834,30 @@ __global__ __launch_bounds__(TPB) void k_slice_tiled(const float *__restrict__ v
                                                      const unsigned short *__restrict__ lidx,
                                                      const phl_replay_t *__restrict__ replay, float *__restrict__ out,
                                                      int64_t out_rs, const float *__restrict__ sub_src, int64_t sub_rs,
-                                                     float cdiv, float rcdiv, int nchunks, int xcd_chunk)
+                                                     float cdiv, float rcdiv, int nchunks, int xcd_chunk,
+                                                     const int *__restrict__ heavy_list, int heavy_n, int heavy_pad, int heavy_thr)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    // XCD-aware chunk order (see k_blur): neighbouring chunks share boundary vertices
-    const int c = xcd_chunk > 0 ? (int)(blockIdx.x & 7) * xcd_chunk + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
-    if (c >= nchunks) return;
+    // Heavy chunks first: the first heavy_pad blocks take the heavy_n chunks with more than heavy_thr local vertices
+    // (narrow slabs, several times the work of a typical chunk) so that they run under the bulk instead of forming
+    // the launch's tail; the other blocks walk all chunks in the XCD-aware order (see k_blur: neighbouring chunks
+    // share boundary vertices) and skip those.  heavy_pad is a multiple of 8: the XCD of a chunk does not move.
+    int c;
+    const bool heavy_block = (int)blockIdx.x < heavy_pad;
+    if (heavy_block) {
+        if ((int)blockIdx.x >= heavy_n) return;
+        c = heavy_list[blockIdx.x];
+    } else {
+        const int b = (int)blockIdx.x - heavy_pad;
+        c = xcd_chunk > 0 ? (b & 7) * xcd_chunk + (b >> 3) : b;
+        if (c >= nchunks) return;
+    }
     const int base = c * P;
     const int cnt = min(P, n - base);
     const int E = cnt * dp1;
     const int64_t ebase = (int64_t)base * dp1;
     const int vbase = vptr[c], nv = vptr[c + 1] - vbase;
+    if (!heavy_block && nv > heavy_thr) return;
     // index data first (its size does not depend on the slab width), rows behind it
     uint2 *ent = reinterpret_cast<uint2 *>(lds);                    // [P*dp1] {row offset or vertex id, weight}
     int *pixl = reinterpret_cast<int *>(ent + P * dp1);             // [P]
@@ -1789,16 +1802,28 @@ int phl_launch_slice_tiled(const phl_lattice *lat, const float *vert, int vd, fl
     unsigned cgrid;
     int xcd_chunk;
     chunk_grid(lat->nchunks, &cgrid, &xcd_chunk);
+    // heavy chunks = those that cannot take at least half the widest slab; worth a head start only if they are few
+    int heavy_thr = 0x7FFFFFFF, heavy_n = 0;
+    if (lat->nv_cum && lat->chunk_by_nv && cfg.lsh_max > 2) {
+        const int64_t fixed0 = (int64_t)lat->P * (lat->d + 1) * 8 + (int64_t)lat->P * 4 + 16;
+        const int thr = (int)(((int64_t)cfg.lds - fixed0) / ((16 << (cfg.lsh_max - 1)) + 4));
+        const int above = chunks_above(lat, thr);
+        if (above > 0 && (int64_t)above * 16 <= lat->nchunks) { heavy_thr = thr; heavy_n = above; }
+    }
+    const int heavy_pad = (heavy_n + 7) & ~7;
+    cgrid += (unsigned)heavy_pad;
     if (exact) {
         if ((rc = allow_lds(k_slice_tiled<true>, cfg.lds)) != PHL_OK) return rc;
         k_slice_tiled<true><<<dim3(cgrid), dim3(TPB), cfg.lds, st>>>(
             vert, vd, (int)lat->n, lat->P, lat->d + 1, cfg.lsh_max, (int)cfg.lds, lat->pix_order, lat->chunk_vptr, lat->slot_vert,
-            lat->lidx, lat->replay, out, out_rs, sub, sub_rs, cdiv, rcdiv, lat->nchunks, xcd_chunk);
+            lat->lidx, lat->replay, out, out_rs, sub, sub_rs, cdiv, rcdiv, lat->nchunks, xcd_chunk, lat->chunk_by_nv, heavy_n,
+            heavy_pad, heavy_thr);
     } else {
         if ((rc = allow_lds(k_slice_tiled<false>, cfg.lds)) != PHL_OK) return rc;
         k_slice_tiled<false><<<dim3(cgrid), dim3(TPB), cfg.lds, st>>>(
             vert, vd, (int)lat->n, lat->P, lat->d + 1, cfg.lsh_max, (int)cfg.lds, lat->pix_order, lat->chunk_vptr, lat->slot_vert,
-            lat->lidx, lat->replay, out, out_rs, sub, sub_rs, cdiv, rcdiv, lat->nchunks, xcd_chunk);
+            lat->lidx, lat->replay, out, out_rs, sub, sub_rs, cdiv, rcdiv, lat->nchunks, xcd_chunk, lat->chunk_by_nv, heavy_n,
+            heavy_pad, heavy_thr);
     }
     if (rc) return rc;
     PHL_HIP(hipGetLastError());
