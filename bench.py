@@ -130,8 +130,24 @@ def tsukuba_features(H, W, sigma_c, sigma_p):
     return feat
 
 
-def features_for(H, W, sigma_xy=SIGMA_XY, sigma_c=SIGMA_C, iid=False, tsukuba=None):
-    """One place that turns the bench's feature options into [H, W, 5] features and a short label."""
+def xyd_features(H, W, sigma_xy=SIGMA_XY, sigma_d=1.0, max_disp=64.0):
+    """The north star's other feature set, (x, y, disparity): d = 3.  Disparity = a smooth field in [0, max_disp]
+    (one channel of the SURVEY 8d noise recipe) / sigma_d.  Returns [H, W, 3] fp32."""
+    rng = np.random.default_rng(4242)
+    disp = box_blur(box_blur(rng.standard_normal((H, W, 1)).astype(np.float32), 16), 16)
+    disp -= disp.min()
+    disp *= max_disp / disp.max()
+    feat = np.empty((H, W, 3), np.float32)
+    feat[..., 0] = (np.arange(W, dtype=np.float32) / sigma_xy)[None, :]
+    feat[..., 1] = (np.arange(H, dtype=np.float32) / sigma_xy)[:, None]
+    feat[..., 2] = disp[..., 0] / sigma_d
+    return feat
+
+
+def features_for(H, W, sigma_xy=SIGMA_XY, sigma_c=SIGMA_C, iid=False, tsukuba=None, xyd=None):
+    """One place that turns the bench's feature options into [H, W, d] features and a short label."""
+    if xyd is not None:
+        return xyd_features(H, W, sigma_xy, xyd), f"(x, y, disparity) d=3 sigma_xy={sigma_xy} sigma_d={xyd}"
     if tsukuba is not None:
         sc, sp = tsukuba
         return tsukuba_features(H, W, sc, sp), f"tsukuba-upsampled sigma_c={sc} sigma_p={sp}"

@@ -139,10 +139,18 @@ class BatchedLatticeFilter(Function):
         with torch.no_grad():
             g = grad_output
             if need_ref:
-                wall = batched_filter(_wide_operand(srcs, refs, g), refs, ctx.num_threads)
-                grad_reference = _ref_gradient(srcs, refs, g, wall)
-                if need_src:
-                    grad_source = wall[..., :srcs.shape[-1]]
+                # item by item through the fused kernels (phl_filter_grad) where they take the shape
+                fused = [_fused_grad(srcs[i].contiguous(), refs[i].contiguous(), g[i].contiguous(), need_src)
+                         for i in range(srcs.shape[0])] if srcs.dim() == 3 else [None]
+                if all(f is not None for f in fused):
+                    grad_reference = torch.stack([f[1] for f in fused])
+                    if need_src:
+                        grad_source = torch.stack([f[0] for f in fused])
+                else:
+                    wall = batched_filter(_wide_operand(srcs, refs, g), refs, ctx.num_threads)
+                    grad_reference = _ref_gradient(srcs, refs, g, wall)
+                    if need_src:
+                        grad_source = wall[..., :srcs.shape[-1]]
             elif need_src:
                 grad_source = batched_filter(g, refs, ctx.num_threads)
         return grad_source, grad_reference, None

@@ -662,6 +662,200 @@ __global__ __launch_bounds__(TPB_S) void k_splat_tiled(const float *__restrict__
     }
 }
 
+// ---- wide splat, one sum phase per slab -------------------------------------------------------------------------------
+// phl_filter_grad's first stage: vertex rows [set][vd], set 0 = splat of src, set 1+k = splat of src (x) fref[:, k]
+// (NS = d+1 sets).  k_splat_tiled's nsets > 1 mode runs its sum phase NS times per slab, re-staging the entry weights in
+// between: NS times the LDS row reads, which is what bounds it (1.56 ms at C2 against 0.42 for a plain splat).  Here
+// every LDS row read feeds NS accumulators: a lane keeps its entry's barycentric weight AND its pixel's d features
+// (gathered from the L2-resident feature rows one batch ahead), and per entry the weights w, w*f_0 ... w*f_{d-1} are
+// formed from row broadcasts.  Same products, same summation order, same combine as the nsets > 1 mode: bitwise the
+// same rows.  64-channel slabs (16 lanes per row) only; other widths keep the multi-phase mode.
+// one entry (lane K of every DPP row) into all NS accumulators; K must be a literal for the DPP control field
+template <int K, int NS>
+__device__ __forceinline__ void wide_entry(float4 (&acc)[NS], const float4 q, const float w, const float (&f)[NS > 1 ? NS - 1 : 1])
+{
+    acc[0] = fma4(acc[0], w, q);
+#define PHL_WJ(j)                                                                                            \
+    if constexpr (j + 1 < NS) {                                                                              \
+        const float wj = w * __uint_as_float(PHL_ROW_BCAST(__float_as_uint(f[j < NS - 1 ? j : 0]), K));      \
+        acc[j + 1 < NS ? j + 1 : 0] = fma4(acc[j + 1 < NS ? j + 1 : 0], wj, q);                              \
+    }
+    PHL_WJ(0) PHL_WJ(1) PHL_WJ(2) PHL_WJ(3) PHL_WJ(4) PHL_WJ(5) PHL_WJ(6)
+#undef PHL_WJ
+}
+
+// four consecutive entries K0..K0+3: the four row reads in flight together, then the NS x 4 accumulations
+template <int K0, int NS>
+__device__ __forceinline__ void sum4w(float4 (&acc)[NS], const uint2 e, const float (&f)[NS > 1 ? NS - 1 : 1], const char *rbase)
+{
+    const float w0 = __uint_as_float(PHL_ROW_BCAST(e.y, K0 + 0)), w1 = __uint_as_float(PHL_ROW_BCAST(e.y, K0 + 1));
+    const float w2 = __uint_as_float(PHL_ROW_BCAST(e.y, K0 + 2)), w3 = __uint_as_float(PHL_ROW_BCAST(e.y, K0 + 3));
+    const float4 q0 = *reinterpret_cast<const float4 *>(rbase + PHL_ROW_BCAST(e.x, K0 + 0));
+    const float4 q1 = *reinterpret_cast<const float4 *>(rbase + PHL_ROW_BCAST(e.x, K0 + 1));
+    const float4 q2 = *reinterpret_cast<const float4 *>(rbase + PHL_ROW_BCAST(e.x, K0 + 2));
+    const float4 q3 = *reinterpret_cast<const float4 *>(rbase + PHL_ROW_BCAST(e.x, K0 + 3));
+    wide_entry<K0 + 0, NS>(acc, q0, w0, f);
+    wide_entry<K0 + 1, NS>(acc, q1, w1, f);
+    wide_entry<K0 + 2, NS>(acc, q2, w2, f);
+    wide_entry<K0 + 3, NS>(acc, q3, w3, f);
+}
+
+template <int NS>
+__global__ __launch_bounds__(TPB_S) void k_splat_wide(const float *__restrict__ src, int64_t src_rs, int vd, int n, int P,
+                                                    int nv_cap, const int *__restrict__ pix_order, const int *__restrict__ vptr,
+                                                    const int *__restrict__ slot_vert, const int *__restrict__ slot_pidx,
+                                                    const int2 *__restrict__ seg_rng, const phl_contrib_t *__restrict__ seg,
+                                                    float *__restrict__ vert, float *__restrict__ partial, int nchunks, int xcd_chunk,
+                                                    const int *__restrict__ chunk_list, int nv_lo, int nv_hi, int long_seg,
+                                                    const float *__restrict__ fref, int64_t fref_rs, int64_t fref_cs)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int LPRS = 16, SL = 64, G = TPB_S / LPRS, Q = 4, NW = TPB_S / 64, PF = 8, NF = NS - 1, dp1 = NS;
+    const int g = threadIdx.x / LPRS, l = threadIdx.x % LPRS;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int q = lane / LPRS;
+    const int ci = xcd_chunk > 0 ? (int)(blockIdx.x & 7) * xcd_chunk + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    if (ci >= nchunks) return;
+    const int c = chunk_list ? chunk_list[ci] : ci;
+    const int base = c * P;
+    const int cnt = min(P, n - base);
+    const int E = cnt * dp1;
+    const int64_t ebase = (int64_t)base * dp1;
+    const int vbase = vptr[c], nv = vptr[c + 1] - vbase;
+    if (nv <= nv_lo || nv > nv_hi) return;
+    const int64_t out_rs = (int64_t)NS * vd;
+    // LDS layout and prologue as in k_splat_tiled<16>
+    float *rows = lds;
+    uint2 *ent = reinterpret_cast<uint2 *>(lds + (size_t)(P + 1) * SL);
+    int2 *meta = reinterpret_cast<int2 *>(ent + P * dp1);
+    int *pixl = reinterpret_cast<int *>(meta + nv_cap);
+    int *ctr = pixl + P;
+    const int kclamp = cnt - 1;
+    const char *rbase = reinterpret_cast<const char *>(rows) + l * 16;
+    float4 pf[PF];
+    int prow[PF];
+#pragma unroll
+    for (int u = 0; u < PF; u++) prow[u] = pix_order[base + min(g + u * G, kclamp)];
+    for (int e = threadIdx.x; e < E; e += TPB_S) {
+        const phl_contrib_t sg = seg[ebase + e];
+        ent[e] = make_uint2((unsigned)(sg.pixel * SL * 4), __float_as_uint(sg.w));
+    }
+    for (int k = threadIdx.x; k < cnt; k += TPB_S) pixl[k] = pix_order[base + k];
+    for (int i = threadIdx.x; i < nv; i += TPB_S) {
+        const int2 rg = seg_rng[vbase + i];
+        const int sv = slot_vert[vbase + i];
+        meta[i] = make_int2((int)(rg.x - ebase) | ((int)(rg.y - ebase) << 16), sv < 0 ? sv : slot_pidx[vbase + i]);
+        const bool lng = rg.y - rg.x >= long_seg;
+        if (i + 1 < nv) {
+            const int2 rn = seg_rng[vbase + i + 1];
+            if (lng && rn.y - rn.x < long_seg) ctr[2] = i + 1;
+        } else if (lng) {
+            ctr[2] = nv;
+        }
+        if (i == 0 && !lng) ctr[2] = 0;
+    }
+    if (nv == 0 && threadIdx.x == 0) ctr[2] = 0;
+    if (threadIdx.x < 2) ctr[threadIdx.x] = NW;
+    if (threadIdx.x < LPRS) st4(rows + (size_t)P * SL + threadIdx.x * 4, make_float4(0.f, 0.f, 0.f, 0.f));
+    {
+        const bool chok = l * 4 < vd;
+        const int chc = chok ? l * 4 : 0;
+#pragma unroll
+        for (int u = 0; u < PF; u++) pf[u] = ld4(src + (int64_t)prow[u] * src_rs + chc);
+#pragma unroll
+        for (int u = 0; u < PF; u++)
+            if (chok && g + u * G < cnt) st4(rows + (g + u * G) * SL + l * 4, pf[u]);
+    }
+    const int r16 = lane & 15;
+    const unsigned zoff = (unsigned)P * SL * 4;
+    const int elast = E - 1;
+    // an entry and the features of its pixel (weight-0 padding entries point at the row of zeros; any pixel's features do)
+    auto fetch = [&](int pos, int s1, uint2 &e, float (&f)[NF > 0 ? NF : 1]) {
+        e = ent[min(max(pos, 0), elast)];
+        if (pos >= s1) e = make_uint2(zoff, 0u);
+        const int64_t px = pixl[min((int)(e.x / (SL * 4)), kclamp)];
+#pragma unroll
+        for (int j = 0; j < NF; j++) f[j] = fref[px * fref_rs + (int64_t)j * fref_cs];
+    };
+    for (int c0 = 0; c0 < vd; c0 += SL) {
+        const int ch = c0 + l * 4;
+        const bool chok = ch < vd;
+        __syncthreads();                   // rows of this slab are in LDS
+        const int slab = c0 / SL;
+        if (threadIdx.x == 0) ctr[(slab + 1) & 1] = NW;
+        const int chn = ch + SL;
+        const bool more = c0 + SL < vd;
+        const bool chnok = more && chn < vd;
+        const int chnc = chnok ? chn : 0;
+        if (more) {
+#pragma unroll
+            for (int u = 0; u < PF; u++) pf[u] = ld4(src + (int64_t)pixl[min(g + u * G, kclamp)] * src_rs + chnc);
+        }
+        int *slab_ctr = ctr + (slab & 1);
+        const int nlong = ctr[2];
+        const int nitems = nlong + (nv - nlong + Q - 1) / Q;
+        for (int gi = wave; gi < nitems;) {
+            const bool coop = gi < nlong;
+            const int i = coop ? gi : nlong + (gi - nlong) * Q + q;
+            int2 m = make_int2(0, 0);
+            if (i < nv) m = meta[i];
+            int nxt = 0;
+            if (lane == 0) nxt = atomicAdd(slab_ctr, 1);
+            const int s1 = (int)((unsigned)m.x >> 16);
+            int s = m.x & 0xFFFF;
+            float4 acc[NS];
+#pragma unroll
+            for (int t = 0; t < NS; t++) acc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+            const int len = s1 - s;
+            int lmax = __builtin_amdgcn_readlane(len, 0);
+            lmax = max(lmax, __builtin_amdgcn_readlane(len, 32));
+            lmax = max(max(lmax, __builtin_amdgcn_readlane(len, 16)), __builtin_amdgcn_readlane(len, 48));
+            const int step = coop ? 16 * Q : 16;
+            if (coop) s += 16 * q;
+            uint2 e;
+            float f[NF > 0 ? NF : 1];
+            fetch(s + r16, s1, e, f);
+            for (int b = 0; b < lmax; b += step) {
+                uint2 en;
+                float fn[NF > 0 ? NF : 1];
+                fetch(s + b + step + r16, s1, en, fn);       // next sixteen, under this batch's work
+                sum4w<0, NS>(acc, e, f, rbase);
+                sum4w<4, NS>(acc, e, f, rbase);
+                if (b + 8 < lmax) {
+                    sum4w<8, NS>(acc, e, f, rbase);
+                    sum4w<12, NS>(acc, e, f, rbase);
+                }
+                e = en;
+#pragma unroll
+                for (int j = 0; j < NF; j++) f[j] = fn[j];
+            }
+            if (coop) {
+#pragma unroll
+                for (int t = 0; t < NS; t++) {
+                    float4 a = acc[t];
+                    a = make_float4(a.x + __shfl_xor(a.x, LPRS), a.y + __shfl_xor(a.y, LPRS), a.z + __shfl_xor(a.z, LPRS),
+                                    a.w + __shfl_xor(a.w, LPRS));
+                    a = make_float4(a.x + __shfl_xor(a.x, 2 * LPRS), a.y + __shfl_xor(a.y, 2 * LPRS), a.z + __shfl_xor(a.z, 2 * LPRS),
+                                    a.w + __shfl_xor(a.w, 2 * LPRS));
+                    acc[t] = a;
+                }
+            }
+            if (i < nv && chok && !(coop && q != 0)) {
+                float *dst = m.y < 0 ? vert + (int64_t)(m.y & 0x7FFFFFFF) * out_rs : partial + (int64_t)m.y * out_rs;
+#pragma unroll
+                for (int t = 0; t < NS; t++) st4(dst + (int64_t)t * vd + ch, acc[t]);
+            }
+            gi = __builtin_amdgcn_readfirstlane(nxt);
+        }
+        __syncthreads();                   // everyone is done reading this slab
+        if (more) {
+#pragma unroll
+            for (int u = 0; u < PF; u++)
+                if (chnok && g + u * G < cnt) st4(rows + (g + u * G) * SL + l * 4, pf[u]);
+        }
+    }
+}
+
 // vertices with != 1 contributing chunk: sum their partial rows in ascending chunk order
 // (0 chunks = ghost vertex of a neighbouring row band: zeros).  One lane group per vertex, independent waves.
 // Vertices with more than `long_list` rows are left to k_splat_reduce_long.
@@ -1076,6 +1270,20 @@ __global__ __launch_bounds__(256) void k_fill_vs_rows(phl_contrib_t *__restrict_
     if (e < S) vs[e].w = __int_as_float(slot_pidx[vs[e].pixel]);
 }
 
+// sort key of a long vertex: lists in descending length
+__global__ __launch_bounds__(256) void k_long_keys(const int *__restrict__ vlong, int n, const int *__restrict__ vs_ptr, int kmax,
+                                                   int *__restrict__ key)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) key[i] = kmax - min(vs_ptr[vlong[i] + 1] - vs_ptr[vlong[i]], kmax);
+}
+
+__global__ __launch_bounds__(256) void k_gather_i32(const int *__restrict__ src, const int *__restrict__ perm, int n, int *__restrict__ dst)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[perm[i]];
+}
+
 __global__ __launch_bounds__(256) void k_flag_long(const int *__restrict__ vs_ptr, int M, int long_list, int *__restrict__ flag)
 {
     const int v = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1142,7 +1350,6 @@ int lds_budget()
 // bytes of index data staged next to the rows (entries, pixel ids, local pointers)
 inline int64_t lds_extra(int P, int dp1, int nv_max) { return (int64_t)P * dp1 * 8 + (int64_t)P * 4 + ((int64_t)nv_max + 2) * 8 + 16 + 256; }
 // k_slice_tiled keeps less: entries, pixel ids, one vertex id per local vertex
-inline int64_t lds_extra_slice(int P, int dp1, int nv_max) { return (int64_t)P * dp1 * 8 + (int64_t)P * 4 + ((int64_t)nv_max + 4) * 4; }
 
 // Launch configuration of a chunk kernel: lanes (of 4 floats) per slab row and LDS bytes per workgroup.
 // Candidates in order of preference: every slab width, widest first, at two workgroups per CU (80 KiB); only then
@@ -1157,14 +1364,13 @@ struct tile_cfg {
 inline int64_t lds_big() { return lds_budget() > 160 * 1024 ? lds_budget() : 160 * 1024; }
 
 // k-th candidate for `vd` channels (k = 0 is the preferred one); returns false past the last
-inline bool cfg_candidate(int vd, bool for_slice, int k, int *lprs, int64_t *budget)
+inline bool cfg_candidate(int vd, int k, int *lprs, int64_t *budget)
 {
     const int need = (vd + 3) / 4;
     int w = 4;
     while (w < 64 && w < need) w <<= 1;
-    static const int max_w[2] = {getenv("PHL_MAX_LPRS_SPLAT") ? atoi(getenv("PHL_MAX_LPRS_SPLAT")) : 64,
-                                 getenv("PHL_MAX_LPRS_SLICE") ? atoi(getenv("PHL_MAX_LPRS_SLICE")) : 64};   // experiments
-    while (w > 4 && w > max_w[for_slice ? 1 : 0]) w >>= 1;
+    static const int max_w = getenv("PHL_MAX_LPRS_SPLAT") ? atoi(getenv("PHL_MAX_LPRS_SPLAT")) : 64;   // experiments
+    while (w > 4 && w > max_w) w >>= 1;
     int nw = 0;
     for (int x = w; x >= 4; x >>= 1) nw++;
     if (k >= 2 * nw) return false;
@@ -1174,17 +1380,16 @@ inline bool cfg_candidate(int vd, bool for_slice, int k, int *lprs, int64_t *bud
 }
 
 inline int64_t splat_lds(int P, int dp1, int lprs, int nv) { return (int64_t)(P + 1) * lprs * 16 + lds_extra(P, dp1, nv); }
-inline int64_t slice_lds(int P, int dp1, int lprs, int nv) { return (int64_t)nv * lprs * 16 + lds_extra_slice(P, dp1, nv); }
 
 // first candidate that holds a chunk of `nv` local vertices, sized for exactly that many
-inline tile_cfg pick_cfg(const phl_lattice *lat, int vd, bool for_slice, int nv)
+inline tile_cfg pick_cfg(const phl_lattice *lat, int vd, int nv)
 {
     tile_cfg c;
     int lprs;
     int64_t budget;
     const int P = lat->P, dp1 = lat->d + 1;
-    for (int k = 0; cfg_candidate(vd, for_slice, k, &lprs, &budget); k++) {
-        const int64_t need = for_slice ? slice_lds(P, dp1, lprs, nv) : splat_lds(P, dp1, lprs, nv);
+    for (int k = 0; cfg_candidate(vd, k, &lprs, &budget); k++) {
+        const int64_t need = splat_lds(P, dp1, lprs, nv);
         if (need > budget) continue;
         c.lprs = lprs;
         c.cap = nv;
@@ -1216,10 +1421,10 @@ constexpr int MIN_CLASS = 64;
 // chunks with more than nv local vertices
 inline int chunks_above(const phl_lattice *lat, int nv) { return nv >= lat->nv_max ? 0 : lat->nchunks - lat->nv_cum[nv < 0 ? 0 : nv]; }
 
-inline tile_plan plan_tiles(const phl_lattice *lat, int vd, bool for_slice)
+inline tile_plan plan_tiles(const phl_lattice *lat, int vd)
 {
     tile_plan p;
-    const tile_cfg all = pick_cfg(lat, vd, for_slice, lat->nv_max);
+    const tile_cfg all = pick_cfg(lat, vd, lat->nv_max);
     if (all.lprs < 0) return p;
     static const bool classes = !(getenv("PHL_CLASSES") && atoi(getenv("PHL_CLASSES")) == 0);
     const int P = lat->P, dp1 = lat->d + 1;
@@ -1227,20 +1432,27 @@ inline tile_plan plan_tiles(const phl_lattice *lat, int vd, bool for_slice)
     if (classes && lat->nv_cum && lat->chunk_by_nv) {
         int lprs;
         int64_t budget;
-        for (int k = 0; covered < lat->nv_max && cfg_candidate(vd, for_slice, k, &lprs, &budget); k++) {
-            const int64_t base = for_slice ? slice_lds(P, dp1, lprs, 0) : splat_lds(P, dp1, lprs, 0);
+        for (int k = 0; covered < lat->nv_max && cfg_candidate(vd, k, &lprs, &budget); k++) {
+            const int64_t base = splat_lds(P, dp1, lprs, 0);
             if (base > budget) continue;
-            const int64_t per_v = for_slice ? (int64_t)lprs * 16 + 4 : 8;
+            const int64_t per_v = 8;
             int cap = (int)((budget - base) / per_v);
             if (cap > lat->nv_max) cap = lat->nv_max;
             if (cap <= covered) continue;
             const int count = chunks_above(lat, covered) - chunks_above(lat, cap);
             if (cap < lat->nv_max && count < MIN_CLASS) continue;
             if (count == 0) { covered = cap; continue; }
+            // a class of at most one chunk per CU is all tail: occupancy buys nothing, half the slabs halve its time
+            if (count <= 256) {
+                int wmax = 4;
+                while (wmax < 64 && wmax < (vd + 3) / 4) wmax <<= 1;
+                for (int x = wmax; x > lprs; x >>= 1)
+                    if (splat_lds(P, dp1, x, cap) <= lds_big()) { lprs = x; break; }
+            }
             tile_class &c = p.cls[p.n++];
             c.cfg.lprs = lprs;
             c.cfg.cap = cap;
-            c.cfg.lds = (size_t)(for_slice ? slice_lds(P, dp1, lprs, cap) : splat_lds(P, dp1, lprs, cap));
+            c.cfg.lds = (size_t)splat_lds(P, dp1, lprs, cap);
             c.lo = covered;
             c.hi = cap;
             c.begin = chunks_above(lat, cap);
@@ -1267,7 +1479,7 @@ inline tile_plan plan_tiles(const phl_lattice *lat, int vd, bool for_slice)
     static const bool dbg = getenv("PHL_DEBUG") != nullptr;
     if (dbg)
         for (int i = 0; i < p.n; i++)
-            fprintf(stderr, "[phl] %s vd=%d class %d/%d: %d < nv <= %d, %d chunks, %d lanes, %zu B LDS%s\n", for_slice ? "slice" : "splat",
+            fprintf(stderr, "[phl] splat vd=%d class %d/%d: %d < nv <= %d, %d chunks, %d lanes, %zu B LDS%s\n",
                     vd, i, p.n, p.cls[i].lo, p.cls[i].hi, p.cls[i].count, p.cls[i].cfg.lprs, p.cls[i].cfg.lds,
                     p.cls[i].full_grid ? " (whole grid)" : "");
     return p;
@@ -1453,6 +1665,24 @@ int phl_tiles_link_vertices(phl_lattice *lat, hipStream_t st)
     PHL_HIP(hipStreamSynchronize(st));
     lat->S_multi = s_multi;
     lat->n_long = n_long;
+    if (n_long > 64) {
+        // longest lists first: k_splat_reduce_long runs one workgroup per vertex, and a 600-row list that starts
+        // last is the launch's tail
+        int *lkey, *lperm, *lsorted;
+        PHL_HIP(tmp.get(&lkey, (size_t)n_long));
+        PHL_HIP(tmp.get(&lperm, (size_t)n_long));
+        PHL_HIP(tmp.get(&lsorted, (size_t)n_long));
+        const unsigned gl = (unsigned)((n_long + 255) / 256);
+        const int kmax = lat->nchunks + 1;
+        hipLaunchKernelGGL(k_long_keys, dim3(gl), dim3(256), 0, st, lat->vlong, n_long, lat->vs_ptr, kmax, lkey);
+        PHL_HIP(hipGetLastError());
+        rc = stable_sort_perm(lkey, n_long, (int64_t)kmax + 1, lperm, tmp, st);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_gather_i32, dim3(gl), dim3(256), 0, st, lat->vlong, lperm, n_long, lsorted);
+        PHL_HIP(hipGetLastError());
+        PHL_HIP(hipMemcpyAsync(lat->vlong, lsorted, sizeof(int) * (size_t)n_long, hipMemcpyDeviceToDevice, st));
+        PHL_HIP(hipStreamSynchronize(st));
+    }
     return PHL_OK;
 }
 
@@ -1666,7 +1896,7 @@ int phl_tiles_lprs(const phl_lattice *lat, int vd, int for_slice)
 {
     if (lat->nchunks == 0 || vd % 4 != 0) return -1;
     if (for_slice) return 1 << plan_slice(lat, vd).lsh_max;      // any chunk: the workgroup picks its own slab width
-    return pick_cfg(lat, vd, false, lat->nv_max).lprs;
+    return pick_cfg(lat, vd, lat->nv_max).lprs;
 }
 
 // which chunks hold a slot of any of the listed vertex rows
@@ -1716,7 +1946,7 @@ int phl_launch_splat_tiled(phl_lattice *lat, const float *src, int64_t src_rs, i
     // subset: run only the listed chunks, then complete only the listed vertex rows (either list may be empty)
     const int M = subset ? (int)nvl : (int)lat->M;
     if (lat->M == 0 || vd == 0) return PHL_OK;
-    const tile_plan plan = plan_tiles(lat, vd, false);
+    const tile_plan plan = plan_tiles(lat, vd);
     if (plan.n == 0) {
         phl_set_error("tiled splat: chunk does not fit LDS");
         return PHL_ERR_UNSUPPORTED;
@@ -1743,6 +1973,22 @@ int phl_launch_splat_tiled(phl_lattice *lat, const float *src, int64_t src_rs, i
             PHL_HIP(phl_dev_malloc((void **)&tl, tl_n * 8));
             PHL_HIP(hipMemsetAsync(tl, 0, tl_n * 8, st));
             tlc = tl;
+        }
+        const char *env1 = getenv("PHL_WIDE_ONE_PHASE");            // read per call: the parity test toggles it
+        const bool one_phase = !(env1 && atoi(env1) == 0);
+        if (wide && one_phase && c.cfg.lprs == 16 && wide->nsets >= 2 && wide->nsets <= 8 && lat->P <= 256) {
+            // every LDS row read feeds all nsets accumulators (k_splat_wide)
+#define PHL_SW(NS_)                                                                                                           \
+    case NS_:                                                                                                                 \
+        if ((rc = allow_lds(k_splat_wide<NS_>, c.cfg.lds)) != PHL_OK) break;                                                  \
+        k_splat_wide<NS_><<<dim3(cgrid), dim3(TPB_S), c.cfg.lds, st>>>(                                                       \
+            src, src_rs, vd, (int)lat->n, lat->P, c.cfg.cap, lat->pix_order, lat->chunk_vptr, lat->slot_vert, lat->slot_pidx, \
+            lat->seg_rng, lat->seg, vert, partial, cnt, xcd_chunk, list, c.lo, c.hi, long_seg(), wide->fref, wide->rs,        \
+            wide->cs);                                                                                                        \
+        break;
+            switch (wide->nsets) { PHL_SW(2) PHL_SW(3) PHL_SW(4) PHL_SW(5) PHL_SW(6) PHL_SW(7) PHL_SW(8) }
+#undef PHL_SW
+            continue;
         }
         dispatch_lprs(c.cfg.lprs, [&](auto L) {
             constexpr int LPRS = decltype(L)::value;

@@ -124,3 +124,49 @@ def test_full_size_timing_c2():
     assert float((got_ref - want_ref).abs().max()) <= 2e-4 * float(want_ref.abs().max())
     assert float((got_src - want_src).abs().max()) <= 1e-5 * float(want_src.abs().max())
     assert ms < 60.0
+
+
+def test_batched_backward_takes_the_fused_path_item_by_item(monkeypatch):
+    """BatchedLatticeFilter.backward (gaussian_matrix.py:396-421): [bs, n, L] / [bs, n, d] views of NCHW tensors."""
+    import crf.gaussian_matrix as gm
+
+    rng = np.random.default_rng(8)
+    bs, h, w, d, L = 2, 40, 48, 5, 8
+    n = h * w
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
+    guide = np.stack([np.stack([xx / 4, yy / 4] + [np.sin(xx / (5 + k + b)) + rng.random((h, w), dtype=np.float32) * 0.1 for k in range(d - 2)])
+                      for b in range(bs)]).astype(np.float32)               # [bs, d, h, w]
+    srcs_nchw = torch.from_numpy(rng.random((bs, L, h, w), dtype=np.float32)).cuda()
+    gout = torch.from_numpy(rng.standard_normal((bs, n, L)).astype(np.float32)).cuda()
+
+    def grads():
+        refs = torch.from_numpy(guide).cuda().reshape(bs, d, n).permute(0, 2, 1).requires_grad_(True)
+        srcs = srcs_nchw.reshape(bs, L, n).permute(0, 2, 1).detach().requires_grad_(True)
+        gm.BatchedLatticeFilter.apply(srcs, refs).backward(gout)
+        return srcs.grad, refs.grad
+
+    gs_f, gr_f = grads()
+    monkeypatch.setattr(gm, "_fused_grad", lambda *a: None)
+    gs_c, gr_c = grads()
+    assert float((gs_f - gs_c).abs().max()) <= 1e-5 * float(gs_c.abs().max())
+    assert float((gr_f - gr_c).abs().max()) <= 2e-4 * float(gr_c.abs().max())
+
+
+def test_one_phase_wide_splat_equals_the_multi_phase_form_bitwise(monkeypatch):
+    """k_splat_wide (every LDS row read feeds all d+1 accumulators) against k_splat_tiled's nsets > 1 mode (the sum
+    phase repeated per set): same products, same summation order -> the same gradients bit for bit."""
+    import phl
+
+    rng = np.random.default_rng(21)
+    side, d, L = 112, 5, 128
+    f = _features("image", side * side, d, rng)
+    n = f.shape[0]
+    ref = torch.from_numpy(f).cuda()
+    src = torch.from_numpy(rng.random((n, L), dtype=np.float32)).cuda()
+    g = torch.from_numpy(rng.standard_normal((n, L)).astype(np.float32)).cuda()
+    lat = phl.Lattice(ref)
+    monkeypatch.setenv("PHL_WIDE_ONE_PHASE", "1")
+    a_src, a_ref = lat.filter_grad(src, g, ref)
+    monkeypatch.setenv("PHL_WIDE_ONE_PHASE", "0")
+    b_src, b_ref = lat.filter_grad(src, g, ref)
+    assert torch.equal(a_src, b_src) and torch.equal(a_ref, b_ref)

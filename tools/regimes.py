@@ -31,6 +31,7 @@ REGIMES = [
     ("tsu_.1_.1", dict(tsukuba=(0.1, 0.1))),
     ("tsu_.08_.03", dict(tsukuba=(0.08, 0.03))),
     ("tsu_.125_.01", dict(tsukuba=(0.125, 0.01))),
+    ("xyd", dict(sigma_xy=8.0, xyd=1.0)),        # d = 3: (x, y, disparity), the north star's other feature set
     ("iid", dict(sigma_xy=8.0, iid=True)),
 ]
 
@@ -61,6 +62,7 @@ def main():
             if name not in args.regimes.split(","):
                 continue
             feat, desc = bench.features_for(H, W, **opt)
+            d = feat.shape[-1]
             ref = torch.from_numpy(feat.reshape(-1, d)).to(device)
             torch.cuda.synchronize()
             t0 = time.time()
