@@ -152,3 +152,41 @@ def test_long_lists_and_long_segments_are_exercised(phl):
     assert e_fast <= 2e-6 and e_exact <= 2e-5, (e_fast, e_exact)   # tree-like partial sums beat the reference's running sum
     again = lat.to_first_touch(lat.splat(s)).cpu().numpy()
     assert np.array_equal(v_fast.view(np.uint32), again.view(np.uint32))
+
+
+def test_randomised_mixtures_of_chunk_kinds(phl):
+    """Random images made of flat, smooth and noisy patches, random d, channel counts and position scales: every
+    combination of (chunk class, slab width incl. the direct form, cooperative / plain segments, short / long
+    partial-row lists) must give the oracle's result -- exact mode bit for bit, default mode to fp32 rounding."""
+    from oracle import phl_oracle as po
+
+    rng = np.random.default_rng(20261005)
+    for trial in range(10):
+        d = int(rng.choice([2, 3, 5, 5, 8]))
+        vd = int(rng.choice([4, 20, 64, 100, 256]))
+        H, W = int(rng.choice([64, 96, 128])), int(rng.choice([96, 160, 224]))
+        sxy = float(rng.choice([2.0, 6.0, 25.0, 120.0]))
+        feat = np.empty((H, W, d), np.float32)
+        feat[..., 0] = (np.arange(W, dtype=np.float32) / sxy)[None, :]
+        feat[..., 1] = (np.arange(H, dtype=np.float32) / sxy)[:, None]
+        for k in range(2, d):
+            feat[..., k] = 1.0
+        # patches: 0 flat, 1 smooth ramp, 2 iid noise
+        for by in range(0, H, 32):
+            for bx in range(0, W, 32):
+                kind = int(rng.integers(0, 3))
+                blk = feat[by:by + 32, bx:bx + 32, 2:]
+                if kind == 1:
+                    blk[...] = (np.linspace(0, 3, blk.shape[1], dtype=np.float32)[None, :, None] + float(rng.random()))
+                elif kind == 2:
+                    blk[...] = rng.random(blk.shape, dtype=np.float32) * float(rng.choice([2.0, 10.0]))
+        ref = np.ascontiguousarray(feat.reshape(-1, d))
+        src = rng.standard_normal((H * W, vd)).astype(np.float32)
+        want = po.oracle_filter(src, ref)
+        lat = phl.Lattice(torch.from_numpy(ref).cuda())
+        s = torch.from_numpy(src).cuda()
+        exact = lat.filter(s, exact=True).cpu().numpy()
+        assert np.array_equal(exact.view(np.uint32), want.view(np.uint32)), (trial, d, vd, H, W, sxy)
+        got = lat.filter(s).cpu().numpy()
+        assert scaled_err(got, want) <= 1e-5, (trial, d, vd, H, W, sxy, lat.tile_stats(vd))
+        assert scaled_err(lat.filter(s, no_tiles=True).cpu().numpy(), want) <= 1e-5
