@@ -701,7 +701,7 @@ __device__ __forceinline__ void sum4w(float4 (&acc)[NS], const uint2 e, const fl
 }
 
 template <int NS>
-__global__ __launch_bounds__(TPB_S) void k_splat_wide(const float *__restrict__ src, int64_t src_rs, int vd, int n, int P,
+__global__ __launch_bounds__(TPB_S) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_splat_wide(const float *__restrict__ src, int64_t src_rs, int vd, int n, int P,
                                                     int nv_cap, const int *__restrict__ pix_order, const int *__restrict__ vptr,
                                                     const int *__restrict__ slot_vert, const int *__restrict__ slot_pidx,
                                                     const int2 *__restrict__ seg_rng, const phl_contrib_t *__restrict__ seg,
@@ -787,10 +787,6 @@ __global__ __launch_bounds__(TPB_S) void k_splat_wide(const float *__restrict__ 
         const bool more = c0 + SL < vd;
         const bool chnok = more && chn < vd;
         const int chnc = chnok ? chn : 0;
-        if (more) {
-#pragma unroll
-            for (int u = 0; u < PF; u++) pf[u] = ld4(src + (int64_t)pixl[min(g + u * G, kclamp)] * src_rs + chnc);
-        }
         int *slab_ctr = ctr + (slab & 1);
         const int nlong = ctr[2];
         const int nitems = nlong + (nv - nlong + Q - 1) / Q;
@@ -849,6 +845,10 @@ __global__ __launch_bounds__(TPB_S) void k_splat_wide(const float *__restrict__ 
         }
         __syncthreads();                   // everyone is done reading this slab
         if (more) {
+            // next slab's rows: loaded here, not prefetched into registers under the sums (32 VGPRs that decide between one
+            // and two workgroups per CU; the other workgroup's sums cover this round trip)
+#pragma unroll
+            for (int u = 0; u < PF; u++) pf[u] = ld4(src + (int64_t)pixl[min(g + u * G, kclamp)] * src_rs + chnc);
 #pragma unroll
             for (int u = 0; u < PF; u++)
                 if (chnok && g + u * G < cnt) st4(rows + (g + u * G) * SL + l * 4, pf[u]);
