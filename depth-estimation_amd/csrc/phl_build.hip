@@ -143,7 +143,7 @@ __device__ __forceinline__ uint32_t mix_end(uint32_t h)
 // launch, and the index read back from the atomic is always a candidate whose key is fully
 // written, so no in-kernel hand-off of plain data is needed.
 __global__ __launch_bounds__(256) void k_insert(const int16_t *__restrict__ ckeys, int d, int n, int *table,
-                                                uint32_t mask, int *__restrict__ slot_of)
+                                                uint32_t mask, int *__restrict__ slot_of, int max_probe, int *__restrict__ err)
 {
     // A wavefront takes 64 CONSECUTIVE pixels of ONE remainder: neighbouring pixels mostly lie
     // in the same simplex, so the same key repeats along the lanes and only the first lane of
@@ -176,7 +176,13 @@ __global__ __launch_bounds__(256) void k_insert(const int16_t *__restrict__ ckey
     int slot = 0;
     if (active && lane == head_lane) {
         h &= mask;
-        for (;;) {
+        // max_probe: the table is sized for the vertex counts images have, not for the worst case (every candidate its
+        // own vertex); a probe sequence this long means it is too small -- flag it, the host repeats with the full size
+        for (int steps = 0;; steps++) {
+            if (steps >= max_probe) {
+                atomicOr(err, 2);
+                break;
+            }
             int prev = atomicCAS(&table[h], PHL_EMPTY, e);
             if (prev == PHL_EMPTY) break;
             const int16_t *other = ckeys + (int64_t)prev * d;
@@ -454,9 +460,17 @@ int phl_build_device(phl_lattice *lat, const float *ref, int64_t rs, int64_t cs,
         sf.v[i] *= (d + 1) * sqrtf(2.0 / 3);
     }
 
-    uint64_t cap = 1024;
-    while (cap < (uint64_t)N * 2) cap <<= 1;
-    const uint32_t mask = (uint32_t)(cap - 1);
+    // Candidate table.  Worst case every one of the N candidates is a vertex (iid features): 2N slots.  Images have
+    // M <= n/2 or so, and a table sized for N = n(d+1) candidates (268 MB at C3) makes every probe, flag and
+    // vertex-id lookup a miss in L2 and the Infinity Cache: start with 2n slots (holds M <= n at load 1/2; 33 MB at C3)
+    // and repeat the insertion with the full size only if a probe sequence runs long (k_insert's max_probe).
+    uint64_t cap_full = 1024;
+    while (cap_full < (uint64_t)N * 2) cap_full <<= 1;
+    uint64_t cap = 1 << 16;
+    while (cap < (uint64_t)n * 2) cap <<= 1;
+    static const bool small_table = !(getenv("PHL_SMALL_TABLE") && atoi(getenv("PHL_SMALL_TABLE")) == 0);
+    if (cap > cap_full || !small_table) cap = cap_full;
+    uint32_t mask = (uint32_t)(cap - 1);
 
     temp_pool tmp;
     int16_t *ckeys;
@@ -479,21 +493,30 @@ int phl_build_device(phl_lattice *lat, const float *ref, int64_t rs, int64_t cs,
         default: phl_set_error("d=%d unsupported (1..%d)", d, PHL_MAX_D); return PHL_ERR_UNSUPPORTED;
     }
     const unsigned gN = (unsigned)((N + 255) / 256);
-    hipLaunchKernelGGL(k_fill_i32, dim3(2048), dim3(256), 0, st, table, (int64_t)cap, PHL_EMPTY);
-    {
-        const int64_t waves = ((n + 63) / 64) * (d + 1);
-        hipLaunchKernelGGL(k_insert, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, ckeys, d, (int)n, table, mask, slot_of);
-    }
-    hipLaunchKernelGGL(k_flag, dim3(gN), dim3(256), 0, st, table, slot_of, N, flag);
-    PHL_HIP(hipGetLastError());
-    int rc = exclusive_scan(flag, rankv, N, tile_sums, st);
-    if (rc) return rc;
-
     int host[2] = {0, 0};
-    PHL_HIP(hipMemcpyAsync(&host[0], rankv + N, sizeof(int), hipMemcpyDeviceToHost, st));
-    PHL_HIP(hipMemcpyAsync(&host[1], err, sizeof(int), hipMemcpyDeviceToHost, st));
-    PHL_HIP(hipStreamSynchronize(st));
-    if (host[1]) {
+    int rc = PHL_OK;
+    for (;;) {
+        hipLaunchKernelGGL(k_fill_i32, dim3(2048), dim3(256), 0, st, table, (int64_t)cap, PHL_EMPTY);
+        {
+            const int64_t waves = ((n + 63) / 64) * (d + 1);
+            hipLaunchKernelGGL(k_insert, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, ckeys, d, (int)n, table, mask, slot_of,
+                               cap == cap_full ? 0x7FFFFFFF : 1024, err);
+        }
+        hipLaunchKernelGGL(k_flag, dim3(gN), dim3(256), 0, st, table, slot_of, N, flag);
+        PHL_HIP(hipGetLastError());
+        rc = exclusive_scan(flag, rankv, N, tile_sums, st);
+        if (rc) return rc;
+        PHL_HIP(hipMemcpyAsync(&host[0], rankv + N, sizeof(int), hipMemcpyDeviceToHost, st));
+        PHL_HIP(hipMemcpyAsync(&host[1], err, sizeof(int), hipMemcpyDeviceToHost, st));
+        PHL_HIP(hipStreamSynchronize(st));
+        if ((host[1] & 1) || !(host[1] & 2) || cap == cap_full) break;
+        // the small table overflowed (little sharing: most candidates are vertices of their own): full size
+        cap = cap_full;
+        mask = (uint32_t)(cap - 1);
+        PHL_HIP(tmp.get(&table, cap));
+        PHL_HIP(hipMemsetAsync(err, 0, sizeof(int), st));
+    }
+    if (host[1] & 1) {
         phl_set_error("lattice coordinate outside int16 (reference keys are `short`, permutohedral.h:39,398); "
                       "rescale the features");
         return PHL_ERR_KEY_RANGE;
