@@ -464,6 +464,7 @@ def main():
     ap.add_argument("--mean-field", dest="mean_field", action="store_true", default=True,
                     help="also time one full mean-field iteration and its fused compatibility kernel (extra key; default on)")
     ap.add_argument("--no-mean-field", dest="mean_field", action="store_false")
+    ap.add_argument("--no-small-image", action="store_true", help="skip the Tsukuba-sized extra (key c1_small_image)")
     ap.add_argument("--dry-launch", action="store_true", help="launcher / rendezvous plumbing only, gloo on CPU, no filter")
     ap.add_argument("--cpu-worker", default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
@@ -681,7 +682,7 @@ def main():
                            lat if not rowtiled else None, feat, H, W, L, d, src, out_rt if rowtiled else out)
 
     small = None
-    if rank == 0 and world == 1 and not rowtiled and args.mean_field and default_features:
+    if rank == 0 and world == 1 and not rowtiled and args.mean_field and default_features and not args.no_small_image:
         small = small_image(torch, phl, device)
 
     cpu = None

@@ -18,9 +18,9 @@ for c in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
 done
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${tag}_exact -- python3 $R/bench.py $Q --exact > $R/gpurun_out/bench_final_exact.log 2>&1 || exit 1
 # mean-field iteration: filter - Q, then the fused compatibility product + softmax (k_compat_softmax)
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${tag}_mf -- python3 $R/bench.py --no-cpu-baseline --no-regimes --steps 5 > $R/gpurun_out/bench_final_mf.log 2>&1 || exit 1
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${tag}_mf -- python3 $R/bench.py --no-cpu-baseline --no-regimes --no-small-image --steps 5 > $R/gpurun_out/bench_final_mf.log 2>&1 || exit 1
 for c in "FETCH_SIZE" "WRITE_SIZE"; do
-  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $R/gpurun_out/pmc_${tag}_mf_$c -- python3 $R/bench.py --no-cpu-baseline --no-regimes --steps 2 --warmup 1 > $R/gpurun_out/pmc_${tag}_mf_$c.log 2>&1 || exit 1
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $R/gpurun_out/pmc_${tag}_mf_$c -- python3 $R/bench.py --no-cpu-baseline --no-regimes --no-small-image --steps 2 --warmup 1 > $R/gpurun_out/pmc_${tag}_mf_$c.log 2>&1 || exit 1
 done
 cd $R && python tools/regimes.py --workloads c3,c2 --out gpurun_out/regimes_$tag.json > gpurun_out/regimes_$tag.log 2>&1 || exit 1
 grep "^{" $R/gpurun_out/bench_final.log | cut -c1-200
