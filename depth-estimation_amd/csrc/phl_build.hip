@@ -151,6 +151,8 @@ __global__ __launch_bounds__(256) void k_insert(const int16_t *__restrict__ ckey
     // the atomicMin wants anyway).
     const int dp1 = d + 1;
     const int lane = threadIdx.x & 63;
+    // the small table has been found too small: the host will repeat the insertion, nothing of this launch is kept
+    if (max_probe != 0x7FFFFFFF && (*reinterpret_cast<volatile int *>(err) & 2)) return;
     const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int r = (int)(wave % dp1);
     const int64_t p = (wave / dp1) * 64 + lane;
@@ -463,7 +465,8 @@ int phl_build_device(phl_lattice *lat, const float *ref, int64_t rs, int64_t cs,
     // Candidate table.  Worst case every one of the N candidates is a vertex (iid features): 2N slots.  Images have
     // M <= n/2 or so, and a table sized for N = n(d+1) candidates (268 MB at C3) makes every probe, flag and
     // vertex-id lookup a miss in L2 and the Infinity Cache: start with 2n slots (holds M <= n at load 1/2; 33 MB at C3)
-    // and repeat the insertion with the full size only if a probe sequence runs long (k_insert's max_probe).
+    // and repeat the insertion with the full size only if a probe sequence runs long (k_insert's max_probe: 128 steps,
+    // which at load 1/2 does not happen; waves that start after the flag is up leave at once, so finding out is cheap).
     uint64_t cap_full = 1024;
     while (cap_full < (uint64_t)N * 2) cap_full <<= 1;
     uint64_t cap = 1 << 16;
@@ -500,7 +503,7 @@ int phl_build_device(phl_lattice *lat, const float *ref, int64_t rs, int64_t cs,
         {
             const int64_t waves = ((n + 63) / 64) * (d + 1);
             hipLaunchKernelGGL(k_insert, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, ckeys, d, (int)n, table, mask, slot_of,
-                               cap == cap_full ? 0x7FFFFFFF : 1024, err);
+                               cap == cap_full ? 0x7FFFFFFF : 128, err);
         }
         hipLaunchKernelGGL(k_flag, dim3(gN), dim3(256), 0, st, table, slot_of, N, flag);
         PHL_HIP(hipGetLastError());
