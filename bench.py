@@ -796,9 +796,12 @@ def regime_sweep(torch, phl, H, W, L, d, src, out, base_ms, base_M):
     base_gbs = alg(base_M) / (base_ms * 1e-3) / 1e9
     rows = {"default": {"M_over_n": round(base_M / n, 4), "ms": round(base_ms, 4), "algorithmic_GBps": round(base_gbs, 1), "rel": 1.0}}
     for name, opt in (("sigma_xy=3", dict(sigma_xy=3.0)), ("sigma_xy=30", dict(sigma_xy=30.0)),
-                      ("tsukuba 0.08/0.03", dict(tsukuba=(0.08, 0.03))), ("tsukuba 0.1/0.1", dict(tsukuba=(0.1, 0.1)))):
+                      ("tsukuba 0.08/0.03", dict(tsukuba=(0.08, 0.03))), ("tsukuba 0.1/0.1", dict(tsukuba=(0.1, 0.1))),
+                      ("(x, y, disparity) d=3", dict(xyd=1.0))):
         feat, _ = features_for(H, W, **opt)
-        lat = phl.Lattice(torch.from_numpy(feat.reshape(-1, d)).to(src.device))
+        dd = feat.shape[-1]
+        alg = lambda M, dd=dd: sum(algorithmic_bytes(n, M, L, dd).values())
+        lat = phl.Lattice(torch.from_numpy(feat.reshape(-1, dd)).to(src.device))
         for _ in range(4):
             lat.filter(src, out=out)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
