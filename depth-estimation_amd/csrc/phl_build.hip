@@ -212,21 +212,14 @@ __global__ __launch_bounds__(256) void k_flag(const int *__restrict__ table, con
 
 __global__ __launch_bounds__(256) void k_assign(const int *__restrict__ flag, const int *__restrict__ rankv,
                                                 const int *__restrict__ slot_of, const int16_t *__restrict__ ckeys,
-                                                int d, int N, int *table, int16_t *__restrict__ vkeys)
+                                                int d, int N, int *table, int16_t *__restrict__ vkeys, int *__restrict__ vfirst)
 {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= N || !flag[e]) return;
     const int vid = rankv[e];
     for (int i = 0; i < d; i++) vkeys[(int64_t)vid * d + i] = ckeys[(int64_t)e * d + i];
     table[slot_of[e]] = -(vid + 1);
-}
-
-// first-touch candidate of every vertex (its pixel tells the renumbering where the vertex lives)
-__global__ __launch_bounds__(256) void k_first_candidate(const int *__restrict__ flag, const int *__restrict__ rankv, int N,
-                                                         int *__restrict__ vfirst)
-{
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e < N && flag[e]) vfirst[rankv[e]] = e;
+    vfirst[vid] = e;     // first-touch candidate of the vertex (its pixel tells the renumbering where the vertex lives)
 }
 
 __global__ __launch_bounds__(256) void k_set_vid(const int *__restrict__ table, const int *__restrict__ slot_of, int N,
@@ -528,20 +521,20 @@ int phl_build_device(phl_lattice *lat, const float *ref, int64_t rs, int64_t cs,
     lat->M = M;
 
     PHL_HIP(phl_dev_malloc((void **)&lat->vkeys, sizeof(int16_t) * (size_t)M * d));
-    hipLaunchKernelGGL(k_assign, dim3(gN), dim3(256), 0, st, flag, rankv, slot_of, ckeys, d, N, table, lat->vkeys);
-    hipLaunchKernelGGL(k_set_vid, dim3(gN), dim3(256), 0, st, table, slot_of, N, lat->replay);
-    PHL_HIP(hipGetLastError());
     if (lat->vfirst) PHL_HIP(phl_dev_free(lat->vfirst));
     lat->vfirst = nullptr;
     lat->vfirst_valid_for_M = 0;
+    PHL_HIP(phl_dev_malloc((void **)&lat->vfirst, sizeof(int) * ((size_t)M + 1)));
+    hipLaunchKernelGGL(k_assign, dim3(gN), dim3(256), 0, st, flag, rankv, slot_of, ckeys, d, N, table, lat->vkeys, lat->vfirst);
+    hipLaunchKernelGGL(k_set_vid, dim3(gN), dim3(256), 0, st, table, slot_of, N, lat->replay);
+    PHL_HIP(hipGetLastError());
     if (lat->build_flags & PHL_BUILD_REFERENCE_TABLE) {
         rc = phl_apply_reference_table(lat, flag, rankv, st);
         if (rc) return rc;
     }
-    if (lat->M == M && M > 0 && lat->vfirst_valid_for_M != lat->M) {     // (duplicate vertices inserted: the replay wrote its own list)
-        PHL_HIP(phl_dev_malloc((void **)&lat->vfirst, sizeof(int) * (size_t)M));
-        hipLaunchKernelGGL(k_first_candidate, dim3(gN), dim3(256), 0, st, flag, rankv, N, lat->vfirst);
-        PHL_HIP(hipGetLastError());
+    if (lat->M != M && lat->vfirst_valid_for_M != lat->M) {     // duplicate vertices inserted without a list of their own
+        PHL_HIP(phl_dev_free(lat->vfirst));
+        lat->vfirst = nullptr;
     }
     lat->M_local = lat->M;
     // (locality renumbering, key -> vertex table and blur neighbours follow in phl_tiles_build)

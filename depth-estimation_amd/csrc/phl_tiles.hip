@@ -41,27 +41,38 @@ namespace {
 __global__ __launch_bounds__(256) void k_minmax(const float *__restrict__ ref, int64_t rs, int64_t cs, int64_t n, int d,
                                                 float *__restrict__ out /* [grid][d][2] */)
 {
+    // one pass over the pixels, all d features of a pixel by the same thread (pixel-major features: every cache line is
+    // touched once, not d times)
     __shared__ float smin[4][PHL_MAX_D], smax[4][PHL_MAX_D];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    for (int i = 0; i < d; i++) {
-        float lo = INFINITY, hi = -INFINITY;
-        for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (int64_t)gridDim.x * blockDim.x) {
-            const float v = ref[p * rs + i * cs];
-            lo = fminf(lo, v);
-            hi = fmaxf(hi, v);
-        }
-        for (int o = 32; o > 0; o >>= 1) {
-            lo = fminf(lo, __shfl_xor(lo, o));
-            hi = fmaxf(hi, __shfl_xor(hi, o));
-        }
-        if (lane == 0) { smin[w][i] = lo; smax[w][i] = hi; }
+    float lo[PHL_MAX_D], hi[PHL_MAX_D];
+#pragma unroll
+    for (int i = 0; i < PHL_MAX_D; i++) { lo[i] = INFINITY; hi[i] = -INFINITY; }
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (int64_t)gridDim.x * blockDim.x) {
+#pragma unroll
+        for (int i = 0; i < PHL_MAX_D; i++)
+            if (i < d) {
+                const float v = ref[p * rs + i * cs];
+                lo[i] = fminf(lo[i], v);
+                hi[i] = fmaxf(hi[i], v);
+            }
     }
+#pragma unroll
+    for (int i = 0; i < PHL_MAX_D; i++)
+        if (i < d) {
+            float a = lo[i], b = hi[i];
+            for (int o = 32; o > 0; o >>= 1) {
+                a = fminf(a, __shfl_xor(a, o));
+                b = fmaxf(b, __shfl_xor(b, o));
+            }
+            if (lane == 0) { smin[w][i] = a; smax[w][i] = b; }
+        }
     __syncthreads();
     if ((int)threadIdx.x < d) {
-        float lo = smin[0][threadIdx.x], hi = smax[0][threadIdx.x];
-        for (int k = 1; k < 4; k++) { lo = fminf(lo, smin[k][threadIdx.x]); hi = fmaxf(hi, smax[k][threadIdx.x]); }
-        out[((int64_t)blockIdx.x * d + threadIdx.x) * 2 + 0] = lo;
-        out[((int64_t)blockIdx.x * d + threadIdx.x) * 2 + 1] = hi;
+        float a = smin[0][threadIdx.x], b = smax[0][threadIdx.x];
+        for (int k = 1; k < 4; k++) { a = fminf(a, smin[k][threadIdx.x]); b = fmaxf(b, smax[k][threadIdx.x]); }
+        out[((int64_t)blockIdx.x * d + threadIdx.x) * 2 + 0] = a;
+        out[((int64_t)blockIdx.x * d + threadIdx.x) * 2 + 1] = b;
     }
 }
 
@@ -1719,7 +1730,7 @@ int phl_tiles_build(phl_lattice *lat, const float *ref, int64_t rs, int64_t cs, 
     {   // temporaries of the chunk build go back to the scratch cache before the vertex lists are linked
     temp_pool tmp;
     // 1. feature ranges -> the two widest dimensions -> uniform grid with ~P pixels per cell
-    constexpr int MMB = 256;
+    constexpr int MMB = 1024;
     float *mm_dev;
     PHL_HIP(tmp.get(&mm_dev, (size_t)MMB * d * 2));
     hipLaunchKernelGGL(k_minmax, dim3(MMB), dim3(256), 0, st, ref, rs, cs, (int64_t)n, d, mm_dev);
