@@ -2027,8 +2027,10 @@ int phl_launch_splat_tiled(phl_lattice *lat, const float *src, int64_t src_rs, i
     int64_t blocks = (waves + 3) / 4;
     if (blocks > 2048) blocks = 2048;
     // long slot lists: the lattice's own list of such vertices, or (subset) the caller's rows, short ones exiting
+    // (a subset call walks its own rows only if the lattice has long vertices at all: one workgroup per listed row is
+    //  tens of thousands of empty workgroups on the row-band path otherwise)
     const int *llist = subset ? vlist : lat->vlong;
-    const int64_t nl = subset ? nvl : lat->n_long;
+    const int64_t nl = lat->n_long == 0 ? 0 : (subset ? nvl : lat->n_long);
     const int long_list = llist ? LONG_LIST : 0x7FFFFFFF;
 #define PHL_RED(LPR_)                                                                                                  \
     k_splat_reduce<LPR_><<<dim3((unsigned)blocks), dim3(256), 0, st>>>(partial, lat->vs_ptr, lat->vs, lat->slot_pidx, \
