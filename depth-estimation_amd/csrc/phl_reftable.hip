@@ -83,7 +83,61 @@ struct ref_sim {
         return h;
     }
     bool need_grow() const { return (uint64_t)F >= cap / 2 - 1; }   // :62
-    void prefetch(uint64_t hfull) const { __builtin_prefetch(&slots[(size_t)(hfull & (cap - 1))], 1, 1); }
+    void prefetch(uint64_t hfull) const
+    {
+        if (!frozen) __builtin_prefetch(&slots[(size_t)(hfull & (cap - 1))], 1, 1);
+    }
+
+    // ---- the LAST doubling is not carried out --------------------------------------------------------------------
+    // Re-filing the table at the last doubling of a build moves more entries than all earlier doublings together, and
+    // nothing after it needs the table itself: no further doubling will read its slot order.  What lookups in the
+    // re-filed table return follows from the OLD table (kept as it is, `slots` with `cap_old` slots):
+    //  * entries are re-filed in ascending old slot index, all entries of one key from the same new home, so of a
+    //    key's old entries the one with the smallest old slot index comes first on every probe path from that home
+    //    and is what lookups find; a key's old entries lie on the probe paths from its home under cap_old (filed or
+    //    re-filed properly) and under cap_old / 2 (the one entry a stale probe left there at the previous doubling);
+    //  * a probe that starts from a STALE slot (the key in flight at this doubling, hash bit log2(cap_old) set) walks
+    //    cap_old slots before it could meet the key's entries; fewer than cap_old / 2 slots are occupied, so it ends
+    //    on an empty slot: not found, and a vertex it creates there is unreachable for every later lookup;
+    //  * vertices created afterwards from their proper home are found by later lookups of their key, behind the
+    //    key's old entries.
+    bool frozen = false;
+    uint64_t cap_old = 0;
+    std::vector<std::pair<int32_t, bool>> post;      // vertices created after the freeze by tracked-key paths: (id, reachable)
+    void freeze()
+    {
+        frozen = true;
+        cap_old = cap;
+        cap *= 2;
+    }
+    int32_t new_vertex(const int16_t *key, bool reachable, bool record)
+    {
+        keys.insert(keys.end(), key, key + d);
+        if (record) post.push_back({(int32_t)F, reachable});
+        return (int32_t)(F++);
+    }
+    // what a lookup from the key's proper home returns in the re-filed table, or -1
+    int32_t frozen_find(const int16_t *key, uint64_t hfull) const
+    {
+        int64_t best_slot = -1;
+        int32_t best = -1;
+        const uint64_t homes[2] = {hfull & (cap_old - 1), hfull & (cap_old / 2 - 1)};
+        for (int t = 0; t < (homes[0] == homes[1] ? 1 : 2); t++) {
+            uint64_t h = homes[t];
+            for (uint64_t steps = 0; steps < cap_old && slots[h]; steps++, h = (h + 1) & (cap_old - 1)) {
+                const slot_t sl = slots[h];
+                if ((uint32_t)sl == (uint32_t)hfull && memcmp(keys.data() + (size_t)vertex(sl) * d, key, sizeof(int16_t) * d) == 0 &&
+                    (best_slot < 0 || (int64_t)h < best_slot)) {
+                    best_slot = (int64_t)h;
+                    best = vertex(sl);
+                }
+            }
+        }
+        if (best >= 0) return best;
+        for (const auto &pv : post)
+            if (pv.second && memcmp(keys.data() + (size_t)pv.first * d, key, sizeof(int16_t) * d) == 0) return pv.first;
+        return -1;
+    }
     void grow()                                                      // :122-155, entries re-filed in old slot order
     {
         const slot_t *old = slots;
@@ -117,6 +171,13 @@ struct ref_sim {
     int32_t probe(const int16_t *key, uint64_t hfull, uint64_t h, bool create, bool *created)
     {
         *created = false;
+        if (frozen) {
+            const bool proper = h == (hfull & (cap - 1));
+            const int32_t found = proper ? frozen_find(key, hfull) : -1;
+            if (found >= 0 || !create) return found;
+            *created = true;
+            return new_vertex(key, proper, true);
+        }
         const uint64_t mask = cap - 1;
         for (;;) {
             const slot_t s = slots[h];
@@ -137,8 +198,13 @@ struct ref_sim {
         const uint64_t hf = hash(key);
         return probe(key, hf, hf & (cap - 1), create, created);
     }
+    // the creation loop's lookup: a clean first touch, i.e. a key the table has never seen
     int32_t lookup_hashed(const int16_t *key, uint64_t hf, bool create, bool *created)
     {
+        if (frozen && create) {
+            *created = true;
+            return new_vertex(key, true, false);
+        }
         return probe(key, hf, hf & (cap - 1), create, created);
     }
 };
@@ -200,7 +266,12 @@ int phl_reference_table_sim(const int16_t *keys_clean, const int32_t *efirst, in
             const uint64_t hf = hclean[(size_t)K];
             const uint64_t h_old = hf % sim.cap;                // :102, computed before grow()
             const auto tg0 = std::chrono::steady_clock::now();
-            sim.grow();
+            // the last doubling of this build?  (the next one comes at cap - 1 vertices; duplicates add a few to M)
+            const char *env_sf = getenv("PHL_REPLAY_SKIP_FINAL");       // per call: the CPU test runs both forms
+            const bool skip_final = !(env_sf && atoi(env_sf) == 0);
+            if (sim.frozen) return PHL_ERR_INVALID;                      // cannot happen: M + 128 < cap - 1 was checked
+            if (skip_final && (uint64_t)M + 128 < sim.cap - 1) sim.freeze();
+            else sim.grow();
             t_grow += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tg0).count();
             const uint64_t h_new = hf % sim.cap;
             bool created = false;

@@ -101,3 +101,30 @@ def test_threshold_hit_exactly_at_the_last_vertex():
         assert nb != -2 and nb == Of.neighbors()[0, 0, 0]
         return
     pytest.fail("no prefix with exactly 16383 vertices in 30 draws")
+
+
+def test_skipping_the_last_doubling_changes_nothing(monkeypatch):
+    """The replay does not carry out the LAST doubling of a build (csrc/phl_reftable.hip, `frozen`): what lookups in
+    the re-filed table return is derived from the old table.  Both forms -- every doubling simulated, and the last one
+    skipped -- must produce the same vertices, candidate resolutions, hidden list and blur neighbour, on vertex counts
+    well inside an epoch, just above a doubling and just below the next one (where the skip must not apply)."""
+    cases = 0
+    for seed in range(60):
+        rng = np.random.default_rng(5000 + seed)
+        d = int(rng.integers(2, 7))
+        # aim the vertex count at interesting places relative to the thresholds 16383, 32767, 65535
+        target = int(rng.choice([17000, 20000, 30000, 32600, 32900, 34000, 50000, 65400, 66000, 90000]))
+        n = max(2000, target // (d + 1) + int(rng.integers(0, 400)))
+        ref = (rng.random((n, d), dtype=np.float32) * np.float32(rng.choice([40.0, 80.0]))).astype(np.float32)   # ~every candidate its own vertex
+        Oc = po.Oracle(ref)
+        if Oc.M < 16383:
+            continue
+        keys_c = np.ascontiguousarray(Oc.keys())
+        cand = np.ascontiguousarray(Oc.replay()[0].ravel())
+        monkeypatch.setenv("PHL_REPLAY_SKIP_FINAL", "1")
+        a = _replay(keys_c, cand)
+        monkeypatch.setenv("PHL_REPLAY_SKIP_FINAL", "0")
+        b = _replay(keys_c, cand)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) and a[3] == b[3], (seed, Oc.M)
+        cases += 1
+    assert cases >= 40
