@@ -88,6 +88,14 @@ struct phl_lattice {
 struct phl_reftable_query {
     virtual int vid_at(int64_t candidate) = 0;                          // clean vertex id of a candidate
     virtual int64_t next_occurrence(int clean_vid, int64_t after) = 0;  // next candidate with that key, or -1
+    // A linear-probing table of `cap` slots holds the clean vertices [0, n_clean), one more entry for every key of
+    // extra_clean, and (counted in addition: a superset of the real occupancy) one entry filed from the home under
+    // cap / 2 for every key of stale_clean.  For every key of `check`: is there an empty slot between the key's home
+    // and the table's last slot, i.e. do the key's entries lie in index order along their probe path?  1 = yes for
+    // all (certain), 0 = not for all, or it cannot be told.  Depends on the occupancy only, not on the insertion order.
+    virtual int probe_paths_do_not_wrap(int64_t n_clean, const std::vector<int32_t> &extra_clean,
+                                        const std::vector<int32_t> &stale_clean, uint64_t cap,
+                                        const std::vector<int32_t> &check) = 0;
     virtual ~phl_reftable_query() {}
 };
 struct phl_reftable_result {
@@ -101,6 +109,9 @@ struct phl_reftable_result {
 };
 int phl_reference_table_sim(const int16_t *keys_clean, const int32_t *efirst, int64_t M, int d, int64_t N,
                             phl_reftable_query &q, phl_reftable_result &out);
+// the same result without simulating the table (phl_reftable.hip, "analytic replay"); 1 = not applicable here, use the sim
+int phl_reference_table_fast(const int16_t *keys_clean, const int32_t *efirst, int64_t M, int d, int64_t N,
+                             phl_reftable_query &q, phl_reftable_result &out);
 int phl_apply_reference_table(phl_lattice *lat, const int *flag, const int *rankv, hipStream_t st);
 
 // Buffers one filter call writes: the [M][vd] Jacobi ping-pong pair, the partial rows of the chunk splat and

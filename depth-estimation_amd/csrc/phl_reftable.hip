@@ -380,6 +380,238 @@ int phl_reference_table_sim(const int16_t *keys_clean, const int32_t *efirst, in
     return PHL_OK;
 }
 
+// ---- analytic replay -------------------------------------------------------------------------------------------------
+// The simulation above spends its time keeping a table nobody looks at: what the build needs from it is (1) WHEN the
+// doublings happen, (2) whether the key in flight at a doubling is probed from a stale slot, (3) for the handful of
+// keys that ever got a second vertex, which of their vertices a lookup finds in each epoch.  All three follow from
+// counting and from the ORDER of a key's entries, without slot positions, as long as no entry of any epoch's table
+// wraps past the table's last slot (then "smaller slot index" and "earlier on the probe path" are the same thing):
+//  * the vertex count after candidate t is (#clean first touches <= t) + (#extra creations <= t); the doubling of
+//    capacity c is triggered by the lookup after the creation that brings the count to c/2 - 1 (:62);
+//  * the key in flight is hashed with c before and 2c after (:101-103): a stale start iff bit log2(c) of its hash is
+//    set; from a stale start the probe meets none of the key's entries (they lie c slots further on, fewer than c/2
+//    slots are occupied) and appends a vertex there, unreachable for lookups until the next doubling;
+//  * grow() re-files in ascending slot order (:122-155).  Entries of one key are re-filed from one home, so they keep
+//    their order; the stale one of the previous doubling lies c/2 slots BELOW the key's home, hence is re-filed first
+//    and from then on is what lookups find; vertices created later in an epoch are filed behind the existing ones.
+// "No entry wraps" is an occupancy property, independent of the insertion order: q.no_wrap() evaluates it for the
+// table at the end of every epoch (the device does it with one histogram and one ordered reduction).  If it does not
+// hold, or the splat ends exactly at a threshold (the doubling inside blur()), 1 is returned and the caller simulates.
+int phl_reference_table_fast(const int16_t *keys_clean, const int32_t *efirst, int64_t M, int d, int64_t N,
+                             phl_reftable_query &q, phl_reftable_result &out)
+{
+    struct tracked {
+        int clean;
+        std::vector<int32_t> P;                          // reachable vertices in probe order
+        int32_t S = -1;                                  // vertex filed from a stale slot in the current epoch
+        int64_t pending_e = -1;
+        std::vector<std::pair<int32_t, int32_t>> seg;    // (from candidate, vertex)
+    };
+    std::vector<tracked> tk;
+    std::unordered_map<int, int> tindex;
+    struct extra_t { int64_t e; int clean; int32_t id; };
+    std::vector<extra_t> extras;                         // creations that are not clean first touches, ascending e
+    auto hash_of = [&](int clean) {
+        uint64_t h = 0;
+        const int16_t *k = keys_clean + (size_t)clean * d;
+        for (int i = 0; i < d; i++) { h += (uint64_t)(int64_t)k[i]; h *= 2531011; }
+        return h;
+    };
+    auto clean_before = [&](int64_t e) { return (int64_t)(std::lower_bound(efirst, efirst + M, (int32_t)std::min<int64_t>(e, 0x7FFFFFFF)) - efirst); };
+    // reference id of clean vertex v: v plus the extra creations before its first touch
+    auto ref_id = [&](int v) {
+        int64_t k = 0;
+        for (const extra_t &x : extras) k += x.e < efirst[v];
+        return (int32_t)(v + k);
+    };
+    auto track = [&](int clean, bool exists) -> int {
+        auto it = tindex.find(clean);
+        if (it != tindex.end()) return it->second;
+        tracked t;
+        t.clean = clean;
+        if (exists) {
+            const int32_t id = ref_id(clean);
+            t.seg.push_back({efirst[clean], id});
+            t.P.push_back(id);
+        }
+        tk.push_back(t);
+        tindex[clean] = (int)tk.size() - 1;
+        return (int)tk.size() - 1;
+    };
+    uint64_t cap = (uint64_t)1 << 15;
+    int64_t vi = 0;                                       // clean first touches consumed
+    int64_t F = 0;                                        // vertices so far
+    for (;;) {
+        // creations up to the next doubling: clean first touches in candidate order, pending creations in between
+        const int64_t T = (int64_t)(cap / 2 - 1);
+        int64_t t_last = -1;
+        bool reached = F >= T;
+        while (!reached) {
+            int pi = -1;
+            for (size_t i = 0; i < tk.size(); i++)
+                if (tk[i].pending_e >= 0 && (pi < 0 || tk[i].pending_e < tk[(size_t)pi].pending_e)) pi = (int)i;
+            const int64_t need = T - F;
+            const int64_t e_clean = vi + need - 1 < M ? (int64_t)efirst[vi + need - 1] : ((int64_t)1 << 62);
+            if (pi < 0 || e_clean < tk[(size_t)pi].pending_e) {
+                if (vi + need - 1 >= M) break;            // the splat ends before the next doubling
+                vi += need;
+                F += need;
+                t_last = e_clean;
+                reached = true;
+            } else {
+                const int64_t ep = tk[(size_t)pi].pending_e;
+                const int64_t k = clean_before(ep) - vi;  // clean first touches before the pending creation
+                vi += k;
+                F += k;
+                tracked &t = tk[(size_t)pi];
+                const int32_t r = (int32_t)F++;
+                extras.push_back({ep, t.clean, r});
+                t.P.assign(1, r);
+                t.seg.push_back({(int32_t)ep, r});
+                t.pending_e = -1;
+                if (F >= T) { t_last = ep; reached = true; }
+            }
+        }
+        if (!reached) break;
+        const int64_t eg = t_last + 1;
+        if (eg >= N) { if (getenv("PHL_DEBUG")) fprintf(stderr, "[phl] analytic replay: doubling inside blur\n"); return 1; }   // simulate
+        {
+            // the order of a key's entries is read off their probe path: that needs the path not to wrap past the
+            // table's last slot -- asked for every key that has more than one entry
+            std::vector<int32_t> ex, st, chk;
+            for (const extra_t &x : extras) ex.push_back(x.clean);
+            for (const tracked &t : tk) {
+                if (t.S >= 0) st.push_back(t.clean);      // filed from the home under cap / 2, not from its own
+                if (t.P.size() + (t.S >= 0 ? 1 : 0) >= 2) chk.push_back(t.clean);
+            }
+            if (!chk.empty() && q.probe_paths_do_not_wrap(vi, ex, st, cap, chk) != 1) {
+                if (getenv("PHL_DEBUG")) fprintf(stderr, "[phl] analytic replay: a tracked key's probe path wraps at capacity %llu\n", (unsigned long long)cap);
+                return 1;
+            }
+        }
+        const bool first_touch = vi < M && efirst[vi] == eg;
+        const int K = first_touch ? (int)vi : q.vid_at(eg);
+        if (K < 0 || K >= M) return PHL_ERR_INVALID;
+        const uint64_t hf = hash_of(K);
+        const bool stale = (hf & cap) != 0;
+        cap *= 2;
+        for (tracked &t : tk)                             // re-filing: the stale entry of the last epoch comes first now
+            if (t.S >= 0) {
+                t.P.insert(t.P.begin(), t.S);
+                t.S = -1;
+                t.pending_e = -1;                         // ... and is found by the key's next lookup: nothing to append
+            }
+        if (!stale) {
+            if (first_touch) {                            // an ordinary creation
+                vi++;
+                F++;
+            } else if (tindex.count(K)) {
+                tracked &t = tk[(size_t)tindex[K]];
+                int32_t r;
+                if (!t.P.empty()) r = t.P[0];
+                else {                                    // nothing reachable: this lookup appends a vertex
+                    r = (int32_t)F++;
+                    extras.push_back({eg, K, r});
+                    t.P.assign(1, r);
+                }
+                t.seg.push_back({(int32_t)eg, r});
+                if (t.pending_e == eg) t.pending_e = -1;
+            }
+        } else {
+            const int32_t r = (int32_t)F++;
+            const int ti = track(K, !first_touch);
+            tracked &t = tk[(size_t)ti];
+            if (first_touch) {
+                vi++;                                     // the clean vertex itself, filed from the stale slot
+                t.seg.push_back({(int32_t)eg, r});
+            } else {
+                extras.push_back({eg, K, r});
+                t.seg.push_back({(int32_t)eg, r});
+            }
+            t.S = r;
+            if (t.pending_e == eg) t.pending_e = -1;
+        }
+        for (tracked &t : tk) {
+            if (!t.P.empty()) {
+                t.seg.push_back({(int32_t)(eg + 1), t.P[0]});
+            } else if (t.pending_e <= eg) {
+                t.pending_e = q.next_occurrence(t.clean, eg);
+            }
+        }
+    }
+    // creations after the last doubling
+    for (;;) {
+        int pi = -1;
+        for (size_t i = 0; i < tk.size(); i++)
+            if (tk[i].pending_e >= 0 && (pi < 0 || tk[i].pending_e < tk[(size_t)pi].pending_e)) pi = (int)i;
+        if (pi < 0) break;
+        tracked &t = tk[(size_t)pi];
+        const int64_t ep = t.pending_e;
+        const int64_t k = clean_before(ep) - vi;
+        vi += k;
+        F += k;
+        const int32_t r = (int32_t)F++;
+        extras.push_back({ep, t.clean, r});
+        t.P.assign(1, r);
+        t.seg.push_back({(int32_t)ep, r});
+        t.pending_e = -1;
+    }
+    F += M - vi;
+    if ((uint64_t)F >= cap / 2 - 1) { if (getenv("PHL_DEBUG")) fprintf(stderr, "[phl] analytic replay: splat ends at a threshold\n"); return 1; }   // blur() would double the table: simulate
+
+    // ---- results in the simulation's format ----
+    out.M_ref = F;
+    out.blur_grow = false;
+    out.blur_first_nbr = -1;
+    std::sort(extras.begin(), extras.end(), [](const extra_t &a, const extra_t &b) { return a.e < b.e; });
+    out.keys.resize((size_t)F * d);
+    out.remap.resize((size_t)M);
+    {
+        size_t xi = 0;
+        int64_t id = 0;
+        for (int64_t v = 0; v < M; v++) {
+            while (xi < extras.size() && extras[xi].e < efirst[v]) {
+                if (extras[xi].id != id) return PHL_ERR_INVALID;
+                memcpy(out.keys.data() + (size_t)id * d, keys_clean + (size_t)extras[xi].clean * d, sizeof(int16_t) * d);
+                id++;
+                xi++;
+            }
+            out.remap[(size_t)v] = (int32_t)id;
+            memcpy(out.keys.data() + (size_t)id * d, keys_clean + (size_t)v * d, sizeof(int16_t) * d);
+            id++;
+        }
+        for (; xi < extras.size(); xi++, id++) {
+            if (extras[xi].id != id) return PHL_ERR_INVALID;
+            memcpy(out.keys.data() + (size_t)id * d, keys_clean + (size_t)extras[xi].clean * d, sizeof(int16_t) * d);
+        }
+        if (id != F) return PHL_ERR_INVALID;
+    }
+    out.dup_clean.clear();
+    out.dup_ptr.assign(1, 0);
+    out.seg_e.clear();
+    out.seg_id.clear();
+    out.hidden.clear();
+    for (size_t i = 0; i < tk.size(); i++) {
+        const tracked &t = tk[i];
+        const int32_t visible = t.P.empty() ? -1 : t.P[0];
+        std::vector<int32_t> ids;
+        for (auto &sg : t.seg) ids.push_back(sg.second);
+        std::sort(ids.begin(), ids.end());
+        ids.erase(std::unique(ids.begin(), ids.end()), ids.end());
+        for (int32_t id : ids)
+            if (id != visible) out.hidden.push_back(id);
+        out.remap[(size_t)t.clean] = -(int32_t)(i + 1);
+        out.dup_clean.push_back(t.clean);
+        for (auto &sg : t.seg) {
+            out.seg_e.push_back(sg.first);
+            out.seg_id.push_back(sg.second);
+        }
+        out.dup_ptr.push_back((int32_t)out.seg_e.size());
+    }
+    std::sort(out.hidden.begin(), out.hidden.end());
+    return PHL_OK;
+}
+
 namespace {
 
 // ---- device side ---------------------------------------------------------------------------------
@@ -434,6 +666,8 @@ __global__ void k_set_pairs(const int *__restrict__ idx, const int *__restrict__
 }
 
 struct device_query : phl_reftable_query {
+    int probe_paths_do_not_wrap(int64_t, const std::vector<int32_t> &, const std::vector<int32_t> &, uint64_t,
+                                const std::vector<int32_t> &) override { return 0; }
     const phl_replay_t *replay;
     int N;
     int *scratch;            // one device int
@@ -562,6 +796,37 @@ namespace {
 struct host_query : phl_reftable_query {
     const int32_t *cand;
     int64_t N;
+    const int16_t *keys = nullptr;
+    int d = 0;
+    uint64_t hash_of(int clean) const
+    {
+        uint64_t h = 0;
+        for (int i = 0; i < d; i++) { h += (uint64_t)(int64_t)keys[(size_t)clean * d + i]; h *= 2531011; }
+        return h;
+    }
+    int probe_paths_do_not_wrap(int64_t n_clean, const std::vector<int32_t> &extra_clean, const std::vector<int32_t> &stale_clean,
+                                uint64_t cap, const std::vector<int32_t> &check) override
+    {
+        std::vector<int32_t> hist((size_t)cap, 0);
+        for (int64_t v = 0; v < n_clean; v++) hist[(size_t)(hash_of((int)v) & (cap - 1))]++;
+        for (int32_t v : extra_clean) hist[(size_t)(hash_of(v) & (cap - 1))]++;
+        for (int32_t v : stale_clean) hist[(size_t)(hash_of(v) & (cap / 2 - 1))]++;
+        // carry[x] = entries that arrive at slot x from the left still looking for a slot; two passes settle the wrap
+        int64_t carry = 0;
+        for (int pass = 0; pass < 2; pass++)
+            for (uint64_t x = 0; x < cap; x++) carry = std::max<int64_t>(0, carry + hist[(size_t)x] - 1);
+        std::vector<uint8_t> empty((size_t)cap);
+        for (uint64_t x = 0; x < cap; x++) {
+            empty[(size_t)x] = (carry + hist[(size_t)x]) == 0;
+            carry = std::max<int64_t>(0, carry + hist[(size_t)x] - 1);
+        }
+        for (int32_t v : check) {
+            bool ok = false;
+            for (uint64_t x = hash_of(v) & (cap - 1); x < cap && !ok; x++) ok = empty[(size_t)x];
+            if (!ok) return 0;
+        }
+        return 1;
+    }
     int vid_at(int64_t e) override { return cand[e]; }
     int64_t next_occurrence(int vid, int64_t after) override
     {
@@ -583,8 +848,20 @@ extern "C" int phl_debug_reference_table(const int16_t *keys_clean, const int32_
     host_query q;
     q.cand = cand_vid;
     q.N = N;
+    q.keys = keys_clean;
+    q.d = d;
     phl_reftable_result R;
-    const int rc = phl_reference_table_sim(keys_clean, efirst.data(), M, d, N, q, R);
+    // PHL_REPLAY_FAST: 1 = analytic replay where it applies (else the simulation), 2 = analytic only (error if it does
+    // not apply), unset / 0 = the simulation
+    const char *envf = getenv("PHL_REPLAY_FAST");
+    const int mode = envf ? atoi(envf) : 0;
+    int rc = 1;
+    if (mode >= 1) rc = phl_reference_table_fast(keys_clean, efirst.data(), M, d, N, q, R);
+    if (rc == 1) {
+        if (mode == 2) { phl_set_error("analytic replay not applicable"); return PHL_ERR_UNSUPPORTED; }
+        R = phl_reftable_result();
+        rc = phl_reference_table_sim(keys_clean, efirst.data(), M, d, N, q, R);
+    }
     if (rc) return rc;
     *M_ref_out = R.M_ref;
     if (R.M_ref > keys_ref_cap || (int)R.hidden.size() > hidden_cap) { phl_set_error("phl_debug_reference_table: output too small"); return PHL_ERR_INVALID; }

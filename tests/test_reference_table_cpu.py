@@ -51,16 +51,24 @@ def _check(ref):
     return Of.M - Oc.M, len(hidden)
 
 
+@pytest.fixture(params=["simulation", "analytic"])
+def replay_mode(request, monkeypatch):
+    """Both forms of the replay: the table simulation, and the analytic form (which falls back to the simulation
+    where it does not apply)."""
+    monkeypatch.setenv("PHL_REPLAY_FAST", "1" if request.param == "analytic" else "0")
+    return request.param
+
+
 @pytest.mark.parametrize("n,d,scale,seed", [(3000, 5, 3.0, 1), (20000, 5, 8.0, 21), (60000, 5, 6.0, 22), (200000, 3, 40.0, 23),
                                             (9000, 8, 2.0, 5), (30000, 2, 300.0, 6), (12000, 5, 9.0, 7), (50000, 4, 12.0, 8)])
-def test_replay_equals_faithful_oracle_random(n, d, scale, seed):
+def test_replay_equals_faithful_oracle_random(n, d, scale, seed, replay_mode):
     rng = np.random.default_rng(seed)
     ref = (rng.random((n, d), dtype=np.float32) * np.float32(scale)).astype(np.float32)
     extra, nh = _check(ref)
     print(f"n={n} d={d}: {extra} duplicate vertices, {nh} hidden")
 
 
-def test_replay_equals_faithful_oracle_many_seeds():
+def test_replay_equals_faithful_oracle_many_seeds(replay_mode):
     """Sweep seeds so that all the sub-cases occur: stale slot == proper slot (no duplicate), in-flight key new /
     already present, the duplicate found again only after the next doubling, several doublings."""
     seen = set()
@@ -75,7 +83,7 @@ def test_replay_equals_faithful_oracle_many_seeds():
 
 @pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "growth_*.npz"))),
                          ids=os.path.basename)
-def test_replay_on_stored_growth_cases(path):
+def test_replay_on_stored_growth_cases(path, replay_mode):
     from _golden_util import load_growth_case
 
     g = load_growth_case(path)
@@ -128,3 +136,39 @@ def test_skipping_the_last_doubling_changes_nothing(monkeypatch):
         assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) and a[3] == b[3], (seed, Oc.M)
         cases += 1
     assert cases >= 40
+
+
+def test_analytic_replay_equals_the_simulation(monkeypatch):
+    """phl_reference_table_fast derives doubling times, stale probes and the order of a key's entries by counting,
+    without a table (csrc/phl_reftable.hip); wherever it applies its result must be the simulation's: vertices,
+    candidate resolutions, hidden list.  120 random lattices around the thresholds 16383 / 32767 / 65535 / 131071."""
+    applied = fell_back = with_dups = 0
+    for seed in range(120):
+        rng = np.random.default_rng(9000 + seed)
+        d = int(rng.integers(2, 7))
+        target = int(rng.choice([16500, 17000, 20000, 30000, 32700, 32800, 34000, 50000, 65500, 65600, 70000, 100000, 131200, 150000]))
+        n = max(2000, target // (d + 1) + int(rng.integers(0, 300)))
+        scale = float(rng.choice([40.0, 80.0])) if seed % 2 else float(rng.choice([6.0, 9.0, 12.0]))
+        if seed % 2 == 0:
+            n = int(rng.integers(20000, 90000))          # vertices shared by many pixels: keys looked up again and again
+        ref = (rng.random((n, d), dtype=np.float32) * np.float32(scale)).astype(np.float32)
+        Oc = po.Oracle(ref)
+        if Oc.M < 16383:
+            continue
+        keys_c = np.ascontiguousarray(Oc.keys())
+        cand = np.ascontiguousarray(Oc.replay()[0].ravel())
+        monkeypatch.setenv("PHL_REPLAY_FAST", "0")
+        want = _replay(keys_c, cand)
+        monkeypatch.setenv("PHL_REPLAY_FAST", "2")
+        try:
+            got = _replay(keys_c, cand)
+        except AssertionError:
+            fell_back += 1                                # not applicable here (wrap, or a doubling inside blur)
+            continue
+        applied += 1
+        with_dups += int(len(want[0]) > Oc.M)
+        assert np.array_equal(got[0], want[0]), (seed, "keys")
+        assert np.array_equal(got[1], want[1]), (seed, "candidate resolution")
+        assert np.array_equal(got[2], want[2]) and got[3] == want[3], (seed, "hidden / blur neighbour")
+    print(f"analytic replay applied {applied}x (with duplicate vertices {with_dups}x), fell back {fell_back}x")
+    assert applied >= 60 and with_dups >= 10 and fell_back <= applied // 4
