@@ -32,6 +32,7 @@
 //     (from candidate index, vertex) segments.  At most two extra vertices per doubling.
 // The device then re-labels replay[].vid (one pass), uploads the new key list, and builds its own lookup
 // table from the vertices the reference's final table can reach.
+#include <limits.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -567,24 +568,26 @@ int phl_reference_table_fast(const int16_t *keys_clean, const int32_t *efirst, i
     out.keys.resize((size_t)F * d);
     out.remap.resize((size_t)M);
     {
-        size_t xi = 0;
-        int64_t id = 0;
-        for (int64_t v = 0; v < M; v++) {
-            while (xi < extras.size() && extras[xi].e < efirst[v]) {
+        // reference order = clean first touches and extra creations merged by candidate index: whole runs of clean
+        // vertices between two extras are copied (keys) and numbered (remap) in one go
+        int64_t v = 0, id = 0;
+        for (size_t xi = 0; xi <= extras.size(); xi++) {
+            const int64_t vend = xi < extras.size() ? clean_before(extras[xi].e) : M;     // clean vertices before this extra
+            if (vend > v) {
+                memcpy(out.keys.data() + (size_t)id * d, keys_clean + (size_t)v * d, sizeof(int16_t) * (size_t)(vend - v) * d);
+                int32_t *rm = out.remap.data() + v;
+                const int32_t off = (int32_t)(id - v);
+                for (int64_t k = 0; k < vend - v; k++) rm[k] = (int32_t)(v + k) + off;
+                id += vend - v;
+                v = vend;
+            }
+            if (xi < extras.size()) {
                 if (extras[xi].id != id) return PHL_ERR_INVALID;
                 memcpy(out.keys.data() + (size_t)id * d, keys_clean + (size_t)extras[xi].clean * d, sizeof(int16_t) * d);
                 id++;
-                xi++;
             }
-            out.remap[(size_t)v] = (int32_t)id;
-            memcpy(out.keys.data() + (size_t)id * d, keys_clean + (size_t)v * d, sizeof(int16_t) * d);
-            id++;
         }
-        for (; xi < extras.size(); xi++, id++) {
-            if (extras[xi].id != id) return PHL_ERR_INVALID;
-            memcpy(out.keys.data() + (size_t)id * d, keys_clean + (size_t)extras[xi].clean * d, sizeof(int16_t) * d);
-        }
-        if (id != F) return PHL_ERR_INVALID;
+        if (id != F || v != M) return PHL_ERR_INVALID;
     }
     out.dup_clean.clear();
     out.dup_ptr.assign(1, 0);
@@ -665,9 +668,112 @@ __global__ void k_set_pairs(const int *__restrict__ idx, const int *__restrict__
     if (i < k) out[idx[i]] = val[i];
 }
 
+// ---- occupancy of the reference's table, for the analytic replay's one assumption ---------------------------------
+// hist[x] = entries whose home is slot x (hash as permutohedral.h:109-116, size_t arithmetic; capacity a power of two)
+__global__ __launch_bounds__(256) void k_home_hist(const int16_t *__restrict__ vkeys, int64_t count, int d, uint32_t mask,
+                                                   int *__restrict__ hist)
+{
+    const int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= count) return;
+    unsigned long long h = 0;
+    for (int i = 0; i < d; i++) {
+        h += (unsigned long long)(long long)vkeys[v * d + i];
+        h *= 2531011ull;
+    }
+    atomicAdd(&hist[(uint32_t)h & mask], 1);
+}
+
+__global__ void k_add_homes(const int *__restrict__ homes, int k, int *__restrict__ hist)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < k) atomicAdd(&hist[homes[i]], 1);
+}
+
+// One workgroup per key to check: is there an empty slot in [home, cap)?  Linear probing fills slots from the left:
+// carry(x+1) = max(0, carry(x) + hist[x] - 1) entries arrive at slot x+1 still looking for a slot, and slot x is empty
+// iff carry(x) + hist[x] == 0.  The carry at slot 0 is what wraps around; two sweeps settle it.  Every thread folds its
+// contiguous piece of the table into a map c -> max(m, c + s); thread 0 chains the 1024 maps (twice for the wrap, once
+// more for every piece's incoming carry); then every thread walks its piece with its real carry.
+__global__ __launch_bounds__(1024) void k_cluster_check(const int *__restrict__ hist, uint32_t cap, const int *__restrict__ homes,
+                                                        int *__restrict__ result)
+{
+    __shared__ long long sm[1024], ss[1024], cin[1024];
+    __shared__ int found;
+    const uint32_t piece = cap / 1024u;                    // cap >= 2^15
+    const uint32_t x0 = threadIdx.x * piece;
+    long long m = LLONG_MIN / 4, s = 0;                    // identity map
+    for (uint32_t x = x0; x < x0 + piece; x++) {
+        const long long a = (long long)hist[x] - 1;
+        m = max(0ll, m + a);
+        s += a;
+    }
+    sm[threadIdx.x] = m;
+    ss[threadIdx.x] = s;
+    if (threadIdx.x == 0) found = 0;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        long long c = 0;
+        for (int pass = 0; pass < 2; pass++)
+            for (int t = 0; t < 1024; t++) c = max(sm[t], c + ss[t]);
+        for (int t = 0; t < 1024; t++) {                   // c = the carry that wraps into slot 0
+            cin[t] = c;
+            c = max(sm[t], c + ss[t]);
+        }
+    }
+    __syncthreads();
+    const uint32_t h = (uint32_t)homes[blockIdx.x];
+    long long c = cin[threadIdx.x];
+    bool hit = false;
+    for (uint32_t x = x0; x < x0 + piece; x++) {
+        const long long hx = hist[x];
+        hit |= (x >= h) && (c + hx == 0);
+        c = max(0ll, c + hx - 1);
+    }
+    if (hit) found = 1;
+    __syncthreads();
+    if (threadIdx.x == 0) result[blockIdx.x] = found;
+}
+
 struct device_query : phl_reftable_query {
-    int probe_paths_do_not_wrap(int64_t, const std::vector<int32_t> &, const std::vector<int32_t> &, uint64_t,
-                                const std::vector<int32_t> &) override { return 0; }
+    const int16_t *vkeys_dev = nullptr;      // clean keys, clean order (device)
+    const int16_t *keys_host = nullptr;      // the same on the host
+    int d = 0;
+    int *hist = nullptr;                     // [max capacity] device
+    int *small = nullptr;                    // [256] device ints: homes in, results out
+    uint64_t hash_of(int clean) const
+    {
+        uint64_t h = 0;
+        for (int i = 0; i < d; i++) { h += (uint64_t)(int64_t)keys_host[(size_t)clean * d + i]; h *= 2531011; }
+        return h;
+    }
+    int probe_paths_do_not_wrap(int64_t n_clean, const std::vector<int32_t> &extra_clean, const std::vector<int32_t> &stale_clean,
+                                uint64_t cap, const std::vector<int32_t> &check) override
+    {
+        if (!hist || !small || cap > ((uint64_t)1 << 27) || check.size() > 64 || extra_clean.size() + stale_clean.size() > 128) return 0;
+        std::vector<int> homes;
+        for (int32_t v : extra_clean) homes.push_back((int)(hash_of(v) & (cap - 1)));
+        for (int32_t v : stale_clean) homes.push_back((int)(hash_of(v) & (cap / 2 - 1)));
+        const int nadd = (int)homes.size();
+        for (int32_t v : check) homes.push_back((int)(hash_of(v) & (cap - 1)));
+        hipError_t r = hipMemsetAsync(hist, 0, sizeof(int) * (size_t)cap, st);
+        if (r == hipSuccess) r = hipMemcpyAsync(small, homes.data(), sizeof(int) * homes.size(), hipMemcpyHostToDevice, st);
+        if (r == hipSuccess) {
+            if (n_clean > 0)
+                hipLaunchKernelGGL(k_home_hist, dim3((unsigned)((n_clean + 255) / 256)), dim3(256), 0, st, vkeys_dev, n_clean, d,
+                                   (uint32_t)(cap - 1), hist);
+            if (nadd > 0) hipLaunchKernelGGL(k_add_homes, dim3(1), dim3(256), 0, st, small, nadd, hist);
+            hipLaunchKernelGGL(k_cluster_check, dim3((unsigned)check.size()), dim3(1024), 0, st, hist, (uint32_t)cap, small + nadd,
+                               small + 192);
+            r = hipGetLastError();
+        }
+        std::vector<int> res(check.size(), 0);
+        if (r == hipSuccess) r = hipMemcpyAsync(res.data(), small + 192, sizeof(int) * res.size(), hipMemcpyDeviceToHost, st);
+        if (r == hipSuccess) r = hipStreamSynchronize(st);      // (also keeps `homes` alive until the copy has run)
+        if (r != hipSuccess) { err = r; return 0; }
+        for (int x : res)
+            if (!x) return 0;
+        return 1;
+    }
     const phl_replay_t *replay;
     int N;
     int *scratch;            // one device int
@@ -728,8 +834,24 @@ int phl_apply_reference_table(phl_lattice *lat, const int *flag, const int *rank
     q.N = N;
     q.scratch = scratch;
     q.st = st;
+    q.vkeys_dev = lat->vkeys;
+    q.keys_host = keys.data();
+    q.d = d;
     phl_reftable_result R;
-    int rc = phl_reference_table_sim(keys.data(), efirst.data(), M, d, N, q, R);
+    // the analytic replay first (counting, no table: phl_reference_table_fast); the simulation where it does not apply
+    int rc = 1;
+    const char *envf = getenv("PHL_REPLAY_FAST");
+    if (!(envf && atoi(envf) == 0)) {
+        uint64_t cap_max = (uint64_t)1 << 15;
+        while (cap_max / 2 - 1 <= (uint64_t)M + 128) cap_max <<= 1;
+        if (tmp.get(&q.hist, (size_t)cap_max) == hipSuccess && tmp.get(&q.small, 256) == hipSuccess)
+            rc = phl_reference_table_fast(keys.data(), efirst.data(), M, d, N, q, R);
+        else
+            (void)hipGetLastError();
+        if (dbg) fprintf(stderr, "[phl] reference table: analytic replay %s after %.2f ms\n", rc == 0 ? "done" : (rc == 1 ? "not applicable" : "failed"), since());
+        if (rc == 1) R = phl_reftable_result();
+    }
+    if (rc == 1) rc = phl_reference_table_sim(keys.data(), efirst.data(), M, d, N, q, R);
     if (q.err != hipSuccess) return phl_hip_fail(q.err, "reference-table device query", __FILE__, __LINE__);
     if (rc) { phl_set_error("reference-table replay failed (inconsistent first-touch list)"); return rc; }
     if ((int)R.hidden.size() > PHL_MAX_HIDDEN) { phl_set_error("reference-table replay: too many duplicate vertices"); return PHL_ERR_UNSUPPORTED; }
