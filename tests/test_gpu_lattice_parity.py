@@ -792,3 +792,20 @@ def test_threads_with_different_channel_counts_share_one_lattice(phl):
     for t in threads:
         t.join()
     assert not errors, errors[:5]
+
+
+def test_analytic_and_simulated_table_replay_build_the_same_lattice(phl, monkeypatch):
+    """PHL_BUILD_REFERENCE_TABLE through the analytic replay (default; its occupancy check runs on the device) and
+    through the table simulation (PHL_REPLAY_FAST=0, also the fallback): identical vertices, per-pixel lookups,
+    blur neighbours -- on shared-vertex features with several doublings and on iid features."""
+    rng = np.random.default_rng(77)
+    for n, d, scale in ((120000, 5, 9.0), (60000, 3, 30.0), (40000, 5, 60.0)):
+        ref = torch.from_numpy((rng.random((n, d), dtype=np.float32) * np.float32(scale)).astype(np.float32)).cuda()
+        got = {}
+        for mode in ("1", "0"):
+            monkeypatch.setenv("PHL_REPLAY_FAST", mode)
+            L = phl.Lattice(ref, reference_table=True)
+            got[mode] = (L.M, L.keys(), L.replay()[0], L.neighbors())
+        assert got["1"][0] == got["0"][0] >= 16383
+        for a, b in zip(got["1"][1:], got["0"][1:]):
+            assert np.array_equal(a, b)
