@@ -439,6 +439,9 @@ int phl_reference_table_fast(const int16_t *keys_clean, const int32_t *efirst, i
         tindex[clean] = (int)tk.size() - 1;
         return (int)tk.size() - 1;
     };
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto ms_since = [&](std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
+    double t_check = 0, t_query = 0;
     uint64_t cap = (uint64_t)1 << 15;
     int64_t vi = 0;                                       // clean first touches consumed
     int64_t F = 0;                                        // vertices so far
@@ -485,13 +488,18 @@ int phl_reference_table_fast(const int16_t *keys_clean, const int32_t *efirst, i
                 if (t.S >= 0) st.push_back(t.clean);      // filed from the home under cap / 2, not from its own
                 if (t.P.size() + (t.S >= 0 ? 1 : 0) >= 2) chk.push_back(t.clean);
             }
-            if (!chk.empty() && q.probe_paths_do_not_wrap(vi, ex, st, cap, chk) != 1) {
+            const auto tc0 = std::chrono::steady_clock::now();
+            const int nowrap = chk.empty() ? 1 : q.probe_paths_do_not_wrap(vi, ex, st, cap, chk);
+            t_check += ms_since(tc0);
+            if (nowrap != 1) {
                 if (getenv("PHL_DEBUG")) fprintf(stderr, "[phl] analytic replay: a tracked key's probe path wraps at capacity %llu\n", (unsigned long long)cap);
                 return 1;
             }
         }
         const bool first_touch = vi < M && efirst[vi] == eg;
+        const auto tq0 = std::chrono::steady_clock::now();
         const int K = first_touch ? (int)vi : q.vid_at(eg);
+        t_query += ms_since(tq0);
         if (K < 0 || K >= M) return PHL_ERR_INVALID;
         const uint64_t hf = hash_of(K);
         const bool stale = (hf & cap) != 0;
@@ -536,7 +544,9 @@ int phl_reference_table_fast(const int16_t *keys_clean, const int32_t *efirst, i
             if (!t.P.empty()) {
                 t.seg.push_back({(int32_t)(eg + 1), t.P[0]});
             } else if (t.pending_e <= eg) {
+                const auto tq1 = std::chrono::steady_clock::now();
                 t.pending_e = q.next_occurrence(t.clean, eg);
+                t_query += ms_since(tq1);
             }
         }
     }
@@ -612,6 +622,9 @@ int phl_reference_table_fast(const int16_t *keys_clean, const int32_t *efirst, i
         out.dup_ptr.push_back((int32_t)out.seg_e.size());
     }
     std::sort(out.hidden.begin(), out.hidden.end());
+    if (getenv("PHL_DEBUG"))
+        fprintf(stderr, "[phl] analytic replay: M %lld -> %lld, %zu tracked keys, %zu extra creations; %.2f ms (occupancy checks %.2f, candidate queries %.2f)\n",
+                (long long)M, (long long)F, tk.size(), extras.size(), ms_since(t_begin), t_check, t_query);
     return PHL_OK;
 }
 
@@ -689,49 +702,91 @@ __global__ void k_add_homes(const int *__restrict__ homes, int k, int *__restric
     if (i < k) atomicAdd(&hist[homes[i]], 1);
 }
 
-// One workgroup per key to check: is there an empty slot in [home, cap)?  Linear probing fills slots from the left:
+// Is there an empty slot in [home, cap) for every key to check?  Linear probing fills slots from the left:
 // carry(x+1) = max(0, carry(x) + hist[x] - 1) entries arrive at slot x+1 still looking for a slot, and slot x is empty
-// iff carry(x) + hist[x] == 0.  The carry at slot 0 is what wraps around; two sweeps settle it.  Every thread folds its
-// contiguous piece of the table into a map c -> max(m, c + s); thread 0 chains the 1024 maps (twice for the wrap, once
-// more for every piece's incoming carry); then every thread walks its piece with its real carry.
+// iff carry(x) + hist[x] == 0.  The carry at slot 0 is what wraps around; two sweeps settle it.  ONE workgroup: every
+// thread folds its contiguous piece of the table into a map c -> max(m, c + s); the 1024 maps are chained (twice for
+// the wrap, once more for every piece's incoming carry); then every thread walks its piece with its real carry and
+// the workgroup keeps the LAST empty slot of the table: a key passes iff its home is not behind it.
+// (hist is read 16 bytes at a time, eight loads in flight: the walk is latency-bound otherwise -- 276 us at 2^19 slots.)
 __global__ __launch_bounds__(1024) void k_cluster_check(const int *__restrict__ hist, uint32_t cap, const int *__restrict__ homes,
-                                                        int *__restrict__ result)
+                                                        int nkeys, int *__restrict__ result)
 {
-    __shared__ long long sm[1024], ss[1024], cin[1024];
-    __shared__ int found;
-    const uint32_t piece = cap / 1024u;                    // cap >= 2^15
+    __shared__ int sm[1024], ss[1024], cin[1024], gm[64], gs[64], gc[64];
+    __shared__ int last_empty;
+    const uint32_t piece = cap / 1024u;                    // cap >= 2^15: a multiple of 32
     const uint32_t x0 = threadIdx.x * piece;
-    long long m = LLONG_MIN / 4, s = 0;                    // identity map
-    for (uint32_t x = x0; x < x0 + piece; x++) {
-        const long long a = (long long)hist[x] - 1;
-        m = max(0ll, m + a);
-        s += a;
+    const int4 *__restrict__ hp = reinterpret_cast<const int4 *>(hist + x0);
+    const uint32_t nq = piece / 4u;
+    int m = INT_MIN / 4, s = 0;                            // identity map
+    for (uint32_t q = 0; q < nq; q += 8) {
+        int4 v[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) v[j] = hp[q + j];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int a[4] = {v[j].x - 1, v[j].y - 1, v[j].z - 1, v[j].w - 1};
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                m = max(0, m + a[k]);
+                s += a[k];
+            }
+        }
     }
     sm[threadIdx.x] = m;
     ss[threadIdx.x] = s;
-    if (threadIdx.x == 0) found = 0;
+    if (threadIdx.x == 0) last_empty = -1;
+    __syncthreads();
+    // chain the 1024 maps in two levels (maps compose: (m2, s2) after (m1, s1) = (max(m2, m1 + s2), s1 + s2)):
+    // 64 threads fold 16 maps each, one thread chains the 64 results, the 64 threads hand every piece its carry
+    const int t0 = (int)threadIdx.x * 16;
+    if (threadIdx.x < 64) {
+        int a = INT_MIN / 4, b = 0;
+        for (int j = 0; j < 16; j++) {
+            a = max(sm[t0 + j], a + ss[t0 + j]);
+            b += ss[t0 + j];
+        }
+        gm[threadIdx.x] = a;
+        gs[threadIdx.x] = b;
+    }
     __syncthreads();
     if (threadIdx.x == 0) {
-        long long c = 0;
+        int c = 0;
         for (int pass = 0; pass < 2; pass++)
-            for (int t = 0; t < 1024; t++) c = max(sm[t], c + ss[t]);
-        for (int t = 0; t < 1024; t++) {                   // c = the carry that wraps into slot 0
-            cin[t] = c;
-            c = max(sm[t], c + ss[t]);
+            for (int t = 0; t < 64; t++) c = max(gm[t], c + gs[t]);
+        for (int t = 0; t < 64; t++) {                     // c = the carry that wraps into slot 0
+            gc[t] = c;
+            c = max(gm[t], c + gs[t]);
         }
     }
     __syncthreads();
-    const uint32_t h = (uint32_t)homes[blockIdx.x];
-    long long c = cin[threadIdx.x];
-    bool hit = false;
-    for (uint32_t x = x0; x < x0 + piece; x++) {
-        const long long hx = hist[x];
-        hit |= (x >= h) && (c + hx == 0);
-        c = max(0ll, c + hx - 1);
+    if (threadIdx.x < 64) {
+        int c = gc[threadIdx.x];
+        for (int j = 0; j < 16; j++) {
+            cin[t0 + j] = c;
+            c = max(sm[t0 + j], c + ss[t0 + j]);
+        }
     }
-    if (hit) found = 1;
     __syncthreads();
-    if (threadIdx.x == 0) result[blockIdx.x] = found;
+    int c = cin[threadIdx.x];
+    int last = -1;
+    for (uint32_t q = 0; q < nq; q += 8) {
+        int4 v[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) v[j] = hp[q + j];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int a[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                if (c + a[k] == 0) last = (int)(x0 + (q + (uint32_t)j) * 4u + (uint32_t)k);
+                c = max(0, c + a[k] - 1);
+            }
+        }
+    }
+    if (last >= 0) atomicMax(&last_empty, last);
+    __syncthreads();
+    for (int k = threadIdx.x; k < nkeys; k += 1024) result[k] = homes[k] <= last_empty ? 1 : 0;
 }
 
 struct device_query : phl_reftable_query {
@@ -762,7 +817,7 @@ struct device_query : phl_reftable_query {
                 hipLaunchKernelGGL(k_home_hist, dim3((unsigned)((n_clean + 255) / 256)), dim3(256), 0, st, vkeys_dev, n_clean, d,
                                    (uint32_t)(cap - 1), hist);
             if (nadd > 0) hipLaunchKernelGGL(k_add_homes, dim3(1), dim3(256), 0, st, small, nadd, hist);
-            hipLaunchKernelGGL(k_cluster_check, dim3((unsigned)check.size()), dim3(1024), 0, st, hist, (uint32_t)cap, small + nadd,
+            hipLaunchKernelGGL(k_cluster_check, dim3(1), dim3(1024), 0, st, hist, (uint32_t)cap, small + nadd, (int)check.size(),
                                small + 192);
             r = hipGetLastError();
         }
@@ -1001,5 +1056,44 @@ extern "C" int phl_debug_reference_table(const int16_t *keys_clean, const int32_
     *n_hidden_out = (int)R.hidden.size();
     for (size_t i = 0; i < R.hidden.size(); i++) hidden_out[i] = R.hidden[i];
     *blur_first_nbr_out = R.blur_grow ? R.blur_first_nbr : -2;
+    return PHL_OK;
+}
+
+// Test entry: the occupancy check of the analytic replay (probe_paths_do_not_wrap) on the device (k_home_hist,
+// k_add_homes, k_cluster_check) or on the host, for a caller-made key set.  result_out: 1 = no probe path wraps.
+extern "C" int phl_debug_probe_paths(const int16_t *keys_clean, int64_t n_clean, int d, const int32_t *extra_clean, int n_extra,
+                                     const int32_t *stale_clean, int n_stale, uint64_t cap, const int32_t *check, int n_check,
+                                     int on_device, int *result_out)
+{
+    if (!keys_clean || n_clean < 0 || d < 1 || !result_out || cap < ((uint64_t)1 << 15) || (cap & (cap - 1)) || n_check < 0) {
+        phl_set_error("phl_debug_probe_paths: bad arguments");
+        return PHL_ERR_INVALID;
+    }
+    const std::vector<int32_t> ex(extra_clean, extra_clean + n_extra), sc(stale_clean, stale_clean + n_stale), ck(check, check + n_check);
+    if (!on_device) {
+        host_query q;
+        q.cand = nullptr;
+        q.N = 0;
+        q.keys = keys_clean;
+        q.d = d;
+        *result_out = q.probe_paths_do_not_wrap(n_clean, ex, sc, cap, ck);
+        return PHL_OK;
+    }
+    temp_pool tmp;
+    device_query q;
+    int16_t *kd;
+    PHL_HIP(tmp.get(&kd, (size_t)n_clean * d + 1));
+    PHL_HIP(tmp.get(&q.hist, (size_t)cap));
+    PHL_HIP(tmp.get(&q.small, 256));
+    PHL_HIP(hipMemcpy(kd, keys_clean, sizeof(int16_t) * (size_t)n_clean * d, hipMemcpyHostToDevice));
+    q.replay = nullptr;
+    q.N = 0;
+    q.scratch = nullptr;
+    q.st = nullptr;
+    q.vkeys_dev = kd;
+    q.keys_host = keys_clean;
+    q.d = d;
+    *result_out = q.probe_paths_do_not_wrap(n_clean, ex, sc, cap, ck);
+    if (q.err != hipSuccess) return phl_hip_fail(q.err, "phl_debug_probe_paths", __FILE__, __LINE__);
     return PHL_OK;
 }

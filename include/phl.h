@@ -296,6 +296,15 @@ int phl_debug_reference_table(const int16_t *keys_clean, const int32_t *cand_vid
                               int32_t *cand_ref_vid_out, int32_t *hidden_out, int hidden_cap, int *n_hidden_out,
                               int *blur_first_nbr_out);
 
+/* Test hook: the one assumption of the analytic table replay -- no tracked key's probe path in the reference's table
+ * (linear probing, permutohedral.h:84-106, capacity `cap` = a power of two >= 2^15) runs past the last slot -- checked
+ * for a caller-made key set on the device (on_device = 1: the kernels the build uses) or on the host (0).
+ * keys_clean [n_clean][d]; extra_clean / stale_clean / check index into it (entries filed a second time under `cap`,
+ * entries filed under cap / 2, keys whose paths are asked about).  *result_out = 1 if none wraps. */
+int phl_debug_probe_paths(const int16_t *keys_clean, int64_t n_clean, int d, const int32_t *extra_clean, int n_extra,
+                          const int32_t *stale_clean, int n_stale, uint64_t cap, const int32_t *check, int n_check,
+                          int on_device, int *result_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -809,3 +809,35 @@ def test_analytic_and_simulated_table_replay_build_the_same_lattice(phl, monkeyp
         assert got["1"][0] == got["0"][0] >= 16383
         for a, b in zip(got["1"][1:], got["0"][1:]):
             assert np.array_equal(a, b)
+
+
+def test_occupancy_check_on_the_device_equals_the_host(phl):
+    """k_home_hist / k_add_homes / k_cluster_check (the analytic replay's one assumption, checked during the build)
+    against the host form, which tests/test_reference_table_cpu.py holds against brute-force probing."""
+    from test_reference_table_cpu import keys_with_homes, probe_paths, ref_homes
+
+    rng = np.random.default_rng(23)
+    seen = set()
+    for trial in range(16):
+        cap = 1 << int(rng.choice([15, 16, 17, 19]))
+        keys, homes = keys_with_homes(rng, cap, count=1 << 19)
+        n = int(rng.integers(cap // 8, min(cap // 2 - 1, len(keys) - 1)))
+        if trial % 2:
+            order = np.argsort(-homes, kind="stable")
+            pile = order[: int(rng.integers(2, 300))]
+            rest = rng.permutation(np.setdiff1d(np.arange(len(keys)), pile))[: n - len(pile)]
+            sel = np.concatenate([rest, pile])
+        else:
+            sel = rng.permutation(len(keys))[:n]
+        k, hk = keys[sel], homes[sel]
+        extra = rng.integers(0, n, int(rng.integers(0, 4)))
+        stale = rng.integers(0, n, int(rng.integers(0, 3)))
+        for c in list(rng.integers(0, n, 2)) + [n - 1, int(np.argmax(hk))]:
+            want = probe_paths(k, n, extra, stale, cap, [c], on_device=0)
+            got = probe_paths(k, n, extra, stale, cap, [c], on_device=1)
+            assert got == want, (trial, cap, n, c)
+            seen.add(want)
+        # several keys in one call: all must pass
+        many = rng.integers(0, n, 40)
+        assert probe_paths(k, n, extra, stale, cap, many, on_device=1) == probe_paths(k, n, extra, stale, cap, many, on_device=0)
+    assert seen == {0, 1}, "the cases should cover both answers"

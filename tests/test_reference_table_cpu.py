@@ -172,3 +172,86 @@ def test_analytic_replay_equals_the_simulation(monkeypatch):
         assert np.array_equal(got[2], want[2]) and got[3] == want[3], (seed, "hidden / blur neighbour")
     print(f"analytic replay applied {applied}x (with duplicate vertices {with_dups}x), fell back {fell_back}x")
     assert applied >= 60 and with_dups >= 10 and fell_back <= applied // 4
+
+
+# ---- the analytic replay's occupancy check (probe_paths_do_not_wrap) ------------------------------------------------
+def ref_homes(keys, cap):
+    """Home slots under the reference's hash (permutohedral.h:109-116; size_t arithmetic) for a power-of-two capacity."""
+    h = np.zeros(len(keys), np.uint64)
+    with np.errstate(over="ignore"):
+        for i in range(keys.shape[1]):
+            h = (h + keys[:, i].astype(np.int64).astype(np.uint64)) * np.uint64(2531011)
+    return (h & np.uint64(cap - 1)).astype(np.int64)
+
+
+def probe_paths(keys, n_clean, extra, stale, cap, check, on_device=0):
+    import phl
+
+    lib = phl.load_library()
+    keys = np.ascontiguousarray(keys, np.int16)
+    ex, st, ck = (np.ascontiguousarray(a, np.int32) for a in (extra, stale, check))
+    res = C.c_int(-1)
+    rc = lib.phl_debug_probe_paths(keys.ctypes.data_as(C.c_void_p), n_clean, keys.shape[1], ex.ctypes.data_as(C.c_void_p), len(ex),
+                                   st.ctypes.data_as(C.c_void_p), len(st), cap, ck.ctypes.data_as(C.c_void_p), len(ck),
+                                   on_device, C.byref(res))
+    assert rc == 0, lib.phl_last_error()
+    return res.value
+
+
+def brute_force_paths(homes_all, cap, check_homes):
+    """Insert every entry by linear probing (order does not matter for which slots end up full)."""
+    full = np.zeros(cap, bool)
+    for h in homes_all:
+        while full[h]:
+            h = (h + 1) % cap
+        full[h] = True
+    return int(all((~full[h:]).any() for h in check_homes))
+
+
+def keys_with_homes(rng, cap, d=5, count=1 << 18):
+    keys = rng.integers(-3000, 3000, (count, d)).astype(np.int16)
+    keys = np.unique(keys, axis=0)
+    return keys, ref_homes(keys, cap)
+
+
+def test_occupancy_check_sees_a_full_table_tail():
+    cap = 1 << 15
+    rng = np.random.default_rng(5)
+    keys, homes = keys_with_homes(rng, cap)
+    tail = np.nonzero(homes >= cap - 4)[0]
+    assert len(tail) >= 8
+    body = np.nonzero(homes < cap - 64)[0][:9000]
+    # the last four slots full (six entries want them): every path from there wraps
+    sel = np.concatenate([body, tail[:6]])
+    k = keys[sel]
+    n = len(k)
+    assert probe_paths(k, n, [], [], cap, [n - 1]) == 0
+    assert probe_paths(k, n, [], [], cap, [0]) == (1 if homes[sel[0]] < cap - 4 else 0)
+    # one entry in the tail: slots behind it are free
+    sel = np.concatenate([body, tail[:1]])
+    k = keys[sel]
+    want = 1 if homes[tail[0]] < cap - 1 else 0
+    assert probe_paths(k, len(k), [], [], cap, [len(k) - 1]) == want
+
+
+def test_occupancy_check_equals_brute_force_probing():
+    rng = np.random.default_rng(17)
+    for trial in range(12):
+        cap = 1 << int(rng.choice([15, 16]))
+        keys, homes = keys_with_homes(rng, cap, count=1 << 17)
+        n = int(rng.integers(cap // 8, cap // 2 - 1))
+        # bias towards trouble: half of the cases pile entries onto the table's end
+        if trial % 2:
+            order = np.argsort(-homes, kind="stable")
+            pile = order[: int(rng.integers(4, 200))]
+            rest = rng.permutation(np.setdiff1d(np.arange(len(keys)), pile))[: n - len(pile)]
+            sel = np.concatenate([rest, pile])
+        else:
+            sel = rng.permutation(len(keys))[:n]
+        k, hk = keys[sel], homes[sel]
+        extra = rng.integers(0, n, int(rng.integers(0, 4)))
+        stale = rng.integers(0, n, int(rng.integers(0, 3)))
+        all_homes = np.concatenate([hk, hk[extra], ref_homes(k[stale], cap // 2)]) if len(stale) else np.concatenate([hk, hk[extra]])
+        for c in list(rng.integers(0, n, 3)) + [n - 1, int(np.argmax(hk))]:
+            want = brute_force_paths(all_homes.tolist(), cap, [int(hk[c])])
+            assert probe_paths(k, n, extra, stale, cap, [c]) == want, (trial, cap, n, c)
