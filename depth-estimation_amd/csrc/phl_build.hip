@@ -10,8 +10,8 @@
 //   insert     lock-free open addressing: slot <- atomicCAS(EMPTY, e), equal keys fold to the
 //              MINIMUM candidate index with atomicMin  => deterministic representative;
 //              runs of equal keys along a wavefront (neighbouring pixels) probe once
-//   flag+scan  representative candidates, exclusive scan => vertex id = first-touch rank,
-//              i.e. exactly the reference's insertion order                   (:70-77)
+//   flag+scan  representative candidates as a bit mask, scan of its word counts => vertex id =
+//              first-touch rank, i.e. exactly the reference's insertion order (:70-77)
 //   assign     vertex keys [M][d]; table now maps key -> vertex id
 //   (on demand) count/scan/fill/sort   transpose of the replay matrix: per vertex the (pixel,
 //              weight) list in ascending pixel order for the reference-exact gather splat
@@ -202,21 +202,30 @@ __global__ __launch_bounds__(256) void k_insert(const int16_t *__restrict__ ckey
     if (active) slot_of[e] = slot;
 }
 
-__global__ __launch_bounds__(256) void k_flag(const int *__restrict__ table, const int *__restrict__ slot_of, int N,
-                                              int *__restrict__ flag)
+// First-touch flags as a bit mask: bit e is set iff candidate e is the representative (smallest index) of its key;
+// wcount[w] = set bits of word w.  The vertex id of a representative is its rank among the set bits, i.e. the scan of
+// the N / 64 word counts plus a popcount -- not a scan over all N candidates.
+__global__ __launch_bounds__(256) void k_flag_bits(const int *__restrict__ table, const int *__restrict__ slot_of, int N,
+                                                   unsigned long long *__restrict__ bits, int *__restrict__ wcount)
 {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= N) return;
-    flag[e] = (table[slot_of[e]] == e) ? 1 : 0;
+    const bool f = e < N && table[slot_of[e]] == e;
+    const unsigned long long m = __ballot(f);
+    if ((threadIdx.x & 63) == 0) {
+        bits[e >> 6] = m;
+        wcount[e >> 6] = __popcll(m);
+    }
 }
 
-__global__ __launch_bounds__(256) void k_assign(const int *__restrict__ flag, const int *__restrict__ rankv,
+__global__ __launch_bounds__(256) void k_assign(const unsigned long long *__restrict__ bits, const int *__restrict__ wrank,
                                                 const int *__restrict__ slot_of, const int16_t *__restrict__ ckeys,
                                                 int d, int N, int *table, int16_t *__restrict__ vkeys, int *__restrict__ vfirst)
 {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= N || !flag[e]) return;
-    const int vid = rankv[e];
+    if (e >= N) return;
+    const unsigned long long m = bits[e >> 6];
+    if (!((m >> (e & 63)) & 1ull)) return;
+    const int vid = wrank[e >> 6] + __popcll(m & ((1ull << (e & 63)) - 1ull));
     for (int i = 0; i < d; i++) vkeys[(int64_t)vid * d + i] = ckeys[(int64_t)e * d + i];
     table[slot_of[e]] = -(vid + 1);
     vfirst[vid] = e;     // first-touch candidate of the vertex (its pixel tells the renumbering where the vertex lives)
@@ -470,13 +479,17 @@ int phl_build_device(phl_lattice *lat, const float *ref, int64_t rs, int64_t cs,
 
     temp_pool tmp;
     int16_t *ckeys;
-    int *table, *slot_of, *flag, *rankv, *tile_sums, *err;
+    int *table, *slot_of, *wcount, *wrank, *tile_sums, *err;
+    unsigned long long *fbits;
+    const unsigned gN = (unsigned)((N + 255) / 256);
+    const int NW = (int)gN * 4;                      // 64-candidate words of the first-touch mask
     PHL_HIP(tmp.get(&ckeys, (size_t)N * d));
     PHL_HIP(tmp.get(&table, cap));
     PHL_HIP(tmp.get(&slot_of, (size_t)N));
-    PHL_HIP(tmp.get(&flag, (size_t)N));
-    PHL_HIP(tmp.get(&rankv, (size_t)N + 1));
-    PHL_HIP(tmp.get(&tile_sums, (size_t)N / SCAN_TILE + 2));
+    PHL_HIP(tmp.get(&fbits, (size_t)NW));
+    PHL_HIP(tmp.get(&wcount, (size_t)NW));
+    PHL_HIP(tmp.get(&wrank, (size_t)NW + 1));
+    PHL_HIP(tmp.get(&tile_sums, (size_t)NW / SCAN_TILE + 2));
     PHL_HIP(tmp.get(&err, 1));
     PHL_HIP(phl_dev_malloc((void **)&lat->replay, sizeof(phl_replay_t) * (size_t)N));
     PHL_HIP(hipMemsetAsync(err, 0, sizeof(int), st));
@@ -488,7 +501,6 @@ int phl_build_device(phl_lattice *lat, const float *ref, int64_t rs, int64_t cs,
 #undef PHL_CASE
         default: phl_set_error("d=%d unsupported (1..%d)", d, PHL_MAX_D); return PHL_ERR_UNSUPPORTED;
     }
-    const unsigned gN = (unsigned)((N + 255) / 256);
     int host[2] = {0, 0};
     int rc = PHL_OK;
     for (;;) {
@@ -498,11 +510,11 @@ int phl_build_device(phl_lattice *lat, const float *ref, int64_t rs, int64_t cs,
             hipLaunchKernelGGL(k_insert, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, ckeys, d, (int)n, table, mask, slot_of,
                                cap == cap_full ? 0x7FFFFFFF : 128, err);
         }
-        hipLaunchKernelGGL(k_flag, dim3(gN), dim3(256), 0, st, table, slot_of, N, flag);
+        hipLaunchKernelGGL(k_flag_bits, dim3(gN), dim3(256), 0, st, table, slot_of, N, fbits, wcount);
         PHL_HIP(hipGetLastError());
-        rc = exclusive_scan(flag, rankv, N, tile_sums, st);
+        rc = exclusive_scan(wcount, wrank, NW, tile_sums, st);
         if (rc) return rc;
-        PHL_HIP(hipMemcpyAsync(&host[0], rankv + N, sizeof(int), hipMemcpyDeviceToHost, st));
+        PHL_HIP(hipMemcpyAsync(&host[0], wrank + NW, sizeof(int), hipMemcpyDeviceToHost, st));
         PHL_HIP(hipMemcpyAsync(&host[1], err, sizeof(int), hipMemcpyDeviceToHost, st));
         PHL_HIP(hipStreamSynchronize(st));
         if ((host[1] & 1) || !(host[1] & 2) || cap == cap_full) break;
@@ -525,11 +537,11 @@ int phl_build_device(phl_lattice *lat, const float *ref, int64_t rs, int64_t cs,
     lat->vfirst = nullptr;
     lat->vfirst_valid_for_M = 0;
     PHL_HIP(phl_dev_malloc((void **)&lat->vfirst, sizeof(int) * ((size_t)M + 1)));
-    hipLaunchKernelGGL(k_assign, dim3(gN), dim3(256), 0, st, flag, rankv, slot_of, ckeys, d, N, table, lat->vkeys, lat->vfirst);
+    hipLaunchKernelGGL(k_assign, dim3(gN), dim3(256), 0, st, fbits, wrank, slot_of, ckeys, d, N, table, lat->vkeys, lat->vfirst);
     hipLaunchKernelGGL(k_set_vid, dim3(gN), dim3(256), 0, st, table, slot_of, N, lat->replay);
     PHL_HIP(hipGetLastError());
     if (lat->build_flags & PHL_BUILD_REFERENCE_TABLE) {
-        rc = phl_apply_reference_table(lat, flag, rankv, st);
+        rc = phl_apply_reference_table(lat, st);
         if (rc) return rc;
     }
     if (lat->M != M && lat->vfirst_valid_for_M != lat->M) {     // duplicate vertices inserted without a list of their own

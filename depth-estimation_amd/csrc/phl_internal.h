@@ -112,7 +112,7 @@ int phl_reference_table_sim(const int16_t *keys_clean, const int32_t *efirst, in
 // the same result without simulating the table (phl_reftable.hip, "analytic replay"); 1 = not applicable here, use the sim
 int phl_reference_table_fast(const int16_t *keys_clean, const int32_t *efirst, int64_t M, int d, int64_t N,
                              phl_reftable_query &q, phl_reftable_result &out);
-int phl_apply_reference_table(phl_lattice *lat, const int *flag, const int *rankv, hipStream_t st);
+int phl_apply_reference_table(phl_lattice *lat, hipStream_t st);
 
 // Buffers one filter call writes: the [M][vd] Jacobi ping-pong pair, the partial rows of the chunk splat and
 // the staging copies of non pixel-major inputs / outputs.  Grown on demand, reused in stream order.

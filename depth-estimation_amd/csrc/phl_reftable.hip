@@ -631,13 +631,6 @@ int phl_reference_table_fast(const int16_t *keys_clean, const int32_t *efirst, i
 namespace {
 
 // ---- device side ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_efirst(const int *__restrict__ flag, const int *__restrict__ rankv, int N,
-                                                int *__restrict__ efirst)
-{
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e < N && flag[e]) efirst[rankv[e]] = e;
-}
-
 __global__ __launch_bounds__(256) void k_next_occurrence(const phl_replay_t *__restrict__ replay, int N, int vid, int after,
                                                          int *__restrict__ out)
 {
@@ -858,9 +851,9 @@ struct device_query : phl_reftable_query {
 
 }  // namespace
 
-// Called by phl_build_device between the clean numbering and the neighbour tables.  flag / rankv are the
-// first-touch flags and their exclusive scan over the N candidates; replay[].vid holds clean ids.
-int phl_apply_reference_table(phl_lattice *lat, const int *flag, const int *rankv, hipStream_t st)
+// Called by phl_build_device between the clean numbering and the neighbour tables.  lat->vfirst holds every clean
+// vertex's first-touch candidate, replay[].vid the clean ids.
+int phl_apply_reference_table(phl_lattice *lat, hipStream_t st)
 {
     const int d = lat->d;
     const int64_t M = lat->M;
@@ -872,11 +865,10 @@ int phl_apply_reference_table(phl_lattice *lat, const int *flag, const int *rank
     auto since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count(); };
     static const bool dbg = getenv("PHL_DEBUG") != nullptr;
     temp_pool tmp;
-    int *efirst_dev, *scratch;
-    PHL_HIP(tmp.get(&efirst_dev, (size_t)M));
+    int *scratch;
+    const int *efirst_dev = lat->vfirst;
+    if (!efirst_dev) { phl_set_error("reference-table replay: first touches missing"); return PHL_ERR_INVALID; }
     PHL_HIP(tmp.get(&scratch, 1));
-    hipLaunchKernelGGL(k_efirst, dim3((N + 255) / 256), dim3(256), 0, st, flag, rankv, N, efirst_dev);
-    PHL_HIP(hipGetLastError());
     std::vector<int16_t> keys((size_t)M * d);
     std::vector<int32_t> efirst((size_t)M);
     PHL_HIP(hipMemcpyAsync(keys.data(), lat->vkeys, sizeof(int16_t) * keys.size(), hipMemcpyDeviceToHost, st));
@@ -944,7 +936,7 @@ int phl_apply_reference_table(phl_lattice *lat, const int *flag, const int *rank
         int *dv_id_dev, *dv_e_dev;
         PHL_HIP(tmp.get(&dv_id_dev, dv_id.size() + 1));
         PHL_HIP(tmp.get(&dv_e_dev, dv_e.size() + 1));
-        if (lat->vfirst) PHL_HIP(phl_dev_free(lat->vfirst));
+        int *vfirst_clean = lat->vfirst;              // (= efirst_dev: read by the launch below, released behind the sync)
         lat->vfirst = nullptr;
         PHL_HIP(phl_dev_malloc((void **)&lat->vfirst, sizeof(int) * (size_t)R.M_ref));
         PHL_HIP(hipMemsetAsync(lat->vfirst, 0, sizeof(int) * (size_t)R.M_ref, st));
@@ -956,6 +948,7 @@ int phl_apply_reference_table(phl_lattice *lat, const int *flag, const int *rank
         }
         PHL_HIP(hipGetLastError());
         PHL_HIP(hipStreamSynchronize(st));            // host vectors and pool temporaries die on return
+        PHL_HIP(phl_dev_free(vfirst_clean));
         PHL_HIP(phl_dev_free(lat->vkeys));
         lat->vkeys = vkeys_new;
         lat->M = R.M_ref;
