@@ -6,7 +6,7 @@
 //
 // Pipeline (one kernel each, all on the caller's stream):
 //   elevate    per pixel: elevate to H_d, nearest remainder-0 point, rank, barycentric
-//              weights -> d+1 candidate keys (int16[d]) + weights            (:380-447)
+//              weights -> a record the d+1 candidate keys are rebuilt from + weights (:380-447)
 //   insert     lock-free open addressing: slot <- atomicCAS(EMPTY, e), equal keys fold to the
 //              MINIMUM candidate index with atomicMin  => deterministic representative;
 //              runs of equal keys along a wavefront (neighbouring pixels) probe once
@@ -32,11 +32,56 @@ struct sf_t {
 };
 
 // ------------------------------------------------------------------------------------------
+// Per-pixel record the candidate keys are rebuilt from: the first D coordinates of the rounded point (`greedy`, as
+// shorts: every key coordinate is one of them plus a canonical offset, and r = 0 has offset 0, so they are in range
+// whenever the keys are) and their ranks (0..D, five bits each, six to a word).
+template <int D>
+struct pix_rec {
+    static constexpr int GW = (D + 1) / 2;            // words of packed shorts
+    static constexpr int W = GW + (D + 5) / 6;        // + words of packed ranks
+    static __device__ __forceinline__ void load(const uint32_t *__restrict__ p, uint32_t (&w)[W])
+    {
+        if constexpr (W == 4) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(p);
+            w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
+        } else if constexpr (W == 2) {
+            const uint2 v = *reinterpret_cast<const uint2 *>(p);
+            w[0] = v.x; w[1] = v.y;
+        } else {
+#pragma unroll
+            for (int j = 0; j < W; j++) w[j] = p[j];
+        }
+    }
+    static __device__ __forceinline__ void store(uint32_t *__restrict__ p, const uint32_t (&w)[W])
+    {
+        if constexpr (W == 4) *reinterpret_cast<uint4 *>(p) = make_uint4(w[0], w[1], w[2], w[3]);
+        else if constexpr (W == 2) *reinterpret_cast<uint2 *>(p) = make_uint2(w[0], w[1]);
+        else {
+#pragma unroll
+            for (int j = 0; j < W; j++) p[j] = w[j];
+        }
+    }
+    // candidate key r of the pixel, as GW words of packed shorts (the unused half of the last word is zero)
+    static __device__ __forceinline__ void key(const uint32_t (&w)[W], int r, uint32_t (&k)[GW])
+    {
+#pragma unroll
+        for (int j = 0; j < GW; j++) k[j] = 0u;
+#pragma unroll
+        for (int i = 0; i < D; i++) {
+            const int g = (int)(int16_t)(uint16_t)(w[i >> 1] >> (16 * (i & 1)));
+            const int rk = (int)((w[GW + i / 6] >> (5 * (i % 6))) & 31u);
+            const int c = g + (rk <= D - r ? r : r - (D + 1));
+            k[i >> 1] |= (uint32_t)(uint16_t)(int16_t)c << (16 * (i & 1));
+        }
+    }
+};
+
+// ------------------------------------------------------------------------------------------
 // elevate: one thread per pixel, everything in registers (D is a template parameter so that
 // all loops unroll and no array is runtime-indexed).
 template <int D>
 __global__ __launch_bounds__(256) void k_elevate(const float *__restrict__ ref, int64_t rs, int64_t cs, int64_t n,
-                                                 sf_t sf, int16_t *__restrict__ ckeys,
+                                                 sf_t sf, uint32_t *__restrict__ recs,
                                                  phl_replay_t *__restrict__ replay, int *__restrict__ err)
 {
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -110,20 +155,29 @@ __global__ __launch_bounds__(256) void k_elevate(const float *__restrict__ ref, 
     }
     bary[0] = bary[0] + (1.0f + bary[D + 1]);
 
-    // :444-447, :458-460
+    // :444-447, :458-460.  The d+1 candidate keys of the pixel differ only by the canonical offsets (:346-351):
+    // key_r[i] = greedy[i] + (rank[i] <= D - r ? r : r - (D+1)).  Stored once per pixel as a record (pix_rec<D>)
+    // instead of d+1 keys of d shorts each: 16 bytes instead of 60 at d = 5.
     bool bad = false;
-    int16_t *kout = ckeys + p * (int64_t)((D + 1) * D);
-    phl_replay_t *rout = replay + p * (D + 1);
 #pragma unroll
-    for (int r = 0; r <= D; r++) {
+    for (int r = 0; r <= D; r++)
 #pragma unroll
         for (int i = 0; i < D; i++) {
-            int c = greedy[i] + (rank[i] <= D - r ? r : r - (D + 1));  // canonical[r][rank], :346-351
+            const int c = greedy[i] + (rank[i] <= D - r ? r : r - (D + 1));
             bad |= (c < -32768) | (c > 32767);
-            kout[r * D + i] = (int16_t)c;
         }
-        rout[r].w = bary[r];
+    uint32_t rw[pix_rec<D>::W];
+#pragma unroll
+    for (int j = 0; j < pix_rec<D>::W; j++) rw[j] = 0u;
+#pragma unroll
+    for (int i = 0; i < D; i++) {
+        rw[i >> 1] |= (uint32_t)(uint16_t)(int16_t)greedy[i] << (16 * (i & 1));
+        rw[pix_rec<D>::GW + i / 6] |= (uint32_t)rank[i] << (5 * (i % 6));
     }
+    pix_rec<D>::store(recs + p * pix_rec<D>::W, rw);
+    phl_replay_t *rout = replay + p * (D + 1);
+#pragma unroll
+    for (int r = 0; r <= D; r++) rout[r].w = bary[r];
     if (bad) atomicOr(err, 1);
 }
 
@@ -139,17 +193,19 @@ __device__ __forceinline__ uint32_t mix_end(uint32_t h)
 }
 
 // One thread per candidate (pixel, remainder).  table[slot] ends up holding the SMALLEST
-// candidate index among all candidates with that key.  ckeys was written by the previous
-// launch, and the index read back from the atomic is always a candidate whose key is fully
-// written, so no in-kernel hand-off of plain data is needed.
-__global__ __launch_bounds__(256) void k_insert(const int16_t *__restrict__ ckeys, int d, int n, int *table,
+// candidate index among all candidates with that key.  The records were written by the previous
+// launch, and the index read back from the atomic is always a candidate of a pixel whose record is
+// there, so no in-kernel hand-off of plain data is needed.
+template <int D>
+__global__ __launch_bounds__(256) void k_insert(const uint32_t *__restrict__ recs, int n, int *table,
                                                 uint32_t mask, int *__restrict__ slot_of, int max_probe, int *__restrict__ err)
 {
     // A wavefront takes 64 CONSECUTIVE pixels of ONE remainder: neighbouring pixels mostly lie
     // in the same simplex, so the same key repeats along the lanes and only the first lane of
     // each run probes the table (its candidate index is the smallest of the run, which is what
     // the atomicMin wants anyway).
-    const int dp1 = d + 1;
+    using R = pix_rec<D>;
+    constexpr int dp1 = D + 1;
     const int lane = threadIdx.x & 63;
     // the small table has been found too small: the host will repeat the insertion, nothing of this launch is kept
     if (max_probe != 0x7FFFFFFF && (*reinterpret_cast<volatile int *>(err) & 2)) return;
@@ -157,21 +213,19 @@ __global__ __launch_bounds__(256) void k_insert(const int16_t *__restrict__ ckey
     const int r = (int)(wave % dp1);
     const int64_t p = (wave / dp1) * 64 + lane;
     const bool active = p < n;
-    const int e = (int)((active ? p : (int64_t)n - 1) * dp1 + r);
-    const int16_t *key = ckeys + (int64_t)e * d;
+    const int64_t pc = active ? p : (int64_t)n - 1;
+    const int e = (int)(pc * dp1 + r);
+    uint32_t rec[R::W], key[R::GW];
+    R::load(recs + pc * R::W, rec);
+    R::key(rec, r, key);
     uint32_t h = mix_begin();
-    for (int i = 0; i < d; i++) h = mix_step(h, key[i]);
+#pragma unroll
+    for (int i = 0; i < D; i++) h = mix_step(h, (int)(int16_t)(uint16_t)(key[i >> 1] >> (16 * (i & 1))));
     h = mix_end(h);
-    // same key as the previous lane?  (hash first, then the key itself)
-    bool same_prev = false;
-    {
-        const uint32_t hp = (uint32_t)__shfl_up((int)h, 1);
-        if (active && lane > 0 && hp == h) {
-            const int16_t *pk = ckeys + (int64_t)(e - dp1) * d;
-            same_prev = true;
-            for (int i = 0; i < d; i++) same_prev &= (pk[i] == key[i]);
-        }
-    }
+    // same key as the previous lane?
+    bool same_prev = active && lane > 0;
+#pragma unroll
+    for (int j = 0; j < R::GW; j++) same_prev &= ((uint32_t)__shfl_up((int)key[j], 1) == key[j]);
     const unsigned long long heads = __ballot(active && !same_prev);
     const unsigned long long below = heads & ((lane == 63) ? ~0ull : ((2ull << lane) - 1ull));
     const int head_lane = 63 - __clzll(below ? below : 1ull);
@@ -185,11 +239,15 @@ __global__ __launch_bounds__(256) void k_insert(const int16_t *__restrict__ ckey
                 atomicOr(err, 2);
                 break;
             }
-            int prev = atomicCAS(&table[h], PHL_EMPTY, e);
+            const int prev = atomicCAS(&table[h], PHL_EMPTY, e);
             if (prev == PHL_EMPTY) break;
-            const int16_t *other = ckeys + (int64_t)prev * d;
+            const int p2 = prev / dp1;
+            uint32_t rec2[R::W], key2[R::GW];
+            R::load(recs + (int64_t)p2 * R::W, rec2);
+            R::key(rec2, prev - p2 * dp1, key2);
             bool same = true;
-            for (int i = 0; i < d; i++) same &= (other[i] == key[i]);
+#pragma unroll
+            for (int j = 0; j < R::GW; j++) same &= (key2[j] == key[j]);
             if (same) {
                 if (e < prev) atomicMin(&table[h], e);
                 break;
@@ -217,16 +275,23 @@ __global__ __launch_bounds__(256) void k_flag_bits(const int *__restrict__ table
     }
 }
 
+template <int D>
 __global__ __launch_bounds__(256) void k_assign(const unsigned long long *__restrict__ bits, const int *__restrict__ wrank,
-                                                const int *__restrict__ slot_of, const int16_t *__restrict__ ckeys,
-                                                int d, int N, int *table, int16_t *__restrict__ vkeys, int *__restrict__ vfirst)
+                                                const int *__restrict__ slot_of, const uint32_t *__restrict__ recs,
+                                                int N, int *table, int16_t *__restrict__ vkeys, int *__restrict__ vfirst)
 {
+    using R = pix_rec<D>;
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= N) return;
     const unsigned long long m = bits[e >> 6];
     if (!((m >> (e & 63)) & 1ull)) return;
     const int vid = wrank[e >> 6] + __popcll(m & ((1ull << (e & 63)) - 1ull));
-    for (int i = 0; i < d; i++) vkeys[(int64_t)vid * d + i] = ckeys[(int64_t)e * d + i];
+    const int p = e / (D + 1);
+    uint32_t rec[R::W], key[R::GW];
+    R::load(recs + (int64_t)p * R::W, rec);
+    R::key(rec, e - p * (D + 1), key);
+#pragma unroll
+    for (int i = 0; i < D; i++) vkeys[(int64_t)vid * D + i] = (int16_t)(uint16_t)(key[i >> 1] >> (16 * (i & 1)));
     table[slot_of[e]] = -(vid + 1);
     vfirst[vid] = e;     // first-touch candidate of the vertex (its pixel tells the renumbering where the vertex lives)
 }
@@ -382,12 +447,31 @@ __global__ __launch_bounds__(256) void k_append_missing(const int16_t *__restric
 }
 
 template <int D>
-void launch_elevate(const float *ref, int64_t rs, int64_t cs, int64_t n, const sf_t &sf, int16_t *ckeys,
+void launch_elevate(const float *ref, int64_t rs, int64_t cs, int64_t n, const sf_t &sf, uint32_t *recs,
                     phl_replay_t *replay, int *err, hipStream_t st)
 {
     const unsigned blocks = (unsigned)((n + 255) / 256);
-    hipLaunchKernelGGL(k_elevate<D>, dim3(blocks), dim3(256), 0, st, ref, rs, cs, n, sf, ckeys, replay, err);
+    hipLaunchKernelGGL(k_elevate<D>, dim3(blocks), dim3(256), 0, st, ref, rs, cs, n, sf, recs, replay, err);
 }
+
+template <int D>
+void launch_insert(const uint32_t *recs, int64_t n, int *table, uint32_t mask, int *slot_of, int max_probe, int *err, hipStream_t st)
+{
+    const int64_t waves = ((n + 63) / 64) * (D + 1);
+    hipLaunchKernelGGL(k_insert<D>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, recs, (int)n, table, mask, slot_of, max_probe, err);
+}
+
+template <int D>
+void launch_assign(const unsigned long long *bits, const int *wrank, const int *slot_of, const uint32_t *recs, int N, int *table,
+                   int16_t *vkeys, int *vfirst, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_assign<D>, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, bits, wrank, slot_of, recs, N, table, vkeys, vfirst);
+}
+
+constexpr int rec_words(int d) { return (d + 1) / 2 + (d + 5) / 6; }
+
+#define PHL_FOR_D(X)                                                                                                     \
+    X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16)
 
 __global__ __launch_bounds__(256) void k_iota_from(int *p, int n, int first)
 {
@@ -478,12 +562,12 @@ int phl_build_device(phl_lattice *lat, const float *ref, int64_t rs, int64_t cs,
     uint32_t mask = (uint32_t)(cap - 1);
 
     temp_pool tmp;
-    int16_t *ckeys;
+    uint32_t *recs;                                  // per-pixel records the candidate keys are rebuilt from (pix_rec)
     int *table, *slot_of, *wcount, *wrank, *tile_sums, *err;
     unsigned long long *fbits;
     const unsigned gN = (unsigned)((N + 255) / 256);
     const int NW = (int)gN * 4;                      // 64-candidate words of the first-touch mask
-    PHL_HIP(tmp.get(&ckeys, (size_t)N * d));
+    PHL_HIP(tmp.get(&recs, (size_t)n * rec_words(d) + 4));
     PHL_HIP(tmp.get(&table, cap));
     PHL_HIP(tmp.get(&slot_of, (size_t)N));
     PHL_HIP(tmp.get(&fbits, (size_t)NW));
@@ -495,9 +579,8 @@ int phl_build_device(phl_lattice *lat, const float *ref, int64_t rs, int64_t cs,
     PHL_HIP(hipMemsetAsync(err, 0, sizeof(int), st));
 
     switch (d) {
-#define PHL_CASE(D) case D: launch_elevate<D>(ref, rs, cs, n, sf, ckeys, lat->replay, err, st); break;
-        PHL_CASE(1) PHL_CASE(2) PHL_CASE(3) PHL_CASE(4) PHL_CASE(5) PHL_CASE(6) PHL_CASE(7) PHL_CASE(8)
-        PHL_CASE(9) PHL_CASE(10) PHL_CASE(11) PHL_CASE(12) PHL_CASE(13) PHL_CASE(14) PHL_CASE(15) PHL_CASE(16)
+#define PHL_CASE(D) case D: launch_elevate<D>(ref, rs, cs, n, sf, recs, lat->replay, err, st); break;
+        PHL_FOR_D(PHL_CASE)
 #undef PHL_CASE
         default: phl_set_error("d=%d unsupported (1..%d)", d, PHL_MAX_D); return PHL_ERR_UNSUPPORTED;
     }
@@ -505,10 +588,10 @@ int phl_build_device(phl_lattice *lat, const float *ref, int64_t rs, int64_t cs,
     int rc = PHL_OK;
     for (;;) {
         hipLaunchKernelGGL(k_fill_i32, dim3(2048), dim3(256), 0, st, table, (int64_t)cap, PHL_EMPTY);
-        {
-            const int64_t waves = ((n + 63) / 64) * (d + 1);
-            hipLaunchKernelGGL(k_insert, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, ckeys, d, (int)n, table, mask, slot_of,
-                               cap == cap_full ? 0x7FFFFFFF : 128, err);
+        switch (d) {
+#define PHL_CASE(D) case D: launch_insert<D>(recs, n, table, mask, slot_of, cap == cap_full ? 0x7FFFFFFF : 128, err, st); break;
+            PHL_FOR_D(PHL_CASE)
+#undef PHL_CASE
         }
         hipLaunchKernelGGL(k_flag_bits, dim3(gN), dim3(256), 0, st, table, slot_of, N, fbits, wcount);
         PHL_HIP(hipGetLastError());
@@ -537,7 +620,11 @@ int phl_build_device(phl_lattice *lat, const float *ref, int64_t rs, int64_t cs,
     lat->vfirst = nullptr;
     lat->vfirst_valid_for_M = 0;
     PHL_HIP(phl_dev_malloc((void **)&lat->vfirst, sizeof(int) * ((size_t)M + 1)));
-    hipLaunchKernelGGL(k_assign, dim3(gN), dim3(256), 0, st, fbits, wrank, slot_of, ckeys, d, N, table, lat->vkeys, lat->vfirst);
+    switch (d) {
+#define PHL_CASE(D) case D: launch_assign<D>(fbits, wrank, slot_of, recs, N, table, lat->vkeys, lat->vfirst, st); break;
+        PHL_FOR_D(PHL_CASE)
+#undef PHL_CASE
+    }
     hipLaunchKernelGGL(k_set_vid, dim3(gN), dim3(256), 0, st, table, slot_of, N, lat->replay);
     PHL_HIP(hipGetLastError());
     if (lat->build_flags & PHL_BUILD_REFERENCE_TABLE) {

@@ -48,7 +48,8 @@ def _rand_case(n, d, vd, scale, seed):
 
 CASES = [(64, 2, 1, 3.0), (500, 1, 2, 10.0), (2000, 3, 3, 5.0), (2000, 5, 16, 4.0), (3000, 8, 5, 2.0),
          (4096, 5, 64, 2.0), (1000, 2, 7, 300.0), (5000, 5, 256, 3.0), (20000, 5, 4, 8.0), (3000, 16, 8, 1.0),
-         (7000, 4, 20, 2.5), (60000, 5, 12, 6.0), (1, 5, 4, 1.0), (3, 2, 3, 0.0)]
+         (7000, 4, 20, 2.5), (60000, 5, 12, 6.0), (1, 5, 4, 1.0), (3, 2, 3, 0.0),
+         (2500, 7, 3, 2.0), (1500, 11, 2, 1.5), (1200, 13, 2, 1.0), (2000, 6, 4, 3.0)]   # (record packing at every width)
 
 
 @pytest.mark.parametrize("n,d,vd,scale", CASES)
