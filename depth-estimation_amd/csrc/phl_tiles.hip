@@ -172,124 +172,177 @@ __global__ __launch_bounds__(256) void k_perm_to_contrib(const int *__restrict__
     out[i] = c;
 }
 
-// ---- per-chunk structure: one workgroup sorts the chunk's (vertex, entry) pairs in LDS -----------
-// entry e = k*(d+1)+r of the chunk (k-th pixel in chunk order, remainder r).  After the sort
-// the pairs are grouped by vertex with ascending e, i.e. ascending pixel: exactly the
-// per-vertex segment the splat needs.  WRITE=false only counts the distinct vertices.
-// Sort keys: (vertex id, entry) packed into 32 bits when the lattice has fewer than 2^21 vertices (entry < 2048),
-// else 64 bits.
-template <typename KT> struct sort_key;
-template <> struct sort_key<unsigned> {
-    static __device__ __forceinline__ unsigned make(unsigned vid, unsigned e) { return (vid << 11) | e; }
-    static __device__ __forceinline__ unsigned vid(unsigned k) { return k >> 11; }
-    static __device__ __forceinline__ unsigned entry(unsigned k) { return k & 2047u; }
-    static __device__ __forceinline__ unsigned pad() { return ~0u; }
-};
-template <> struct sort_key<unsigned long long> {
-    static __device__ __forceinline__ unsigned long long make(unsigned vid, unsigned e) { return ((unsigned long long)vid << 32) | e; }
-    static __device__ __forceinline__ unsigned vid(unsigned long long k) { return (unsigned)(k >> 32); }
-    static __device__ __forceinline__ unsigned entry(unsigned long long k) { return (unsigned)k; }
-    static __device__ __forceinline__ unsigned long long pad() { return ~0ull; }
-};
+// ---- per-chunk structure: one workgroup groups the chunk's entries by vertex in LDS ----------------
+// entry e = k*(d+1)+r of the chunk (k-th pixel in chunk order, remainder r).  Wanted: the entries grouped by vertex
+// with ascending e inside a group, i.e. ascending pixel: exactly the per-vertex segment the splat needs.
+//   1. the chunk's distinct vertices get dense ids 0..nv-1 through an LDS hash table (slot order);
+//   2. a STABLE least-significant-digit radix sort of the entries by dense id, four bits a pass -- ceil(log2 nv)/4
+//      passes: two for the ~50-250 local vertices of an image chunk, where a comparison sort of (vertex, entry) keys
+//      took 66 compare-exchange stages.  A thread owns PER consecutive entries; its digit histogram is a packed
+//      64-bit register (sixteen 4-bit counts), the workgroup-wide prefix per (digit, thread) a wavefront scan on DPP
+//      row shifts over four words of four 16-bit fields.
+// WRITE=false only counts the distinct vertices.
+#define PHL_DPP_ADD(x, ctrl, rowmask) x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)(x), ctrl, rowmask, 0xF, false)
+__device__ __forceinline__ unsigned wave_inclusive_scan_u32(unsigned x)
+{
+    PHL_DPP_ADD(x, 0x111, 0xF);     // row_shr:1
+    PHL_DPP_ADD(x, 0x112, 0xF);     // row_shr:2
+    PHL_DPP_ADD(x, 0x114, 0xF);     // row_shr:4
+    PHL_DPP_ADD(x, 0x118, 0xF);     // row_shr:8
+    PHL_DPP_ADD(x, 0x142, 0xA);     // row_bcast:15 into rows 1 and 3
+    PHL_DPP_ADD(x, 0x143, 0xC);     // row_bcast:31 into rows 2 and 3
+    return x;
+}
+#undef PHL_DPP_ADD
 
-template <int SORTN, bool WRITE, typename KT>
-__global__ __launch_bounds__(256) void k_chunk_sort(const int *__restrict__ pix_order, int n, int P, int dp1,
-                                                    const phl_replay_t *__restrict__ replay, int *__restrict__ nv_out,
-                                                    const int *__restrict__ vptr, int stride, int *__restrict__ slot_vert,
-                                                    int2 *__restrict__ seg_rng, phl_contrib_t *__restrict__ seg,
-                                                    unsigned short *__restrict__ lidx)
+template <int SORTN, bool WRITE>
+__global__ __launch_bounds__(256) void k_chunk_group(const int *__restrict__ pix_order, int n, int P, int dp1,
+                                                     const phl_replay_t *__restrict__ replay, int *__restrict__ nv_out,
+                                                     const int *__restrict__ vptr, int stride, int *__restrict__ slot_vert,
+                                                     int2 *__restrict__ seg_rng, phl_contrib_t *__restrict__ seg,
+                                                     unsigned short *__restrict__ lidx)
 {
     // vptr != null: slots go to their final place vptr[c] + local index.  vptr == null (first and
     // normally only pass): slots go to a scratch area with a fixed `stride` per chunk (local indices
     // beyond it are dropped -- the host then repeats the pass with the real offsets), and the number of
     // local vertices is reported in nv_out.
-    using SK = sort_key<KT>;
-    __shared__ KT keys[SORTN];
-    constexpr int PER = SORTN / 256;       // consecutive elements owned by a thread in the register stages
+    constexpr int PER = SORTN / 256;       // consecutive entries owned by a thread
+    constexpr int HT = 2 * SORTN;          // hash slots (load <= 1/2)
+    constexpr int HB = SORTN == 2048 ? 12 : (SORTN == 1024 ? 11 : 10);
+    static_assert(PER <= 8, "the per-thread digit histogram has 4-bit counts");
+    __shared__ unsigned keys[SORTN];       // (dense id << 11) | entry
+    __shared__ int tab[HT + 8];            // slot -> vertex id, then slot -> dense id; later hpos | newidx
+    __shared__ int lvid[SORTN];            // dense id -> vertex id
+    __shared__ unsigned wtot[4][8];
+    __shared__ int lbin[258];              // histogram over segment lengths 1..P (P <= 256)
     const int c = blockIdx.x;
     const int base = c * P;
     const int cnt = min(P, n - base);
     const int E = cnt * dp1;
     const int i0 = threadIdx.x * PER;
-    // Bitonic sort.  Compare-exchange distances below PER stay inside one thread's PER consecutive elements:
-    // those sub-stages run in registers (no LDS traffic, no barrier); only distances >= PER go through LDS.
-    KT r[PER];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int j = threadIdx.x; j < HT; j += 256) tab[j] = -1;
+    int vid[PER];
 #pragma unroll
     for (int u = 0; u < PER; u++) {
         const int e = i0 + u;
-        KT key = SK::pad();
+        vid[u] = -1;
         if (e < E) {
             const int k = e / dp1, rr = e - k * dp1;
             const int p = pix_order[base + k];
-            key = SK::make((unsigned)replay[(int64_t)p * dp1 + rr].vid, (unsigned)e);
+            vid[u] = replay[(int64_t)p * dp1 + rr].vid;
         }
-        r[u] = key;
     }
-    auto cmpx = [](KT &a, KT &b, bool up) {
-        if ((a > b) == up) { const KT t = a; a = b; b = t; }
-    };
-#pragma unroll
-    for (int k = 2; k <= PER; k <<= 1)                 // levels entirely inside a thread
-#pragma unroll
-        for (int j = k >> 1; j > 0; j >>= 1)
-#pragma unroll
-            for (int u = 0; u < PER; u++)
-                if ((u ^ j) > u) cmpx(r[u], r[u ^ j], ((i0 + u) & k) == 0);
-#pragma unroll
-    for (int u = 0; u < PER; u++) keys[i0 + u] = r[u];
     __syncthreads();
-    for (int k = 2 * PER; k <= SORTN; k <<= 1) {
-        for (int j = k >> 1; j >= PER; j >>= 1) {      // distances that cross threads: through LDS
-            for (int i = threadIdx.x; i < SORTN; i += 256) {
-                const int ixj = i ^ j;
-                if (ixj > i) {
-                    const KT a = keys[i], b = keys[ixj];
-                    const bool up = (i & k) == 0;
-                    if ((a > b) == up) { keys[i] = b; keys[ixj] = a; }
-                }
-            }
-            __syncthreads();
-        }
-        const bool up = (i0 & k) == 0;                 // the thread's whole run lies in one half of the k-block
-#pragma unroll
-        for (int u = 0; u < PER; u++) r[u] = keys[i0 + u];
-#pragma unroll
-        for (int j = PER >> 1; j > 0; j >>= 1)
-#pragma unroll
-            for (int u = 0; u < PER; u++)
-                if ((u ^ j) > u) cmpx(r[u], r[u ^ j], up);
-#pragma unroll
-        for (int u = 0; u < PER; u++) keys[i0 + u] = r[u];
-        __syncthreads();
-    }
-    // heads = first entry of each distinct vertex; local vertex index = (#heads up to here) - 1
-    int heads = 0;
+    int slot[PER];
 #pragma unroll
     for (int u = 0; u < PER; u++) {
-        const int i = i0 + u;
-        if (i < E && (i == 0 || SK::vid(keys[i]) != SK::vid(keys[i - 1]))) heads++;
+        slot[u] = 0;
+        if (vid[u] >= 0) {
+            unsigned h = ((unsigned)vid[u] * 2654435761u) >> (32 - HB);
+            for (;;) {
+                const int prev = atomicCAS(&tab[h], -1, vid[u]);
+                if (prev == -1 || prev == vid[u]) break;
+                h = (h + 1) & (HT - 1);
+            }
+            slot[u] = (int)h;
+        }
     }
-    int total;
-    int li = block_exclusive_scan(heads, &total) - 1;
-    if (nv_out && threadIdx.x == 0) nv_out[c] = total;
+    __syncthreads();
+    int nv;
+    {
+        constexpr int SPT = HT / 256;      // slots owned by a thread
+        int occ = 0;
+#pragma unroll
+        for (int j = 0; j < SPT; j++) occ += tab[threadIdx.x * SPT + j] >= 0 ? 1 : 0;
+        int id = block_exclusive_scan(occ, &nv);
+#pragma unroll
+        for (int j = 0; j < SPT; j++) {
+            const int sidx = threadIdx.x * SPT + j;
+            const int v = tab[sidx];
+            if (v >= 0) {
+                lvid[id] = v;
+                tab[sidx] = id++;
+            }
+        }
+    }
+    __syncthreads();
+    if (nv_out && threadIdx.x == 0) nv_out[c] = nv;
     if (!WRITE) return;
+    unsigned r[PER];
+#pragma unroll
+    for (int u = 0; u < PER; u++) r[u] = vid[u] >= 0 ? (((unsigned)tab[slot[u]] << 11) | (unsigned)(i0 + u)) : ~0u;
+    const int bits = nv > 1 ? 32 - __clz(nv - 1) : 0;
+    for (int sh = 11; sh < 11 + bits; sh += 4) {
+        // digit histogram of the thread's entries (4-bit counts) and every entry's rank among the thread's equal digits
+        unsigned long long hist = 0;
+        int lr[PER], dg[PER];
+#pragma unroll
+        for (int u = 0; u < PER; u++) {
+            dg[u] = (int)((r[u] >> sh) & 15u);
+            lr[u] = (int)((hist >> (4 * dg[u])) & 15ull);
+            if (r[u] != ~0u) hist += 1ull << (4 * dg[u]);
+        }
+        // eight words of two 16-bit counts (digits 2j, 2j+1); inclusive scan over the workgroup's threads
+        unsigned own[8], inc[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const unsigned x = (unsigned)(hist >> (8 * j)) & 0xFFu;
+            own[j] = (x & 15u) | ((x >> 4) << 16);
+            inc[j] = wave_inclusive_scan_u32(own[j]);
+        }
+        if (lane == 63)                                   // (the previous pass's reads of wtot lie behind its last barrier)
+#pragma unroll
+            for (int j = 0; j < 8; j++) wtot[wv][j] = inc[j];
+        __syncthreads();
+        unsigned pos[8];
+        unsigned run = 0;                                 // exclusive scan over the digits (counts < 2^16)
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            unsigned before = 0, tot = 0;
+#pragma unroll
+            for (int w2 = 0; w2 < 4; w2++) {
+                const unsigned t = wtot[w2][j];
+                tot += t;
+                if (w2 < wv) before += t;
+            }
+            const unsigned lo = run, hi = run + (tot & 0xFFFFu);
+            run = hi + (tot >> 16);
+            pos[j] = (inc[j] - own[j]) + before + (lo | (hi << 16));
+        }
+#pragma unroll
+        for (int u = 0; u < PER; u++) {
+            if (r[u] == ~0u) continue;
+            unsigned q = pos[0];
+#pragma unroll
+            for (int j = 1; j < 8; j++) q = (dg[u] >> 1) == j ? pos[j] : q;
+            const int rank = (int)((q >> (16 * (dg[u] & 1))) & 0xFFFFu) + lr[u];
+            keys[rank] = r[u];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < PER; u++) r[u] = (i0 + u) < E ? keys[i0 + u] : ~0u;
+    }
+    if (bits == 0) {
+#pragma unroll
+        for (int u = 0; u < PER; u++)
+            if (i0 + u < E) keys[i0 + u] = r[u];
+    }
+    __syncthreads();                                      // (tab is dead from here: hpos | newidx take its place)
     // Local vertices are renumbered by DESCENDING segment length (counting sort in LDS): the
     // splat kernel hands neighbouring local vertices to the lane groups of one wavefront, which
     // then run loops of nearly equal length, and takes groups longest-first.
-    __shared__ int hpos[SORTN + 1];   // start position of the segment of vid-order vertex j
-    __shared__ int newidx[SORTN];     // vid-order index -> length-order index
-    __shared__ int lbin[258];         // histogram over segment lengths 1..P (P <= 256)
+    int *hpos = tab;                       // [nv + 1] start position of the segment of dense id j
+    int *newidx = tab + SORTN + 1;         // [nv] dense id -> length-order index
+    const int total = nv;
     const int64_t vbase = vptr ? (int64_t)vptr[c] : (int64_t)c * stride;
     const int vcap = vptr ? SORTN : stride;
     const int64_t ebase = (int64_t)base * dp1;
     for (int j = threadIdx.x; j < 258; j += 256) lbin[j] = 0;
-    {
-        int lj = li;
 #pragma unroll
-        for (int u = 0; u < PER; u++) {
-            const int i = i0 + u;
-            if (i < E && (i == 0 || SK::vid(keys[i]) != SK::vid(keys[i - 1]))) hpos[++lj] = i;
-        }
+    for (int u = 0; u < PER; u++) {
+        const int i = i0 + u;
+        if (i < E && (i == 0 || (keys[i] >> 11) != (keys[i - 1] >> 11))) hpos[keys[i] >> 11] = i;
     }
     if (threadIdx.x == 0) hpos[total] = E;
     __syncthreads();
@@ -318,23 +371,20 @@ __global__ __launch_bounds__(256) void k_chunk_sort(const int *__restrict__ pix_
     for (int u = 0; u < PER; u++) {
         const int i = i0 + u;
         if (i >= E) break;
-        const unsigned vid = SK::vid(keys[i]);
-        const int e = (int)SK::entry(keys[i]);
-        const bool head = (i == 0) || vid != SK::vid(keys[i - 1]);
-        if (head) {
-            li++;
-            if (newidx[li] < vcap) {
-                const int64_t slot = vbase + newidx[li];
-                slot_vert[slot] = (int)vid;
-                seg_rng[slot] = make_int2((int)(ebase + i), (int)(ebase + hpos[li + 1]));
-            }
+        const int li = (int)(keys[i] >> 11);
+        const int e = (int)(keys[i] & 2047u);
+        const bool head = (i == 0) || li != (int)(keys[i - 1] >> 11);
+        if (head && newidx[li] < vcap) {
+            const int64_t sl = vbase + newidx[li];
+            slot_vert[sl] = lvid[li];
+            seg_rng[sl] = make_int2((int)(ebase + i), (int)(ebase + hpos[li + 1]));
         }
-        const int k = e / dp1, r = e - k * dp1;
+        const int k = e / dp1, rr = e - k * dp1;
         const int p = pix_order[base + k];
-        phl_contrib_t s;
-        s.pixel = k;
-        s.w = replay[(int64_t)p * dp1 + r].w;
-        seg[ebase + i] = s;
+        phl_contrib_t sg;
+        sg.pixel = k;
+        sg.w = replay[(int64_t)p * dp1 + rr].w;
+        seg[ebase + i] = sg;
         lidx[ebase + e] = (unsigned short)newidx[li];
     }
 }
@@ -499,7 +549,7 @@ __global__ __launch_bounds__(TPB_S) void k_splat_tiled(const float *__restrict__
         // destination: the vertex row (bit 31 set) if this chunk is the vertex's only contributor, else a partial row
         const int sv = slot_vert[vbase + i];
         meta[i] = make_int2((int)(rg.x - ebase) | ((int)(rg.y - ebase) << 16), sv < 0 ? sv : slot_pidx[vbase + i]);
-        // Local vertices come in descending segment length (k_chunk_sort), so the LONG ones (>= long_seg entries:
+        // Local vertices come in descending segment length (k_chunk_group), so the LONG ones (>= long_seg entries:
         // summed by a whole wavefront, below) are a prefix; its length is written by exactly one thread.
         const bool lng = rg.y - rg.x >= long_seg;
         if (i + 1 < nv) {
@@ -548,7 +598,7 @@ __global__ __launch_bounds__(TPB_S) void k_splat_tiled(const float *__restrict__
         }
         // Each of the wavefront's Q lane groups sums ONE local vertex (its pixel-sorted segment,
         // sequentially, out of LDS).  Local vertices are numbered by descending segment length
-        // (k_chunk_sort), so the Q vertices of a group have nearly equal loops, and the waves take
+        // (k_chunk_group), so the Q vertices of a group have nearly equal loops, and the waves take
         // groups longest-first from a shared counter: no cross-lane combine, no padding, and the
         // per-vertex bookkeeping is paid once per Q vertices.
         for (int set = 0; set < nsets; set++) {
@@ -1828,18 +1878,13 @@ int phl_tiles_build(phl_lattice *lat, const float *ref, int64_t rs, int64_t cs, 
     int *nv;
     PHL_HIP(tmp.get(&nv, (size_t)nchunks + 1));
     PHL_HIP(phl_dev_malloc((void **)&lat->chunk_vptr, sizeof(int) * ((size_t)nchunks + 1)));
-    static const bool force64 = getenv("PHL_SORT_KEY64") != nullptr;       // tests: take the wide-key kernels on small inputs
-    const bool key32 = lat->M < (1 << 21) && !force64;                     // (vertex id, entry < 2048) fits 32 bits
-#define PHL_CHUNK_SORT_K(WRITE_, KT_, ...)                                                                                    \
-    switch (sortn) {                                                                                                          \
-        case 512: hipLaunchKernelGGL((k_chunk_sort<512, WRITE_, KT_>), dim3(nchunks), dim3(256), 0, st, __VA_ARGS__); break;   \
-        case 1024: hipLaunchKernelGGL((k_chunk_sort<1024, WRITE_, KT_>), dim3(nchunks), dim3(256), 0, st, __VA_ARGS__); break; \
-        default: hipLaunchKernelGGL((k_chunk_sort<2048, WRITE_, KT_>), dim3(nchunks), dim3(256), 0, st, __VA_ARGS__); break;   \
+#define PHL_CHUNK_SORT(WRITE_, ...)                                                                                      \
+    switch (sortn) {                                                                                                      \
+        case 512: hipLaunchKernelGGL((k_chunk_group<512, WRITE_>), dim3(nchunks), dim3(256), 0, st, __VA_ARGS__); break;   \
+        case 1024: hipLaunchKernelGGL((k_chunk_group<1024, WRITE_>), dim3(nchunks), dim3(256), 0, st, __VA_ARGS__); break; \
+        default: hipLaunchKernelGGL((k_chunk_group<2048, WRITE_>), dim3(nchunks), dim3(256), 0, st, __VA_ARGS__); break;   \
     }
-#define PHL_CHUNK_SORT(WRITE_, ...)                                            \
-    if (key32) { PHL_CHUNK_SORT_K(WRITE_, unsigned, __VA_ARGS__) }             \
-    else { PHL_CHUNK_SORT_K(WRITE_, unsigned long long, __VA_ARGS__) }
-    // One sort pass: segments and local indices go to their final arrays, the per-chunk slot records to a
+    // One grouping pass: segments and local indices go to their final arrays, the per-chunk slot records to a
     // scratch area with a fixed stride; they are compacted once the chunk offsets are known.  Only when a
     // chunk has more local vertices than the stride (pixels that share next to nothing) the pass is repeated.
     constexpr int SLOT_STRIDE = 384;
@@ -1888,7 +1933,6 @@ int phl_tiles_build(phl_lattice *lat, const float *ref, int64_t rs, int64_t cs, 
                        lat->seg_rng, lat->seg, lat->lidx)
     }
 #undef PHL_CHUNK_SORT
-#undef PHL_CHUNK_SORT_K
     PHL_HIP(hipGetLastError());
     PHL_HIP(hipStreamSynchronize(st));
     }

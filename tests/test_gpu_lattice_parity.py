@@ -532,32 +532,28 @@ def test_more_than_two_million_vertices(phl):
         assert np.array_equal(out.view(np.uint32), want.view(np.uint32)), no_tiles
 
 
-def test_wide_sort_keys_give_the_same_chunks():
-    """The 64-bit-key chunk sort (lattices with >= 2^21 vertices) forced on a small shared lattice in a fresh
-    process: the LDS-staged filter must still match the CPU restatement."""
-    import subprocess
-    import sys
+def test_chunk_grouping_with_one_to_three_digit_passes(phl):
+    """k_chunk_group sorts a chunk's entries by dense local vertex id, four bits a pass: chunks with 1, <= 16, <= 256
+    and > 256 distinct vertices (0 ... 3 passes) in the LDS-staged filter against the CPU restatement."""
+    from oracle import phl_oracle as po
 
-    code = (
-        "import os, sys, numpy as np, torch\n"
-        "root = sys.argv[1]\n"
-        "sys.path[:0] = [os.path.join(root, 'depth-estimation_amd'), root]\n"
-        "import phl\n"
-        "from oracle import phl_oracle as po\n"
-        "rng = np.random.default_rng(3)\n"
-        "ref = np.cumsum(rng.random((9000, 5), dtype=np.float32) * 0.03, axis=0).astype(np.float32)\n"
-        "src = rng.random((9000, 64), dtype=np.float32)\n"
-        "L = phl.Lattice(torch.from_numpy(ref).cuda())\n"
-        "st = L.tile_stats(64)\n"
-        "assert st['staged_splat'] == 1 and st['staged_slice'] == 1, st\n"
-        "want = po.Oracle(ref).filter(src)\n"
-        "got = L.filter(torch.from_numpy(src).cuda()).cpu().numpy()\n"
-        "assert np.abs(got - want).max() <= 1e-5 * np.abs(want).max()\n"
-        "print('ok')\n")
-    env = dict(os.environ, PHL_SORT_KEY64="1")
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, "-c", code, root], env=env, capture_output=True, text=True, timeout=300)
-    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
+    rng = np.random.default_rng(3)
+    n = 4096
+    for name, ref in (
+        ("one simplex", np.full((n, 5), 0.37, np.float32) + rng.random((n, 5), dtype=np.float32) * 1e-4),
+        ("a few vertices", np.cumsum(rng.random((n, 5), dtype=np.float32) * 0.002, axis=0).astype(np.float32)),
+        ("image-like", np.cumsum(rng.random((n, 5), dtype=np.float32) * 0.03, axis=0).astype(np.float32)),
+        ("iid", (rng.random((n, 5), dtype=np.float32) * 40).astype(np.float32)),
+    ):
+        src = rng.random((n, 16), dtype=np.float32)
+        L = phl.Lattice(torch.from_numpy(ref).cuda())
+        st = L.tile_stats(16)
+        want = po.Oracle(ref).filter(src)
+        got = L.filter(torch.from_numpy(src).cuda()).cpu().numpy()
+        assert np.abs(got - want).max() <= 1e-5 * np.abs(want).max(), (name, st)
+        exact = L.filter(torch.from_numpy(src).cuda(), exact=True).cpu().numpy()
+        assert np.array_equal(exact.view(np.uint32), want.view(np.uint32)), (name, st)
+        print(name, st)
 
 
 def test_filter_is_graph_capturable(phl):
