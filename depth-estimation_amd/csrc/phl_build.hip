@@ -329,45 +329,114 @@ __global__ __launch_bounds__(256) void k_fill_sorted(const phl_replay_t *__restr
     csr[i] = c;
 }
 
+// Vertex keys as packed words (two shorts a word, rows padded to a vector load: 16 bytes for d = 5..8): a key
+// comparison in the neighbour search is one divergent load instead of d two-byte loads.
+template <int D>
+struct packed_key {
+    static constexpr int KW = (D + 1) / 2;
+    static constexpr int PW = KW == 3 ? 4 : KW;          // row stride in words
+    static __device__ __forceinline__ void load(const uint32_t *__restrict__ p, uint32_t (&w)[KW])
+    {
+        if constexpr (PW == 4) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(p);
+            w[0] = v.x; w[1] = v.y; w[2] = v.z;
+            if constexpr (KW == 4) w[3] = v.w;
+        } else if constexpr (PW == 2) {
+            const uint2 v = *reinterpret_cast<const uint2 *>(p);
+            w[0] = v.x; w[1] = v.y;
+        } else {
+#pragma unroll
+            for (int j = 0; j < KW; j++) w[j] = p[j];
+        }
+    }
+};
+
+template <int D>
+__global__ __launch_bounds__(256) void k_pack_keys(const int16_t *__restrict__ vkeys, int M, uint32_t *__restrict__ out)
+{
+    using K = packed_key<D>;
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= M) return;
+    uint32_t w[K::PW];
+#pragma unroll
+    for (int j = 0; j < K::PW; j++) w[j] = 0u;
+#pragma unroll
+    for (int i = 0; i < D; i++) w[i >> 1] |= (uint32_t)(uint16_t)vkeys[(int64_t)v * D + i] << (16 * (i & 1));
+#pragma unroll
+    for (int j = 0; j < K::PW; j++) out[(int64_t)v * K::PW + j] = w[j];
+}
+
 // Thread per (axis, vertex): neighbour keys are key +- 1 in every stored coordinate, with
 // coordinate `axis` set to key[axis] -+ d; for axis == d the touched coordinate is the implied
 // (d+1)-th one, i.e. all d stored coordinates move by +-1 (permutohedral.h:504-509).
-__global__ __launch_bounds__(256) void k_neighbors(const int16_t *__restrict__ vkeys, int d, int M,
+// The two sides' probe sequences run interleaved (two independent chains of dependent loads in flight).
+template <int D>
+__global__ __launch_bounds__(256) void k_neighbors(const uint32_t *__restrict__ vkp, int M,
                                                    const int *__restrict__ table, uint32_t mask,
                                                    int *__restrict__ nbr)
 {
+    using K = packed_key<D>;
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (int64_t)M * (d + 1)) return;
+    if (idx >= (int64_t)M * (D + 1)) return;
     const int axis = (int)(idx / M);
     const int v = (int)(idx - (int64_t)axis * M);
-    const int16_t *key = vkeys + (int64_t)v * d;
-    int res[2];
+    uint32_t own[K::KW];
+    K::load(vkp + (int64_t)v * K::PW, own);
+    uint32_t want[2][K::KW];
+    uint32_t h[2];
+#pragma unroll
     for (int side = 0; side < 2; side++) {
         const int step = side == 0 ? 1 : -1;  // side 0 = neighbor1 (vm1), side 1 = neighbor2 (vp1)
-        uint32_t h = mix_begin();
-        for (int i = 0; i < d; i++) {
-            int c = (i == axis) ? key[i] - step * d : key[i] + step;
-            h = mix_step(h, (int16_t)c);
+#pragma unroll
+        for (int j = 0; j < K::KW; j++) want[side][j] = 0u;
+        uint32_t hh = mix_begin();
+#pragma unroll
+        for (int i = 0; i < D; i++) {
+            const int k = (int)(int16_t)(uint16_t)(own[i >> 1] >> (16 * (i & 1)));
+            const int c = (i == axis) ? k - step * D : k + step;
+            hh = mix_step(hh, (int16_t)c);
+            want[side][i >> 1] |= (uint32_t)(uint16_t)(int16_t)c << (16 * (i & 1));
         }
-        h = mix_end(h) & mask;
-        int found = -1;
-        for (;;) {
-            const int t = table[h];
-            if (t == PHL_EMPTY) break;
-            const int vid = -(t + 1);
-            const int16_t *other = vkeys + (int64_t)vid * d;
+        h[side] = mix_end(hh) & mask;
+    }
+    int res[2] = {-1, -1};
+    bool open[2] = {true, true};
+    while (open[0] || open[1]) {
+        int t[2];
+#pragma unroll
+        for (int side = 0; side < 2; side++) t[side] = open[side] ? table[h[side]] : PHL_EMPTY;
+        uint32_t other[2][K::KW];
+#pragma unroll
+        for (int side = 0; side < 2; side++) {
+            if (t[side] == PHL_EMPTY) { open[side] = false; continue; }
+            K::load(vkp + (int64_t)(-(t[side] + 1)) * K::PW, other[side]);
+        }
+#pragma unroll
+        for (int side = 0; side < 2; side++) {
+            if (!open[side]) continue;
             bool same = true;
-            for (int i = 0; i < d; i++) {
-                int c = (i == axis) ? key[i] - step * d : key[i] + step;
-                same &= (other[i] == (int16_t)c);
-            }
-            if (same) { found = vid; break; }
-            h = (h + 1) & mask;
+#pragma unroll
+            for (int j = 0; j < K::KW; j++) same &= (other[side][j] == want[side][j]);
+            if (same) { res[side] = -(t[side] + 1); open[side] = false; }
+            else h[side] = (h[side] + 1) & mask;
         }
-        res[side] = found;
     }
     nbr[idx * 2 + 0] = res[0];
     nbr[idx * 2 + 1] = res[1];
+}
+
+template <int D>
+int launch_neighbors(const int16_t *vkeys, int M, const int *table, uint32_t mask, int *nbr, void **scratch_out, hipStream_t st)
+{
+    using K = packed_key<D>;
+    uint32_t *vkp;
+    PHL_HIP(phl_dev_malloc((void **)&vkp, sizeof(uint32_t) * ((size_t)M * K::PW + 4)));
+    *scratch_out = vkp;
+    hipLaunchKernelGGL(k_pack_keys<D>, dim3((M + 255) / 256), dim3(256), 0, st, vkeys, M, vkp);
+    const int64_t tot = (int64_t)M * (D + 1);
+    hipLaunchKernelGGL(k_neighbors<D>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, vkp, M, table, mask, nbr);
+    PHL_HIP(hipGetLastError());
+    return PHL_OK;
 }
 
 // Neighbour ids for blurring along axes a = 2p and b = 2p+1 in ONE pass (k_blur2):
@@ -490,8 +559,11 @@ __global__ void k_override_nbr00(int *nbr, const int *__restrict__ int_of_ft, in
 }  // namespace
 
 // Persistent compact table (capacity >= 2M) + blur neighbour ids for ALL current vertices.
-int phl_rebuild_table_and_neighbors(phl_lattice *lat, hipStream_t st)
+// *scratch_out: a device block the launches read (packed keys); the caller releases it with phl_dev_free once the
+// stream has been synchronised (the block cache may hand a freed block to another thread's build at once).
+int phl_rebuild_table_and_neighbors(phl_lattice *lat, hipStream_t st, void **scratch_out)
 {
+    *scratch_out = nullptr;
     const int d = lat->d;
     const int M = (int)lat->M;
     if (lat->table) PHL_HIP(phl_dev_free(lat->table));
@@ -512,9 +584,13 @@ int phl_rebuild_table_and_neighbors(phl_lattice *lat, hipStream_t st)
         for (int i = 0; i < lat->n_hidden; i++) hidden.id[i] = lat->hidden[i];
         hipLaunchKernelGGL(k_table_insert, dim3((M + 255) / 256), dim3(256), 0, st, lat->vkeys, d, M, lat->table,
                            lat->table_mask, hidden, lat->int_of_ft);
-        const int64_t tot = (int64_t)M * (d + 1);
-        hipLaunchKernelGGL(k_neighbors, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, lat->vkeys, d, M,
-                           lat->table, lat->table_mask, lat->nbr);
+        int rcn = PHL_OK;
+        switch (d) {
+#define PHL_CASE(D) case D: rcn = launch_neighbors<D>(lat->vkeys, M, lat->table, lat->table_mask, lat->nbr, scratch_out, st); break;
+            PHL_FOR_D(PHL_CASE)
+#undef PHL_CASE
+        }
+        if (rcn) return rcn;
         if (lat->nbr00_override != -2)    // a table doubling inside the reference's blur(): phl_reftable.hip
             hipLaunchKernelGGL(k_override_nbr00, dim3(1), dim3(1), 0, st, lat->nbr, lat->int_of_ft, lat->nbr00_override);
         const int npairs = (d + 1) / 2;
@@ -690,6 +766,7 @@ int phl_ensure_csr(phl_lattice *lat, hipStream_t st)
 // distinct.  Used by the row-band multi-GPU path; rebuilds the table and the neighbour ids.
 int phl_add_vertices_device(phl_lattice *lat, const int16_t *keys_host, int64_t count, int32_t *vid_host, hipStream_t st)
 {
+    void *nbr_scratch = nullptr;
     if (count == 0) return PHL_OK;
     const int d = lat->d;
     const int K = (int)count;
@@ -745,11 +822,12 @@ int phl_add_vertices_device(phl_lattice *lat, const int16_t *keys_host, int64_t 
         lat->csr = nullptr;
         lat->vkeys = vkeys_new;
         lat->M = M_new;
-        rc = phl_rebuild_table_and_neighbors(lat, st);
+        rc = phl_rebuild_table_and_neighbors(lat, st, &nbr_scratch);
         if (rc) return rc;
         // (the value workspaces are sized by M: phl_add_vertices drops them)
     }
     PHL_HIP(hipMemcpyAsync(vid_host, vid, sizeof(int32_t) * (size_t)K, hipMemcpyDeviceToHost, st));
     PHL_HIP(hipStreamSynchronize(st));
+    if (nbr_scratch) PHL_HIP(phl_dev_free(nbr_scratch));
     return PHL_OK;
 }

@@ -161,7 +161,7 @@ int phl_ensure_csr(phl_lattice *lat, hipStream_t st);  // pixel-sorted lists, bu
 namespace std { class mutex; }
 std::mutex *phl_csr_mutex(phl_lattice *lat);
 int phl_add_vertices_device(phl_lattice *lat, const int16_t *keys_host, int64_t count, int32_t *vid_host, hipStream_t st);
-int phl_rebuild_table_and_neighbors(phl_lattice *lat, hipStream_t st);
+int phl_rebuild_table_and_neighbors(phl_lattice *lat, hipStream_t st, void **scratch_out);
 
 // ---- implemented in phl_tiles.hip ----
 int phl_tiles_build(phl_lattice *lat, const float *ref, int64_t rs, int64_t cs, hipStream_t st);   // + renumbering, tables

@@ -1761,8 +1761,11 @@ int phl_tiles_build(phl_lattice *lat, const float *ref, int64_t rs, int64_t cs, 
     }
     lat->P = P;
     if (n == 0) {
-        const int rc0 = phl_rebuild_table_and_neighbors(lat, st);
-        return rc0 ? rc0 : phl_tiles_link_vertices(lat, st);
+        void *scratch = nullptr;
+        const int rc0 = phl_rebuild_table_and_neighbors(lat, st, &scratch);
+        const int rc1 = rc0 ? rc0 : phl_tiles_link_vertices(lat, st);      // (synchronises the stream)
+        if (scratch) { (void)hipStreamSynchronize(st); (void)phl_dev_free(scratch); }
+        return rc1;
     }
     int sortn = 512;
     while (sortn < P * dp1) sortn <<= 1;
@@ -1774,7 +1777,7 @@ int phl_tiles_build(phl_lattice *lat, const float *ref, int64_t rs, int64_t cs, 
     // arrays replaced while launches that read them may still be in flight: released only behind the stream
     // synchronisation at the end of this phase (the block cache may hand a freed block to another thread's build)
     struct deferred_t {
-        void *p[2] = {nullptr, nullptr};
+        void *p[3] = {nullptr, nullptr, nullptr};
         ~deferred_t() { for (void *q : p) if (q) (void)phl_dev_free(q); }
     } deferred;
     {   // temporaries of the chunk build go back to the scratch cache before the vertex lists are linked
@@ -1868,7 +1871,7 @@ int phl_tiles_build(phl_lattice *lat, const float *ref, int64_t rs, int64_t cs, 
         }
         deferred.p[1] = lat->vfirst;                 // build-time only
         lat->vfirst = nullptr;
-        rc = phl_rebuild_table_and_neighbors(lat, st);
+        rc = phl_rebuild_table_and_neighbors(lat, st, &deferred.p[2]);
         if (rc) return rc;
     }
 
