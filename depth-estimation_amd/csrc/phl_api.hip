@@ -286,6 +286,47 @@ int g_scratch_dev = -1;
 bool g_scratch_busy = false;
 }  // namespace
 
+namespace {
+struct pinned_arena {
+    char *base = nullptr;
+    size_t cap = 0, off = 0, wanted = 0;
+};
+thread_local pinned_arena t_pinned;     // (never freed: a thread's exit may come after the runtime has shut down)
+}  // namespace
+
+void phl_pinned_reset()
+{
+    pinned_arena &a = t_pinned;
+    if (a.wanted > a.cap || !a.base) {
+        size_t want = a.wanted > ((size_t)1 << 20) ? a.wanted + (a.wanted >> 2) : ((size_t)1 << 20);
+        if (want <= ((size_t)256 << 20)) {
+            if (a.base) (void)hipHostFree(a.base);
+            a.base = nullptr;
+            a.cap = 0;
+            void *p = nullptr;
+            if (hipHostMalloc(&p, want, hipHostMallocMapped) == hipSuccess) {
+                a.base = (char *)p;
+                a.cap = want;
+            } else {
+                (void)hipGetLastError();
+            }
+        }
+    }
+    a.off = 0;
+    a.wanted = 0;
+}
+
+void *phl_pinned_alloc(size_t bytes)
+{
+    pinned_arena &a = t_pinned;
+    bytes = (bytes + 255) & ~(size_t)255;
+    a.wanted += bytes;
+    if (!a.base || a.off + bytes > a.cap) return nullptr;
+    void *p = a.base + a.off;
+    a.off += bytes;
+    return p;
+}
+
 bool phl_scratch_acquire(void **base, size_t *cap)
 {
     std::lock_guard<std::mutex> lk(g_scratch_mu);

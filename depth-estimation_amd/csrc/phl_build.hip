@@ -21,6 +21,7 @@
 // The whole translation unit is compiled with -ffp-contract=off: elevate must round exactly
 // like the reference's scalar C++ (mul and add separately) so that keys, ranks and weights
 // are bit-identical to the CPU path.
+#include <cstring>
 #include <mutex>
 
 #include "phl_device_utils.h"
@@ -82,13 +83,38 @@ struct pix_rec {
 template <int D>
 __global__ __launch_bounds__(256) void k_elevate(const float *__restrict__ ref, int64_t rs, int64_t cs, int64_t n,
                                                  sf_t sf, uint32_t *__restrict__ recs,
-                                                 phl_replay_t *__restrict__ replay, int *__restrict__ err)
+                                                 phl_replay_t *__restrict__ replay, int *__restrict__ err,
+                                                 float *__restrict__ mm /* [grid][D][2] feature ranges of the block */)
 {
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= n) return;
+    const bool live = p < n;
     float pos[D];
 #pragma unroll
-    for (int i = 0; i < D; i++) pos[i] = ref[p * rs + i * cs];
+    for (int i = 0; i < D; i++) pos[i] = live ? ref[p * rs + i * cs] : 0.f;
+    {   // feature ranges (the chunk grid of phl_tiles_build is laid over the two widest features): the values are in
+        // registers here, a second pass over `ref` would read them again
+        __shared__ float smin[4][D], smax[4][D];
+        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+        for (int i = 0; i < D; i++) {
+            float a = live ? pos[i] : INFINITY, b = live ? pos[i] : -INFINITY;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                a = fminf(a, __shfl_xor(a, o));
+                b = fmaxf(b, __shfl_xor(b, o));
+            }
+            if (lane == 0) { smin[w][i] = a; smax[w][i] = b; }
+        }
+        __syncthreads();
+        if ((int)threadIdx.x < D) {
+            float a = smin[0][threadIdx.x], b = smax[0][threadIdx.x];
+#pragma unroll
+            for (int k = 1; k < 4; k++) { a = fminf(a, smin[k][threadIdx.x]); b = fmaxf(b, smax[k][threadIdx.x]); }
+            mm[((int64_t)blockIdx.x * D + threadIdx.x) * 2 + 0] = a;
+            mm[((int64_t)blockIdx.x * D + threadIdx.x) * 2 + 1] = b;
+        }
+    }
+    if (!live) return;
 
     // permutohedral.h:380-384 (expression order kept)
     float el[D + 1];
@@ -260,31 +286,39 @@ __global__ __launch_bounds__(256) void k_insert(const uint32_t *__restrict__ rec
     if (active) slot_of[e] = slot;
 }
 
-// First-touch flags as a bit mask: bit e is set iff candidate e is the representative (smallest index) of its key;
-// wcount[w] = set bits of word w.  The vertex id of a representative is its rank among the set bits, i.e. the scan of
-// the N / 64 word counts plus a popcount -- not a scan over all N candidates.
-__global__ __launch_bounds__(256) void k_flag_bits(const int *__restrict__ table, const int *__restrict__ slot_of, int N,
-                                                   unsigned long long *__restrict__ bits, int *__restrict__ wcount)
+// First-touch flags as a bit mask: bit e is set iff candidate e is the representative (smallest index) of its key,
+// i.e. iff some table slot holds e -- set from the table (one coalesced pass over the slots, a few hundred thousand
+// atomics) rather than by asking for every candidate.  The vertex id of a representative is its rank among the set
+// bits: the scan of the N / 64 word counts plus a popcount -- not a scan over all N candidates.
+__global__ __launch_bounds__(256) void k_flag_bits(const int *__restrict__ table, int64_t cap, unsigned long long *__restrict__ bits)
 {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool f = e < N && table[slot_of[e]] == e;
-    const unsigned long long m = __ballot(f);
-    if ((threadIdx.x & 63) == 0) {
-        bits[e >> 6] = m;
-        wcount[e >> 6] = __popcll(m);
-    }
+    const int64_t s0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (s0 >= cap) return;                                 // cap is a multiple of 4
+    const int4 t = *reinterpret_cast<const int4 *>(table + s0);
+    const int e[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+        if (e[j] != PHL_EMPTY) atomicOr(&bits[e[j] >> 6], 1ull << (e[j] & 63));
 }
 
+__global__ __launch_bounds__(256) void k_word_counts(const unsigned long long *__restrict__ bits, int NW, int *__restrict__ wcount)
+{
+    const int w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w < NW) wcount[w] = __popcll(bits[w]);
+}
+
+// One thread per table slot: the slot's representative candidate becomes a vertex.
 template <int D>
 __global__ __launch_bounds__(256) void k_assign(const unsigned long long *__restrict__ bits, const int *__restrict__ wrank,
-                                                const int *__restrict__ slot_of, const uint32_t *__restrict__ recs,
-                                                int N, int *table, int16_t *__restrict__ vkeys, int *__restrict__ vfirst)
+                                                const uint32_t *__restrict__ recs, int64_t cap, int *__restrict__ table,
+                                                int16_t *__restrict__ vkeys, int *__restrict__ vfirst)
 {
     using R = pix_rec<D>;
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= N) return;
+    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= cap) return;
+    const int e = table[s];
+    if (e == PHL_EMPTY) return;
     const unsigned long long m = bits[e >> 6];
-    if (!((m >> (e & 63)) & 1ull)) return;
     const int vid = wrank[e >> 6] + __popcll(m & ((1ull << (e & 63)) - 1ull));
     const int p = e / (D + 1);
     uint32_t rec[R::W], key[R::GW];
@@ -292,7 +326,7 @@ __global__ __launch_bounds__(256) void k_assign(const unsigned long long *__rest
     R::key(rec, e - p * (D + 1), key);
 #pragma unroll
     for (int i = 0; i < D; i++) vkeys[(int64_t)vid * D + i] = (int16_t)(uint16_t)(key[i >> 1] >> (16 * (i & 1)));
-    table[slot_of[e]] = -(vid + 1);
+    table[s] = -(vid + 1);
     vfirst[vid] = e;     // first-touch candidate of the vertex (its pixel tells the renumbering where the vertex lives)
 }
 
@@ -517,10 +551,43 @@ __global__ __launch_bounds__(256) void k_append_missing(const int16_t *__restric
 
 template <int D>
 void launch_elevate(const float *ref, int64_t rs, int64_t cs, int64_t n, const sf_t &sf, uint32_t *recs,
-                    phl_replay_t *replay, int *err, hipStream_t st)
+                    phl_replay_t *replay, int *err, float *mm, hipStream_t st)
 {
     const unsigned blocks = (unsigned)((n + 255) / 256);
-    hipLaunchKernelGGL(k_elevate<D>, dim3(blocks), dim3(256), 0, st, ref, rs, cs, n, sf, recs, replay, err);
+    hipLaunchKernelGGL(k_elevate<D>, dim3(blocks), dim3(256), 0, st, ref, rs, cs, n, sf, recs, replay, err, mm);
+}
+
+// [nb][d][2] block ranges -> [d][2]; then the build's scalars into the host's mailbox: {M, err, lo/hi per feature}
+__global__ __launch_bounds__(256) void k_build_info(const float *__restrict__ mm, int nb, int d, const int *__restrict__ m_total,
+                                                    const int *__restrict__ err, int *__restrict__ info)
+{
+    __shared__ float smin[256], smax[256];
+    for (int i = 0; i < d; i++) {
+        float a = INFINITY, b = -INFINITY;
+        for (int k = threadIdx.x; k < nb; k += 256) {
+            a = fminf(a, mm[((int64_t)k * d + i) * 2 + 0]);
+            b = fmaxf(b, mm[((int64_t)k * d + i) * 2 + 1]);
+        }
+        smin[threadIdx.x] = a;
+        smax[threadIdx.x] = b;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if ((int)threadIdx.x < o) {
+                smin[threadIdx.x] = fminf(smin[threadIdx.x], smin[threadIdx.x + o]);
+                smax[threadIdx.x] = fmaxf(smax[threadIdx.x], smax[threadIdx.x + o]);
+            }
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) {
+            info[2 + 2 * i] = __float_as_int(smin[0]);
+            info[3 + 2 * i] = __float_as_int(smax[0]);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        info[0] = *m_total;
+        info[1] = *err;
+    }
 }
 
 template <int D>
@@ -531,10 +598,10 @@ void launch_insert(const uint32_t *recs, int64_t n, int *table, uint32_t mask, i
 }
 
 template <int D>
-void launch_assign(const unsigned long long *bits, const int *wrank, const int *slot_of, const uint32_t *recs, int N, int *table,
+void launch_assign(const unsigned long long *bits, const int *wrank, const uint32_t *recs, int64_t cap, int *table,
                    int16_t *vkeys, int *vfirst, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_assign<D>, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, bits, wrank, slot_of, recs, N, table, vkeys, vfirst);
+    hipLaunchKernelGGL(k_assign<D>, dim3((unsigned)((cap + 255) / 256)), dim3(256), 0, st, bits, wrank, recs, cap, table, vkeys, vfirst);
 }
 
 constexpr int rec_words(int d) { return (d + 1) / 2 + (d + 5) / 6; }
@@ -651,11 +718,20 @@ int phl_build_device(phl_lattice *lat, const float *ref, int64_t rs, int64_t cs,
     PHL_HIP(tmp.get(&wrank, (size_t)NW + 1));
     PHL_HIP(tmp.get(&tile_sums, (size_t)NW / SCAN_TILE + 2));
     PHL_HIP(tmp.get(&err, 1));
+    float *mm;                                       // [blocks of k_elevate][d][2]
+    const int nblk = (int)((n + 255) / 256);
+    PHL_HIP(tmp.get(&mm, (size_t)nblk * d * 2));
+    int *info_dev;                                   // {M, err, lo/hi per feature}: written by k_build_info
+    constexpr int INFO_N = 2 + 2 * PHL_MAX_D;
+    phl_pinned_reset();
+    int *info_pinned = (int *)phl_pinned_alloc(sizeof(int) * INFO_N);
+    int info_host[INFO_N];
+    PHL_HIP(tmp.get(&info_dev, (size_t)INFO_N));
     PHL_HIP(phl_dev_malloc((void **)&lat->replay, sizeof(phl_replay_t) * (size_t)N));
     PHL_HIP(hipMemsetAsync(err, 0, sizeof(int), st));
 
     switch (d) {
-#define PHL_CASE(D) case D: launch_elevate<D>(ref, rs, cs, n, sf, recs, lat->replay, err, st); break;
+#define PHL_CASE(D) case D: launch_elevate<D>(ref, rs, cs, n, sf, recs, lat->replay, err, mm, st); break;
         PHL_FOR_D(PHL_CASE)
 #undef PHL_CASE
         default: phl_set_error("d=%d unsupported (1..%d)", d, PHL_MAX_D); return PHL_ERR_UNSUPPORTED;
@@ -669,13 +745,25 @@ int phl_build_device(phl_lattice *lat, const float *ref, int64_t rs, int64_t cs,
             PHL_FOR_D(PHL_CASE)
 #undef PHL_CASE
         }
-        hipLaunchKernelGGL(k_flag_bits, dim3(gN), dim3(256), 0, st, table, slot_of, N, fbits, wcount);
+        PHL_HIP(hipMemsetAsync(fbits, 0, sizeof(unsigned long long) * (size_t)NW, st));
+        hipLaunchKernelGGL(k_flag_bits, dim3((unsigned)((cap / 4 + 255) / 256)), dim3(256), 0, st, table, (int64_t)cap, fbits);
+        hipLaunchKernelGGL(k_word_counts, dim3((unsigned)((NW + 255) / 256)), dim3(256), 0, st, fbits, NW, wcount);
         PHL_HIP(hipGetLastError());
         rc = exclusive_scan(wcount, wrank, NW, tile_sums, st);
         if (rc) return rc;
-        PHL_HIP(hipMemcpyAsync(&host[0], wrank + NW, sizeof(int), hipMemcpyDeviceToHost, st));
-        PHL_HIP(hipMemcpyAsync(&host[1], err, sizeof(int), hipMemcpyDeviceToHost, st));
+        // one read-back: the kernel writes straight into pinned host memory where there is some
+        hipLaunchKernelGGL(k_build_info, dim3(1), dim3(256), 0, st, mm, nblk, d, wrank + NW, err, info_pinned ? info_pinned : info_dev);
+        PHL_HIP(hipGetLastError());
+        if (!info_pinned) PHL_HIP(hipMemcpyAsync(info_host, info_dev, sizeof(int) * INFO_N, hipMemcpyDeviceToHost, st));
         PHL_HIP(hipStreamSynchronize(st));
+        const int *info = info_pinned ? info_pinned : info_host;
+        host[0] = info[0];
+        host[1] = info[1];
+        for (int i = 0; i < d; i++) {
+            memcpy(&lat->feat_lo[i], &info[2 + 2 * i], sizeof(float));
+            memcpy(&lat->feat_hi[i], &info[3 + 2 * i], sizeof(float));
+        }
+        lat->feat_range_valid = 1;
         if ((host[1] & 1) || !(host[1] & 2) || cap == cap_full) break;
         // the small table overflowed (little sharing: most candidates are vertices of their own): full size
         cap = cap_full;
@@ -697,7 +785,7 @@ int phl_build_device(phl_lattice *lat, const float *ref, int64_t rs, int64_t cs,
     lat->vfirst_valid_for_M = 0;
     PHL_HIP(phl_dev_malloc((void **)&lat->vfirst, sizeof(int) * ((size_t)M + 1)));
     switch (d) {
-#define PHL_CASE(D) case D: launch_assign<D>(fbits, wrank, slot_of, recs, N, table, lat->vkeys, lat->vfirst, st); break;
+#define PHL_CASE(D) case D: launch_assign<D>(fbits, wrank, recs, (int64_t)cap, table, lat->vkeys, lat->vfirst, st); break;
         PHL_FOR_D(PHL_CASE)
 #undef PHL_CASE
     }

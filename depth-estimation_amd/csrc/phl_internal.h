@@ -67,6 +67,9 @@ struct phl_lattice {
     int *nv_cum;            // HOST [nv_max+1]: number of chunks with at most x local vertices
     int32_t *vlong;         // [n_long] vertices fed by more than LONG_LIST chunks (k_splat_reduce_long)
     int64_t n_long;
+    // feature ranges found while elevating (phl_build_device): the chunk grid is laid over the two widest
+    float feat_lo[PHL_MAX_D], feat_hi[PHL_MAX_D];
+    int feat_range_valid;
     int64_t tile_bytes;
 
     // value workspaces (phl_api.hip): a filter call takes one for the duration of its launches, so any number
@@ -113,6 +116,12 @@ int phl_reference_table_sim(const int16_t *keys_clean, const int32_t *efirst, in
 int phl_reference_table_fast(const int16_t *keys_clean, const int32_t *efirst, int64_t M, int d, int64_t N,
                              phl_reftable_query &q, phl_reftable_result &out);
 int phl_apply_reference_table(phl_lattice *lat, hipStream_t st);
+// Pinned, device-visible host memory for the build's read-backs (thread-local bump arena).  hipMemcpyAsync into pageable
+// memory blocks the host until the copy has run -- a stream synchronisation per read-back; into this it does not, and
+// kernels may write into it directly.  phl_pinned_reset() at the start of a build; phl_pinned_alloc() returns null when
+// the arena is too small (the caller then reads back into pageable memory; the next reset grows the arena).
+void phl_pinned_reset();
+void *phl_pinned_alloc(size_t bytes);
 
 // Buffers one filter call writes: the [M][vd] Jacobi ping-pong pair, the partial rows of the chunk splat and
 // the staging copies of non pixel-major inputs / outputs.  Grown on demand, reused in stream order.

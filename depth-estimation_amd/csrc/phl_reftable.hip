@@ -869,10 +869,15 @@ int phl_apply_reference_table(phl_lattice *lat, hipStream_t st)
     const int *efirst_dev = lat->vfirst;
     if (!efirst_dev) { phl_set_error("reference-table replay: first touches missing"); return PHL_ERR_INVALID; }
     PHL_HIP(tmp.get(&scratch, 1));
-    std::vector<int16_t> keys((size_t)M * d);
-    std::vector<int32_t> efirst((size_t)M);
-    PHL_HIP(hipMemcpyAsync(keys.data(), lat->vkeys, sizeof(int16_t) * keys.size(), hipMemcpyDeviceToHost, st));
-    PHL_HIP(hipMemcpyAsync(efirst.data(), efirst_dev, sizeof(int32_t) * efirst.size(), hipMemcpyDeviceToHost, st));
+    // (pinned staging where there is some: a 4 MB copy into pageable memory goes through a bounce buffer)
+    std::vector<int16_t> keys_pageable;
+    std::vector<int32_t> efirst_pageable;
+    int16_t *keys = (int16_t *)phl_pinned_alloc(sizeof(int16_t) * (size_t)M * d);
+    int32_t *efirst = (int32_t *)phl_pinned_alloc(sizeof(int32_t) * (size_t)M);
+    if (!keys) { keys_pageable.resize((size_t)M * d); keys = keys_pageable.data(); }
+    if (!efirst) { efirst_pageable.resize((size_t)M); efirst = efirst_pageable.data(); }
+    PHL_HIP(hipMemcpyAsync(keys, lat->vkeys, sizeof(int16_t) * (size_t)M * d, hipMemcpyDeviceToHost, st));
+    PHL_HIP(hipMemcpyAsync(efirst, efirst_dev, sizeof(int32_t) * (size_t)M, hipMemcpyDeviceToHost, st));
     PHL_HIP(hipStreamSynchronize(st));
     if (dbg) fprintf(stderr, "[phl] reference table: keys + first touches on the host after %.2f ms\n", since());
 
@@ -882,7 +887,7 @@ int phl_apply_reference_table(phl_lattice *lat, hipStream_t st)
     q.scratch = scratch;
     q.st = st;
     q.vkeys_dev = lat->vkeys;
-    q.keys_host = keys.data();
+    q.keys_host = keys;
     q.d = d;
     phl_reftable_result R;
     // the analytic replay first (counting, no table: phl_reference_table_fast); the simulation where it does not apply
@@ -892,13 +897,13 @@ int phl_apply_reference_table(phl_lattice *lat, hipStream_t st)
         uint64_t cap_max = (uint64_t)1 << 15;
         while (cap_max / 2 - 1 <= (uint64_t)M + 128) cap_max <<= 1;
         if (tmp.get(&q.hist, (size_t)cap_max) == hipSuccess && tmp.get(&q.small, 256) == hipSuccess)
-            rc = phl_reference_table_fast(keys.data(), efirst.data(), M, d, N, q, R);
+            rc = phl_reference_table_fast(keys, efirst, M, d, N, q, R);
         else
             (void)hipGetLastError();
         if (dbg) fprintf(stderr, "[phl] reference table: analytic replay %s after %.2f ms\n", rc == 0 ? "done" : (rc == 1 ? "not applicable" : "failed"), since());
         if (rc == 1) R = phl_reftable_result();
     }
-    if (rc == 1) rc = phl_reference_table_sim(keys.data(), efirst.data(), M, d, N, q, R);
+    if (rc == 1) rc = phl_reference_table_sim(keys, efirst, M, d, N, q, R);
     if (q.err != hipSuccess) return phl_hip_fail(q.err, "reference-table device query", __FILE__, __LINE__);
     if (rc) { phl_set_error("reference-table replay failed (inconsistent first-touch list)"); return rc; }
     if ((int)R.hidden.size() > PHL_MAX_HIDDEN) { phl_set_error("reference-table replay: too many duplicate vertices"); return PHL_ERR_UNSUPPORTED; }

@@ -1645,6 +1645,7 @@ int phl_tiles_free(phl_lattice *lat)
 int phl_tiles_link_vertices(phl_lattice *lat, hipStream_t st)
 {
     const int M = (int)lat->M, S = (int)lat->S;
+    phl_pinned_reset();                       // (callers have synchronised the stream: nothing of the arena is in flight)
     if (lat->vs_ptr) PHL_HIP(phl_dev_free(lat->vs_ptr));
     if (lat->vs) PHL_HIP(phl_dev_free(lat->vs));
     if (lat->slot_pidx) PHL_HIP(phl_dev_free(lat->slot_pidx));
@@ -1686,8 +1687,10 @@ int phl_tiles_link_vertices(phl_lattice *lat, hipStream_t st)
     if (rc) return rc;
     hipLaunchKernelGGL(k_fill_vs_rows, dim3(gS), dim3(256), 0, st, lat->vs, S, lat->slot_pidx);
     PHL_HIP(hipGetLastError());
-    int s_multi = 0;
-    PHL_HIP(hipMemcpyAsync(&s_multi, lat->slot_pidx + S, sizeof(int), hipMemcpyDeviceToHost, st));
+    int pageable_counts[2] = {0, 0};
+    int *counts = (int *)phl_pinned_alloc(sizeof(int) * 2);          // {S_multi, n_long}
+    if (!counts) counts = pageable_counts;
+    PHL_HIP(hipMemcpyAsync(&counts[0], lat->slot_pidx + S, sizeof(int), hipMemcpyDeviceToHost, st));
     // vertices with long slot lists (k_splat_reduce_long): flag, scan, compact
     int n_long = 0;
     if (lat->vlong) PHL_HIP(phl_dev_free(lat->vlong));
@@ -1701,7 +1704,7 @@ int phl_tiles_link_vertices(phl_lattice *lat, hipStream_t st)
         PHL_HIP(hipGetLastError());
         rc = exclusive_scan(lflag, lrank, M, tile_sums, st);
         if (rc) return rc;
-        PHL_HIP(hipMemcpyAsync(&n_long, lrank + M, sizeof(int), hipMemcpyDeviceToHost, st));
+        PHL_HIP(hipMemcpyAsync(&counts[1], lrank + M, sizeof(int), hipMemcpyDeviceToHost, st));
         PHL_HIP(phl_dev_malloc((void **)&lat->vlong, sizeof(int) * ((size_t)M + 1)));      // worst case; usually almost empty
         hipLaunchKernelGGL(k_compact_flagged, dim3((M + 255) / 256), dim3(256), 0, st, lflag, lrank, M, lat->vlong);
         PHL_HIP(hipGetLastError());
@@ -1724,6 +1727,8 @@ int phl_tiles_link_vertices(phl_lattice *lat, hipStream_t st)
         PHL_HIP(hipGetLastError());
     }
     PHL_HIP(hipStreamSynchronize(st));
+    const int s_multi = counts[0];
+    n_long = counts[1];
     lat->S_multi = s_multi;
     lat->n_long = n_long;
     if (n_long > 64) {
@@ -1783,20 +1788,24 @@ int phl_tiles_build(phl_lattice *lat, const float *ref, int64_t rs, int64_t cs, 
     {   // temporaries of the chunk build go back to the scratch cache before the vertex lists are linked
     temp_pool tmp;
     // 1. feature ranges -> the two widest dimensions -> uniform grid with ~P pixels per cell
-    constexpr int MMB = 1024;
-    float *mm_dev;
-    PHL_HIP(tmp.get(&mm_dev, (size_t)MMB * d * 2));
-    hipLaunchKernelGGL(k_minmax, dim3(MMB), dim3(256), 0, st, ref, rs, cs, (int64_t)n, d, mm_dev);
-    PHL_HIP(hipGetLastError());
-    std::vector<float> mm((size_t)MMB * d * 2);
-    PHL_HIP(hipMemcpyAsync(mm.data(), mm_dev, sizeof(float) * mm.size(), hipMemcpyDeviceToHost, st));
-    PHL_HIP(hipStreamSynchronize(st));
     std::vector<float> lo(d, INFINITY), hi(d, -INFINITY);
-    for (int b = 0; b < MMB; b++)
-        for (int i = 0; i < d; i++) {
-            lo[i] = fminf(lo[i], mm[((size_t)b * d + i) * 2]);
-            hi[i] = fmaxf(hi[i], mm[((size_t)b * d + i) * 2 + 1]);
-        }
+    if (lat->feat_range_valid) {          // found while elevating (phl_build_device)
+        for (int i = 0; i < d; i++) { lo[i] = lat->feat_lo[i]; hi[i] = lat->feat_hi[i]; }
+    } else {
+        constexpr int MMB = 1024;
+        float *mm_dev;
+        PHL_HIP(tmp.get(&mm_dev, (size_t)MMB * d * 2));
+        hipLaunchKernelGGL(k_minmax, dim3(MMB), dim3(256), 0, st, ref, rs, cs, (int64_t)n, d, mm_dev);
+        PHL_HIP(hipGetLastError());
+        std::vector<float> mm((size_t)MMB * d * 2);
+        PHL_HIP(hipMemcpyAsync(mm.data(), mm_dev, sizeof(float) * mm.size(), hipMemcpyDeviceToHost, st));
+        PHL_HIP(hipStreamSynchronize(st));
+        for (int b = 0; b < MMB; b++)
+            for (int i = 0; i < d; i++) {
+                lo[i] = fminf(lo[i], mm[((size_t)b * d + i) * 2]);
+                hi[i] = fmaxf(hi[i], mm[((size_t)b * d + i) * 2 + 1]);
+            }
+    }
     int da = 0, db = -1;
     for (int i = 1; i < d; i++)
         if (hi[i] - lo[i] > hi[da] - lo[da]) da = i;
@@ -1902,11 +1911,17 @@ int phl_tiles_build(phl_lattice *lat, const float *ref, int64_t rs, int64_t cs, 
     PHL_HIP(hipGetLastError());
     rc = exclusive_scan(nv, lat->chunk_vptr, nchunks, tile_sums, st);
     if (rc) return rc;
-    std::vector<int> nv_host((size_t)nchunks);
-    PHL_HIP(hipMemcpyAsync(nv_host.data(), nv, sizeof(int) * (size_t)nchunks, hipMemcpyDeviceToHost, st));
+    // (pinned staging where there is some: a copy into pageable memory would block the host twice)
+    std::vector<int> nv_pageable, by_nv_pageable;
+    int *nv_host = (int *)phl_pinned_alloc(sizeof(int) * (size_t)nchunks);
+    int *by_nv = (int *)phl_pinned_alloc(sizeof(int) * (size_t)nchunks);
+    if (!nv_host) { nv_pageable.resize((size_t)nchunks); nv_host = nv_pageable.data(); }
+    if (!by_nv) { by_nv_pageable.resize((size_t)nchunks); by_nv = by_nv_pageable.data(); }
+    PHL_HIP(hipMemcpyAsync(nv_host, nv, sizeof(int) * (size_t)nchunks, hipMemcpyDeviceToHost, st));
     PHL_HIP(hipStreamSynchronize(st));
     int nv_max = 0;
-    for (int v : nv_host) {
+    for (int c = 0; c < nchunks; c++) {
+        const int v = nv_host[c];
         S += v;
         if (v > nv_max) nv_max = v;
     }
@@ -1914,17 +1929,16 @@ int phl_tiles_build(phl_lattice *lat, const float *ref, int64_t rs, int64_t cs, 
     lat->nv_max = nv_max;
     // chunk classes (plan_tiles): cumulative histogram of the vertex counts on the host, chunk ids by descending
     // vertex count on the device (counting sort; ascending chunk id among equals)
-    std::vector<int> by_nv((size_t)nchunks);
     {
         lat->nv_cum = (int *)malloc(sizeof(int) * ((size_t)nv_max + 2));
         if (!lat->nv_cum) { phl_set_error("phl_tiles_build: out of host memory"); return PHL_ERR_HIP; }
         std::vector<int> start((size_t)nv_max + 2, 0);
-        for (int v : nv_host) start[(size_t)(nv_max - v) + 1]++;         // bin 0 = heaviest
+        for (int c = 0; c < nchunks; c++) start[(size_t)(nv_max - nv_host[c]) + 1]++;         // bin 0 = heaviest
         for (int b = 0; b <= nv_max; b++) start[(size_t)b + 1] += start[(size_t)b];
         for (int x = 0; x <= nv_max; x++) lat->nv_cum[x] = nchunks - start[(size_t)(nv_max - x)];   // #chunks with nv <= x
-        for (int c = 0; c < nchunks; c++) by_nv[(size_t)start[(size_t)(nv_max - nv_host[(size_t)c])]++] = c;
+        for (int c = 0; c < nchunks; c++) by_nv[start[(size_t)(nv_max - nv_host[c])]++] = c;
         PHL_HIP(phl_dev_malloc((void **)&lat->chunk_by_nv, sizeof(int) * ((size_t)nchunks + 1)));
-        PHL_HIP(hipMemcpyAsync(lat->chunk_by_nv, by_nv.data(), sizeof(int) * (size_t)nchunks, hipMemcpyHostToDevice, st));
+        PHL_HIP(hipMemcpyAsync(lat->chunk_by_nv, by_nv, sizeof(int) * (size_t)nchunks, hipMemcpyHostToDevice, st));
     }
     PHL_HIP(phl_dev_malloc((void **)&lat->slot_vert, sizeof(int) * ((size_t)S + 1)));
     PHL_HIP(phl_dev_malloc((void **)&lat->seg_rng, sizeof(int2) * ((size_t)S + 1)));
