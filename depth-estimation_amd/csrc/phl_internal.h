@@ -96,9 +96,18 @@ struct phl_reftable_query {
     // cap / 2 for every key of stale_clean.  For every key of `check`: is there an empty slot between the key's home
     // and the table's last slot, i.e. do the key's entries lie in index order along their probe path?  1 = yes for
     // all (certain), 0 = not for all, or it cannot be told.  Depends on the occupancy only, not on the insertion order.
-    virtual int probe_paths_do_not_wrap(int64_t n_clean, const std::vector<int32_t> &extra_clean,
-                                        const std::vector<int32_t> &stale_clean, uint64_t cap,
-                                        const std::vector<int32_t> &check) = 0;
+    // Questions are SUBMITTED as the replay goes (the device answers them in stream order, without a round trip each)
+    // and the conjunction of the answers is collected once at the end.
+    virtual void probe_paths_submit(int64_t n_clean, const std::vector<int32_t> &extra_clean,
+                                    const std::vector<int32_t> &stale_clean, uint64_t cap,
+                                    const std::vector<int32_t> &check) = 0;
+    virtual int probe_paths_all_ok() = 0;
+    int probe_paths_do_not_wrap(int64_t n_clean, const std::vector<int32_t> &extra_clean, const std::vector<int32_t> &stale_clean,
+                                uint64_t cap, const std::vector<int32_t> &check)
+    {
+        probe_paths_submit(n_clean, extra_clean, stale_clean, cap, check);
+        return probe_paths_all_ok();
+    }
     virtual ~phl_reftable_query() {}
 };
 struct phl_reftable_result {
@@ -109,12 +118,18 @@ struct phl_reftable_result {
     std::vector<int32_t> hidden;
     bool blur_grow;
     int32_t blur_first_nbr;
+    // compact form (analytic replay): the reference order is the clean order with a few extra creations inserted --
+    // ex_id ascending reference ids, ex_clean the clean vertex each one repeats.  keys / remap are then left empty and
+    // are produced where they are needed (on the device: phl_apply_reference_table; phl_reftable_expand on the host).
+    bool compact = false;
+    std::vector<int32_t> ex_id, ex_clean;
 };
+void phl_reftable_expand(const int16_t *keys_clean, int64_t M, int d, phl_reftable_result &R);
 int phl_reference_table_sim(const int16_t *keys_clean, const int32_t *efirst, int64_t M, int d, int64_t N,
                             phl_reftable_query &q, phl_reftable_result &out);
 // the same result without simulating the table (phl_reftable.hip, "analytic replay"); 1 = not applicable here, use the sim
 int phl_reference_table_fast(const int16_t *keys_clean, const int32_t *efirst, int64_t M, int d, int64_t N,
-                             phl_reftable_query &q, phl_reftable_result &out);
+                             phl_reftable_query &q, phl_reftable_result &out, bool compact);
 int phl_apply_reference_table(phl_lattice *lat, hipStream_t st);
 // Pinned, device-visible host memory for the build's read-backs (thread-local bump arena).  hipMemcpyAsync into pageable
 // memory blocks the host until the copy has run -- a stream synchronisation per read-back; into this it does not, and

@@ -398,8 +398,22 @@ int phl_reference_table_sim(const int16_t *keys_clean, const int32_t *efirst, in
 // "No entry wraps" is an occupancy property, independent of the insertion order: q.no_wrap() evaluates it for the
 // table at the end of every epoch (the device does it with one histogram and one ordered reduction).  If it does not
 // hold, or the splat ends exactly at a threshold (the doubling inside blur()), 1 is returned and the caller simulates.
+static int reference_table_fast_impl(const int16_t *keys_clean, const int32_t *efirst, int64_t M, int d, int64_t N,
+                                     phl_reftable_query &q, phl_reftable_result &out, bool compact);
 int phl_reference_table_fast(const int16_t *keys_clean, const int32_t *efirst, int64_t M, int d, int64_t N,
-                             phl_reftable_query &q, phl_reftable_result &out)
+                             phl_reftable_query &q, phl_reftable_result &out, bool compact)
+{
+    const int rc = reference_table_fast_impl(keys_clean, efirst, M, d, N, q, out, compact);
+    // the occupancy questions were answered behind the replay's back: nothing of it holds if one came back "no"
+    if (q.probe_paths_all_ok() != 1) {
+        if (getenv("PHL_DEBUG")) fprintf(stderr, "[phl] analytic replay: a tracked key's probe path wraps\n");
+        return 1;
+    }
+    return rc;
+}
+
+static int reference_table_fast_impl(const int16_t *keys_clean, const int32_t *efirst, int64_t M, int d, int64_t N,
+                                     phl_reftable_query &q, phl_reftable_result &out, bool compact)
 {
     struct tracked {
         int clean;
@@ -489,12 +503,8 @@ int phl_reference_table_fast(const int16_t *keys_clean, const int32_t *efirst, i
                 if (t.P.size() + (t.S >= 0 ? 1 : 0) >= 2) chk.push_back(t.clean);
             }
             const auto tc0 = std::chrono::steady_clock::now();
-            const int nowrap = chk.empty() ? 1 : q.probe_paths_do_not_wrap(vi, ex, st, cap, chk);
+            if (!chk.empty()) q.probe_paths_submit(vi, ex, st, cap, chk);
             t_check += ms_since(tc0);
-            if (nowrap != 1) {
-                if (getenv("PHL_DEBUG")) fprintf(stderr, "[phl] analytic replay: a tracked key's probe path wraps at capacity %llu\n", (unsigned long long)cap);
-                return 1;
-            }
         }
         const bool first_touch = vi < M && efirst[vi] == eg;
         const auto tq0 = std::chrono::steady_clock::now();
@@ -575,11 +585,24 @@ int phl_reference_table_fast(const int16_t *keys_clean, const int32_t *efirst, i
     out.blur_grow = false;
     out.blur_first_nbr = -1;
     std::sort(extras.begin(), extras.end(), [](const extra_t &a, const extra_t &b) { return a.e < b.e; });
-    out.keys.resize((size_t)F * d);
-    out.remap.resize((size_t)M);
-    {
-        // reference order = clean first touches and extra creations merged by candidate index: whole runs of clean
-        // vertices between two extras are copied (keys) and numbered (remap) in one go
+    out.compact = compact;
+    out.ex_id.clear();
+    out.ex_clean.clear();
+    out.keys.clear();
+    out.remap.clear();
+    if (compact) {
+        // reference order = clean first touches and extra creations merged by candidate index: all the caller needs
+        // is where the extras sit
+        for (size_t xi = 0; xi < extras.size(); xi++) {
+            if (extras[xi].id != clean_before(extras[xi].e) + (int64_t)xi) return PHL_ERR_INVALID;
+            out.ex_id.push_back(extras[xi].id);
+            out.ex_clean.push_back(extras[xi].clean);
+        }
+        if (F != M + (int64_t)extras.size()) return PHL_ERR_INVALID;
+    } else {
+        out.keys.resize((size_t)F * d);
+        out.remap.resize((size_t)M);
+        // whole runs of clean vertices between two extras are copied (keys) and numbered (remap) in one go
         int64_t v = 0, id = 0;
         for (size_t xi = 0; xi <= extras.size(); xi++) {
             const int64_t vend = xi < extras.size() ? clean_before(extras[xi].e) : M;     // clean vertices before this extra
@@ -613,7 +636,7 @@ int phl_reference_table_fast(const int16_t *keys_clean, const int32_t *efirst, i
         ids.erase(std::unique(ids.begin(), ids.end()), ids.end());
         for (int32_t id : ids)
             if (id != visible) out.hidden.push_back(id);
-        out.remap[(size_t)t.clean] = -(int32_t)(i + 1);
+        if (!compact) out.remap[(size_t)t.clean] = -(int32_t)(i + 1);
         out.dup_clean.push_back(t.clean);
         for (auto &sg : t.seg) {
             out.seg_e.push_back(sg.first);
@@ -626,6 +649,29 @@ int phl_reference_table_fast(const int16_t *keys_clean, const int32_t *efirst, i
         fprintf(stderr, "[phl] analytic replay: M %lld -> %lld, %zu tracked keys, %zu extra creations; %.2f ms (occupancy checks %.2f, candidate queries %.2f)\n",
                 (long long)M, (long long)F, tk.size(), extras.size(), ms_since(t_begin), t_check, t_query);
     return PHL_OK;
+}
+
+// keys / remap of a compact result, on the host (tests; more extras than the device kernels take)
+void phl_reftable_expand(const int16_t *keys_clean, int64_t M, int d, phl_reftable_result &R)
+{
+    if (!R.compact) return;
+    const size_t nx = R.ex_id.size();
+    R.keys.resize((size_t)R.M_ref * d);
+    R.remap.resize((size_t)M);
+    size_t j = 0;
+    for (int64_t r = 0; r < R.M_ref; r++) {
+        int64_t src;
+        if (j < nx && R.ex_id[j] == r) src = R.ex_clean[j++];
+        else src = r - (int64_t)j;
+        memcpy(R.keys.data() + (size_t)r * d, keys_clean + (size_t)src * d, sizeof(int16_t) * d);
+    }
+    j = 0;
+    for (int64_t v = 0; v < M; v++) {
+        while (j < nx && (int64_t)R.ex_id[j] - (int64_t)j <= v) j++;     // extras created before clean vertex v
+        R.remap[(size_t)v] = (int32_t)(v + (int64_t)j);
+    }
+    for (size_t i = 0; i < R.dup_clean.size(); i++) R.remap[(size_t)R.dup_clean[i]] = -(int32_t)(i + 1);
+    R.compact = false;
 }
 
 namespace {
@@ -668,6 +714,34 @@ __global__ __launch_bounds__(256) void k_vfirst_ref(const int *__restrict__ rema
     if (r >= 0) vfirst[r] = efirst[v];
 }
 
+// Compact replay result -> remap / keys on the device: the reference order is the clean order with a few extra
+// creations inserted (ex.id ascending; extra k repeats clean vertex ex.clean[k]).
+constexpr int PHL_MAX_EXTRAS = 96;
+struct extras_t {
+    int n;
+    int32_t id[PHL_MAX_EXTRAS], clean[PHL_MAX_EXTRAS];
+};
+
+__global__ __launch_bounds__(256) void k_ref_remap(int M, extras_t ex, int *__restrict__ remap)
+{
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= M) return;
+    int j = 0;
+    while (j < ex.n && ex.id[j] - j <= v) j++;            // extras created before clean vertex v
+    remap[v] = v + j;
+}
+
+__global__ __launch_bounds__(256) void k_ref_keys(const int16_t *__restrict__ vkeys, int d, int M_ref, extras_t ex,
+                                                  int16_t *__restrict__ out)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= M_ref) return;
+    int j = 0;
+    while (j < ex.n && ex.id[j] < r) j++;
+    const int src = (j < ex.n && ex.id[j] == r) ? ex.clean[j] : r - j;
+    for (int i = 0; i < d; i++) out[(int64_t)r * d + i] = vkeys[(int64_t)src * d + i];
+}
+
 __global__ void k_set_pairs(const int *__restrict__ idx, const int *__restrict__ val, int k, int *__restrict__ out)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -689,21 +763,15 @@ __global__ __launch_bounds__(256) void k_home_hist(const int16_t *__restrict__ v
     atomicAdd(&hist[(uint32_t)h & mask], 1);
 }
 
-__global__ void k_add_homes(const int *__restrict__ homes, int k, int *__restrict__ hist)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < k) atomicAdd(&hist[homes[i]], 1);
-}
-
 // Is there an empty slot in [home, cap) for every key to check?  Linear probing fills slots from the left:
 // carry(x+1) = max(0, carry(x) + hist[x] - 1) entries arrive at slot x+1 still looking for a slot, and slot x is empty
 // iff carry(x) + hist[x] == 0.  The carry at slot 0 is what wraps around; two sweeps settle it.  ONE workgroup: every
 // thread folds its contiguous piece of the table into a map c -> max(m, c + s); the 1024 maps are chained (twice for
 // the wrap, once more for every piece's incoming carry); then every thread walks its piece with its real carry and
-// the workgroup keeps the LAST empty slot of the table: a key passes iff its home is not behind it.
+// the workgroup keeps the LAST empty slot of the table: a key passes iff its home is not behind it (k_cluster_verdict).
+// (Used above 2^22 slots; below, k_cluster_fold / k_cluster_walk spread the same computation over the chip.)
 // (hist is read 16 bytes at a time, eight loads in flight: the walk is latency-bound otherwise -- 276 us at 2^19 slots.)
-__global__ __launch_bounds__(1024) void k_cluster_check(const int *__restrict__ hist, uint32_t cap, const int *__restrict__ homes,
-                                                        int nkeys, int *__restrict__ result)
+__global__ __launch_bounds__(1024) void k_cluster_check(const int *__restrict__ hist, uint32_t cap, int *__restrict__ last_empty_out)
 {
     __shared__ int sm[1024], ss[1024], cin[1024], gm[64], gs[64], gc[64];
     __shared__ int last_empty;
@@ -779,7 +847,139 @@ __global__ __launch_bounds__(1024) void k_cluster_check(const int *__restrict__ 
     }
     if (last >= 0) atomicMax(&last_empty, last);
     __syncthreads();
-    for (int k = threadIdx.x; k < nkeys; k += 1024) result[k] = homes[k] <= last_empty ? 1 : 0;
+    if (threadIdx.x == 0) *last_empty_out = last_empty + 1;      // (+1, 0 = no empty slot: as k_cluster_walk)
+}
+
+// The same question with the table spread over many workgroups (cap <= 2^22): k_cluster_fold reduces every 4096-slot
+// piece to one map, k_cluster_walk chains the pieces' maps (a few hundred at most, by one thread), repeats the fold inside
+// its piece with the real incoming carry and keeps the table's last empty slot (+1, 0 = none) in *last_empty.
+constexpr int CL_PIECE = 4096;           // 256 threads x 16 slots
+
+struct cl_map { int m, s; };             // c -> max(m, c + s)
+
+__device__ __forceinline__ cl_map cl_fold16(const int *__restrict__ hist, uint32_t x0)
+{
+    const int4 *__restrict__ hp = reinterpret_cast<const int4 *>(hist + x0);
+    int4 v[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) v[j] = hp[j];
+    cl_map r = {INT_MIN / 4, 0};
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int a[4] = {v[j].x - 1, v[j].y - 1, v[j].z - 1, v[j].w - 1};
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            r.m = max(0, r.m + a[k]);
+            r.s += a[k];
+        }
+    }
+    return r;
+}
+
+// the 256 thread maps of a workgroup, chained in two levels; returns (in sm/ss) nothing, fills gm/gs[16] group maps
+__device__ __forceinline__ void cl_group_maps(const cl_map mine, int *sm, int *ss, int *gm, int *gs)
+{
+    sm[threadIdx.x] = mine.m;
+    ss[threadIdx.x] = mine.s;
+    __syncthreads();
+    if (threadIdx.x < 16) {
+        int a = INT_MIN / 4, b = 0;
+        for (int j = 0; j < 16; j++) {
+            a = max(sm[threadIdx.x * 16 + j], a + ss[threadIdx.x * 16 + j]);
+            b += ss[threadIdx.x * 16 + j];
+        }
+        gm[threadIdx.x] = a;
+        gs[threadIdx.x] = b;
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void k_cluster_fold(const int *__restrict__ hist, int2 *__restrict__ piece_map)
+{
+    __shared__ int sm[256], ss[256], gm[16], gs[16];
+    const cl_map mine = cl_fold16(hist, (uint32_t)blockIdx.x * CL_PIECE + threadIdx.x * 16u);
+    cl_group_maps(mine, sm, ss, gm, gs);
+    if (threadIdx.x == 0) {
+        int a = INT_MIN / 4, b = 0;
+        for (int j = 0; j < 16; j++) {
+            a = max(gm[j], a + gs[j]);
+            b += gs[j];
+        }
+        piece_map[blockIdx.x] = make_int2(a, b);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_cluster_walk(const int *__restrict__ hist, const int2 *__restrict__ piece_map, int npieces,
+                                                      int *__restrict__ last_empty)
+{
+    __shared__ int sm[256], ss[256], gm[16], gs[16], gc[16], cin[256];
+    __shared__ int piece_carry;
+    const uint32_t x0 = (uint32_t)blockIdx.x * CL_PIECE + threadIdx.x * 16u;
+    const cl_map mine = cl_fold16(hist, x0);
+    __shared__ int2 pm[1024];                              // npieces <= 2^22 / CL_PIECE
+    for (int t = threadIdx.x; t < npieces; t += 256) pm[t] = piece_map[t];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int c = 0;                                         // the carry that wraps into slot 0: two sweeps settle it
+        for (int pass = 0; pass < 2; pass++)
+            for (int t = 0; t < npieces; t++) c = max(pm[t].x, c + pm[t].y);
+        for (int t = 0; t < (int)blockIdx.x; t++) c = max(pm[t].x, c + pm[t].y);
+        piece_carry = c;
+    }
+    cl_group_maps(mine, sm, ss, gm, gs);                   // (its barriers publish piece_carry as well)
+    if (threadIdx.x == 0) {
+        int c = piece_carry;
+        for (int j = 0; j < 16; j++) {
+            gc[j] = c;
+            c = max(gm[j], c + gs[j]);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 16) {
+        int c = gc[threadIdx.x];
+        for (int j = 0; j < 16; j++) {
+            cin[threadIdx.x * 16 + j] = c;
+            c = max(sm[threadIdx.x * 16 + j], c + ss[threadIdx.x * 16 + j]);
+        }
+    }
+    __syncthreads();
+    int c = cin[threadIdx.x];
+    int last = 0;
+    const int4 *__restrict__ hp = reinterpret_cast<const int4 *>(hist + x0);
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int4 v = hp[j];
+        const int a[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (c + a[k] == 0) last = (int)(x0 + (uint32_t)(4 * j + k)) + 1;
+            c = max(0, c + a[k] - 1);
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) last = max(last, __shfl_xor(last, o));
+    if ((threadIdx.x & 63) == 0 && last > 0) atomicMax(last_empty, last);
+}
+
+// homes of the entries filed in addition to the clean vertices' own, and of the keys asked about (kernel arguments)
+struct cl_homes {
+    int n_add, n_chk;
+    int add[128], chk[64];
+};
+
+__global__ void k_add_homes_v(cl_homes h, int *__restrict__ hist)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < h.n_add) atomicAdd(&hist[h.add[i]], 1);
+}
+
+// verdict of one question: every asked key's home at or before the last empty slot
+__global__ void k_cluster_verdict(const int *__restrict__ last_empty, cl_homes h, int *__restrict__ verdict)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const int le = *last_empty - 1;
+    int ok = 1;
+    for (int k = 0; k < h.n_chk; k++) ok &= (h.chk[k] <= le) ? 1 : 0;
+    *verdict = ok;
 }
 
 struct device_query : phl_reftable_query {
@@ -794,33 +994,65 @@ struct device_query : phl_reftable_query {
         for (int i = 0; i < d; i++) { h += (uint64_t)(int64_t)keys_host[(size_t)clean * d + i]; h *= 2531011; }
         return h;
     }
-    int probe_paths_do_not_wrap(int64_t n_clean, const std::vector<int32_t> &extra_clean, const std::vector<int32_t> &stale_clean,
-                                uint64_t cap, const std::vector<int32_t> &check) override
+    // answers land in `verdicts` (pinned host memory where there is some, else device memory read back at the end)
+    int *verdicts = nullptr;                 // [MAX_Q]
+    bool verdicts_on_host = false;
+    int2 *piece_map = nullptr;               // [max capacity / CL_PIECE] device
+    int n_submitted = 0;
+    bool cannot_tell = false;
+    static constexpr int MAX_Q = 32;
+    void probe_paths_submit(int64_t n_clean, const std::vector<int32_t> &extra_clean, const std::vector<int32_t> &stale_clean,
+                            uint64_t cap, const std::vector<int32_t> &check) override
     {
-        if (!hist || !small || cap > ((uint64_t)1 << 27) || check.size() > 64 || extra_clean.size() + stale_clean.size() > 128) return 0;
-        std::vector<int> homes;
-        for (int32_t v : extra_clean) homes.push_back((int)(hash_of(v) & (cap - 1)));
-        for (int32_t v : stale_clean) homes.push_back((int)(hash_of(v) & (cap / 2 - 1)));
-        const int nadd = (int)homes.size();
-        for (int32_t v : check) homes.push_back((int)(hash_of(v) & (cap - 1)));
+        if (!hist || !small || !verdicts || cap > ((uint64_t)1 << 27) || check.size() > 64 ||
+            extra_clean.size() + stale_clean.size() > 128 || n_submitted >= MAX_Q) {
+            cannot_tell = true;
+            return;
+        }
+        cl_homes h;
+        h.n_add = 0;
+        for (int32_t v : extra_clean) h.add[h.n_add++] = (int)(hash_of(v) & (cap - 1));
+        for (int32_t v : stale_clean) h.add[h.n_add++] = (int)(hash_of(v) & (cap / 2 - 1));
+        h.n_chk = 0;
+        for (int32_t v : check) h.chk[h.n_chk++] = (int)(hash_of(v) & (cap - 1));
+        int *const last_empty = small;       // one device int
         hipError_t r = hipMemsetAsync(hist, 0, sizeof(int) * (size_t)cap, st);
-        if (r == hipSuccess) r = hipMemcpyAsync(small, homes.data(), sizeof(int) * homes.size(), hipMemcpyHostToDevice, st);
+        if (r == hipSuccess) r = hipMemsetAsync(last_empty, 0, sizeof(int), st);
         if (r == hipSuccess) {
             if (n_clean > 0)
                 hipLaunchKernelGGL(k_home_hist, dim3((unsigned)((n_clean + 255) / 256)), dim3(256), 0, st, vkeys_dev, n_clean, d,
                                    (uint32_t)(cap - 1), hist);
-            if (nadd > 0) hipLaunchKernelGGL(k_add_homes, dim3(1), dim3(256), 0, st, small, nadd, hist);
-            hipLaunchKernelGGL(k_cluster_check, dim3(1), dim3(1024), 0, st, hist, (uint32_t)cap, small + nadd, (int)check.size(),
-                               small + 192);
+            if (h.n_add > 0) hipLaunchKernelGGL(k_add_homes_v, dim3(1), dim3(128), 0, st, h, hist);
+            if (piece_map && cap <= ((uint64_t)1 << 22)) {
+                const int np = (int)(cap / CL_PIECE);
+                hipLaunchKernelGGL(k_cluster_fold, dim3(np), dim3(256), 0, st, hist, piece_map);
+                hipLaunchKernelGGL(k_cluster_walk, dim3(np), dim3(256), 0, st, hist, piece_map, np, last_empty);
+            } else {
+                hipLaunchKernelGGL(k_cluster_check, dim3(1), dim3(1024), 0, st, hist, (uint32_t)cap, last_empty);
+            }
+            hipLaunchKernelGGL(k_cluster_verdict, dim3(1), dim3(64), 0, st, last_empty, h, verdicts + n_submitted);
             r = hipGetLastError();
         }
-        std::vector<int> res(check.size(), 0);
-        if (r == hipSuccess) r = hipMemcpyAsync(res.data(), small + 192, sizeof(int) * res.size(), hipMemcpyDeviceToHost, st);
-        if (r == hipSuccess) r = hipStreamSynchronize(st);      // (also keeps `homes` alive until the copy has run)
+        if (r != hipSuccess) { err = r; cannot_tell = true; return; }
+        n_submitted++;
+    }
+    int probe_paths_all_ok() override
+    {
+        if (cannot_tell) return 0;
+        if (n_submitted == 0) return 1;
+        int host[MAX_Q];
+        const int *v = verdicts;
+        hipError_t r = hipSuccess;
+        if (!verdicts_on_host) {
+            r = hipMemcpyAsync(host, verdicts, sizeof(int) * (size_t)n_submitted, hipMemcpyDeviceToHost, st);
+            v = host;
+        }
+        if (r == hipSuccess) r = hipStreamSynchronize(st);
         if (r != hipSuccess) { err = r; return 0; }
-        for (int x : res)
-            if (!x) return 0;
-        return 1;
+        int ok = 1;
+        for (int i = 0; i < n_submitted; i++) ok &= v[i] == 1 ? 1 : 0;
+        n_submitted = 0;
+        return ok;
     }
     const phl_replay_t *replay;
     int N;
@@ -896,8 +1128,12 @@ int phl_apply_reference_table(phl_lattice *lat, hipStream_t st)
     if (!(envf && atoi(envf) == 0)) {
         uint64_t cap_max = (uint64_t)1 << 15;
         while (cap_max / 2 - 1 <= (uint64_t)M + 128) cap_max <<= 1;
-        if (tmp.get(&q.hist, (size_t)cap_max) == hipSuccess && tmp.get(&q.small, 256) == hipSuccess)
-            rc = phl_reference_table_fast(keys, efirst, M, d, N, q, R);
+        q.verdicts = (int *)phl_pinned_alloc(sizeof(int) * device_query::MAX_Q);
+        q.verdicts_on_host = q.verdicts != nullptr;
+        if (tmp.get(&q.hist, (size_t)cap_max) == hipSuccess && tmp.get(&q.small, 256) == hipSuccess &&
+            tmp.get(&q.piece_map, (size_t)(cap_max / CL_PIECE) + 1) == hipSuccess &&
+            (q.verdicts || tmp.get(&q.verdicts, (size_t)device_query::MAX_Q) == hipSuccess))
+            rc = phl_reference_table_fast(keys, efirst, M, d, N, q, R, true);
         else
             (void)hipGetLastError();
         if (dbg) fprintf(stderr, "[phl] reference table: analytic replay %s after %.2f ms\n", rc == 0 ? "done" : (rc == 1 ? "not applicable" : "failed"), since());
@@ -908,13 +1144,35 @@ int phl_apply_reference_table(phl_lattice *lat, hipStream_t st)
     if (rc) { phl_set_error("reference-table replay failed (inconsistent first-touch list)"); return rc; }
     if ((int)R.hidden.size() > PHL_MAX_HIDDEN) { phl_set_error("reference-table replay: too many duplicate vertices"); return PHL_ERR_UNSUPPORTED; }
 
+    if (R.compact && R.ex_id.size() > (size_t)PHL_MAX_EXTRAS) phl_reftable_expand(keys, M, d, R);
     if (R.M_ref != M || !R.dup_clean.empty()) {
         int *remap_dev, *dup_ptr_dev, *seg_e_dev, *seg_id_dev;
+        extras_t ex;
+        ex.n = 0;
+        if (R.compact) {
+            ex.n = (int)R.ex_id.size();
+            for (int k = 0; k < ex.n; k++) { ex.id[k] = R.ex_id[(size_t)k]; ex.clean[k] = R.ex_clean[(size_t)k]; }
+        }
         PHL_HIP(tmp.get(&remap_dev, (size_t)M));
         PHL_HIP(tmp.get(&dup_ptr_dev, R.dup_ptr.size()));
         PHL_HIP(tmp.get(&seg_e_dev, R.seg_e.size() + 1));
         PHL_HIP(tmp.get(&seg_id_dev, R.seg_id.size() + 1));
-        PHL_HIP(hipMemcpyAsync(remap_dev, R.remap.data(), sizeof(int) * (size_t)M, hipMemcpyHostToDevice, st));
+        std::vector<int32_t> dup_val;                     // (alive until the synchronisation below)
+        if (R.compact) {
+            hipLaunchKernelGGL(k_ref_remap, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, st, (int)M, ex, remap_dev);
+            if (!R.dup_clean.empty()) {                   // tracked keys: -(k+1), resolved per candidate by k_relabel
+                int *di, *dv;
+                PHL_HIP(tmp.get(&di, R.dup_clean.size()));
+                PHL_HIP(tmp.get(&dv, R.dup_clean.size()));
+                for (size_t k = 0; k < R.dup_clean.size(); k++) dup_val.push_back(-(int32_t)(k + 1));
+                PHL_HIP(hipMemcpyAsync(di, R.dup_clean.data(), sizeof(int) * R.dup_clean.size(), hipMemcpyHostToDevice, st));
+                PHL_HIP(hipMemcpyAsync(dv, dup_val.data(), sizeof(int) * dup_val.size(), hipMemcpyHostToDevice, st));
+                hipLaunchKernelGGL(k_set_pairs, dim3((unsigned)((R.dup_clean.size() + 63) / 64)), dim3(64), 0, st, di, dv, (int)R.dup_clean.size(), remap_dev);
+            }
+            PHL_HIP(hipGetLastError());
+        } else {
+            PHL_HIP(hipMemcpyAsync(remap_dev, R.remap.data(), sizeof(int) * (size_t)M, hipMemcpyHostToDevice, st));
+        }
         PHL_HIP(hipMemcpyAsync(dup_ptr_dev, R.dup_ptr.data(), sizeof(int) * R.dup_ptr.size(), hipMemcpyHostToDevice, st));
         if (!R.seg_e.empty()) {
             PHL_HIP(hipMemcpyAsync(seg_e_dev, R.seg_e.data(), sizeof(int) * R.seg_e.size(), hipMemcpyHostToDevice, st));
@@ -925,7 +1183,10 @@ int phl_apply_reference_table(phl_lattice *lat, hipStream_t st)
         PHL_HIP(hipGetLastError());
         int16_t *vkeys_new;
         PHL_HIP(phl_dev_malloc((void **)&vkeys_new, sizeof(int16_t) * (size_t)R.M_ref * d));
-        PHL_HIP(hipMemcpyAsync(vkeys_new, R.keys.data(), sizeof(int16_t) * (size_t)R.M_ref * d, hipMemcpyHostToDevice, st));
+        if (R.compact)
+            hipLaunchKernelGGL(k_ref_keys, dim3((unsigned)((R.M_ref + 255) / 256)), dim3(256), 0, st, lat->vkeys, d, (int)R.M_ref, ex, vkeys_new);
+        else
+            PHL_HIP(hipMemcpyAsync(vkeys_new, R.keys.data(), sizeof(int16_t) * (size_t)R.M_ref * d, hipMemcpyHostToDevice, st));
         // first touches in the reference's numbering (phl_build_device would otherwise have to find every vertex's home
         // cell with an atomicMin over all N candidates: 1.1 ms at C3)
         std::vector<int32_t> dv_id, dv_e;
@@ -979,8 +1240,20 @@ struct host_query : phl_reftable_query {
         for (int i = 0; i < d; i++) { h += (uint64_t)(int64_t)keys[(size_t)clean * d + i]; h *= 2531011; }
         return h;
     }
-    int probe_paths_do_not_wrap(int64_t n_clean, const std::vector<int32_t> &extra_clean, const std::vector<int32_t> &stale_clean,
-                                uint64_t cap, const std::vector<int32_t> &check) override
+    int all_ok = 1;
+    int probe_paths_all_ok() override
+    {
+        const int r = all_ok;
+        all_ok = 1;
+        return r;
+    }
+    void probe_paths_submit(int64_t n_clean, const std::vector<int32_t> &extra_clean, const std::vector<int32_t> &stale_clean,
+                            uint64_t cap, const std::vector<int32_t> &check) override
+    {
+        all_ok &= answer(n_clean, extra_clean, stale_clean, cap, check);
+    }
+    int answer(int64_t n_clean, const std::vector<int32_t> &extra_clean, const std::vector<int32_t> &stale_clean,
+               uint64_t cap, const std::vector<int32_t> &check)
     {
         std::vector<int32_t> hist((size_t)cap, 0);
         for (int64_t v = 0; v < n_clean; v++) hist[(size_t)(hash_of((int)v) & (cap - 1))]++;
@@ -1031,7 +1304,10 @@ extern "C" int phl_debug_reference_table(const int16_t *keys_clean, const int32_
     const char *envf = getenv("PHL_REPLAY_FAST");
     const int mode = envf ? atoi(envf) : 0;
     int rc = 1;
-    if (mode >= 1) rc = phl_reference_table_fast(keys_clean, efirst.data(), M, d, N, q, R);
+    if (mode >= 1) {
+        rc = phl_reference_table_fast(keys_clean, efirst.data(), M, d, N, q, R, true);
+        if (rc == 0) phl_reftable_expand(keys_clean, M, d, R);
+    }
     if (rc == 1) {
         if (mode == 2) { phl_set_error("analytic replay not applicable"); return PHL_ERR_UNSUPPORTED; }
         R = phl_reftable_result();
@@ -1083,6 +1359,8 @@ extern "C" int phl_debug_probe_paths(const int16_t *keys_clean, int64_t n_clean,
     PHL_HIP(tmp.get(&kd, (size_t)n_clean * d + 1));
     PHL_HIP(tmp.get(&q.hist, (size_t)cap));
     PHL_HIP(tmp.get(&q.small, 256));
+    PHL_HIP(tmp.get(&q.piece_map, (size_t)(cap / CL_PIECE) + 1));
+    PHL_HIP(tmp.get(&q.verdicts, (size_t)device_query::MAX_Q));
     PHL_HIP(hipMemcpy(kd, keys_clean, sizeof(int16_t) * (size_t)n_clean * d, hipMemcpyHostToDevice));
     q.replay = nullptr;
     q.N = 0;

@@ -838,3 +838,15 @@ def test_occupancy_check_on_the_device_equals_the_host(phl):
         many = rng.integers(0, n, 40)
         assert probe_paths(k, n, extra, stale, cap, many, on_device=1) == probe_paths(k, n, extra, stale, cap, many, on_device=0)
     assert seen == {0, 1}, "the cases should cover both answers"
+    # above 2^22 slots one workgroup does the whole table (k_cluster_check)
+    cap = 1 << 23
+    keys, homes = keys_with_homes(rng, cap, count=1 << 19)
+    order = np.argsort(-homes, kind="stable")
+    for pile_n in (0, 3):
+        pile = order[:pile_n]
+        sel = np.concatenate([rng.permutation(np.setdiff1d(np.arange(len(keys)), pile))[:300000], pile])
+        # pile the last slots full by asking for the same homes again (extra entries)
+        extra = np.repeat(np.arange(len(sel) - pile_n, len(sel)), 40) if pile_n else np.zeros(0, np.int64)
+        for c in (0, len(sel) - 1):
+            want = probe_paths(keys[sel], len(sel), extra, [], cap, [c], on_device=0)
+            assert probe_paths(keys[sel], len(sel), extra, [], cap, [c], on_device=1) == want, (pile_n, c)
