@@ -475,6 +475,7 @@ int phl_destroy(phl_lattice *lat)
     device_guard g(lat->device);
     (void)hipDeviceSynchronize();      // what hipFree would do: nothing may still be using the arrays (they are cached, not freed)
     phl_tiles_free(lat);
+    phl_release_build_tables(lat);                 // (only a build that failed half-way leaves any)
     void *ptrs[] = {lat->vkeys, lat->replay, lat->csr_ptr, lat->csr, lat->nbr, lat->nbr2, lat->table, lat->ft_of_int, lat->int_of_ft, lat->vfirst};
     for (void *p : ptrs)
         if (p) (void)phl_dev_free(p);

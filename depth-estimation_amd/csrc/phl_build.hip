@@ -330,12 +330,26 @@ __global__ __launch_bounds__(256) void k_assign(const unsigned long long *__rest
     vfirst[vid] = e;     // first-touch candidate of the vertex (its pixel tells the renumbering where the vertex lives)
 }
 
-__global__ __launch_bounds__(256) void k_set_vid(const int *__restrict__ table, const int *__restrict__ slot_of, int N,
-                                                 phl_replay_t *__restrict__ replay)
+// replay[e].vid, written once: clean vertex of the candidate's table slot -> reference vertex (remap; for a key with
+// several vertices the last segment that starts at or before e) -> locality numbering (int_of_ft).
+__global__ __launch_bounds__(256) void k_final_vid(const int *__restrict__ table, const int *__restrict__ slot_of, int N,
+                                                   const int *__restrict__ remap, const int *__restrict__ dup_ptr,
+                                                   const int *__restrict__ seg_e, const int *__restrict__ seg_id,
+                                                   const int *__restrict__ int_of_ft, phl_replay_t *__restrict__ replay)
 {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= N) return;
-    replay[e].vid = -(table[slot_of[e]] + 1);
+    int r = -(table[slot_of[e]] + 1);
+    if (remap) {
+        r = remap[r];
+        if (r < 0) {
+            const int k = -r - 1;
+            int id = seg_id[dup_ptr[k]];
+            for (int s = dup_ptr[k]; s < dup_ptr[k + 1] && seg_e[s] <= e; s++) id = seg_id[s];
+            r = id;
+        }
+    }
+    replay[e].vid = int_of_ft ? int_of_ft[r] : r;
 }
 
 __global__ __launch_bounds__(256) void k_count_vid(const phl_replay_t *__restrict__ replay, int N, int *cnt)
@@ -670,6 +684,27 @@ int phl_rebuild_table_and_neighbors(phl_lattice *lat, hipStream_t st, void **scr
     return PHL_OK;
 }
 
+void phl_release_build_tables(phl_lattice *lat)
+{
+    int32_t **p[] = {&lat->bt_slot_of, &lat->bt_table, &lat->bt_remap, &lat->bt_dup_ptr, &lat->bt_seg_e, &lat->bt_seg_id};
+    for (int32_t **q : p) {
+        if (*q) (void)phl_dev_free(*q);
+        *q = nullptr;
+    }
+}
+
+int phl_write_final_vids(phl_lattice *lat, hipStream_t st)
+{
+    if (!lat->bt_slot_of || !lat->bt_table) { phl_set_error("phl_write_final_vids: no build tables"); return PHL_ERR_INVALID; }
+    const int N = (int)lat->N;
+    if (N > 0) {
+        hipLaunchKernelGGL(k_final_vid, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, lat->bt_table, lat->bt_slot_of, N,
+                           lat->bt_remap, lat->bt_dup_ptr, lat->bt_seg_e, lat->bt_seg_id, lat->int_of_ft, lat->replay);
+        PHL_HIP(hipGetLastError());
+    }
+    return PHL_OK;
+}
+
 int phl_build_device(phl_lattice *lat, const float *ref, int64_t rs, int64_t cs, hipStream_t st)
 {
     const int d = lat->d;
@@ -711,8 +746,11 @@ int phl_build_device(phl_lattice *lat, const float *ref, int64_t rs, int64_t cs,
     const unsigned gN = (unsigned)((N + 255) / 256);
     const int NW = (int)gN * 4;                      // 64-candidate words of the first-touch mask
     PHL_HIP(tmp.get(&recs, (size_t)n * rec_words(d) + 4));
-    PHL_HIP(tmp.get(&table, cap));
-    PHL_HIP(tmp.get(&slot_of, (size_t)N));
+    phl_release_build_tables(lat);
+    PHL_HIP(phl_dev_malloc((void **)&lat->bt_table, sizeof(int) * (size_t)cap));       // (outlive this function: bt_*)
+    PHL_HIP(phl_dev_malloc((void **)&lat->bt_slot_of, sizeof(int) * (size_t)N));
+    table = lat->bt_table;
+    slot_of = lat->bt_slot_of;
     PHL_HIP(tmp.get(&fbits, (size_t)NW));
     PHL_HIP(tmp.get(&wcount, (size_t)NW));
     PHL_HIP(tmp.get(&wrank, (size_t)NW + 1));
@@ -768,7 +806,10 @@ int phl_build_device(phl_lattice *lat, const float *ref, int64_t rs, int64_t cs,
         // the small table overflowed (little sharing: most candidates are vertices of their own): full size
         cap = cap_full;
         mask = (uint32_t)(cap - 1);
-        PHL_HIP(tmp.get(&table, cap));
+        PHL_HIP(phl_dev_free(lat->bt_table));             // (the stream has been synchronised)
+        lat->bt_table = nullptr;
+        PHL_HIP(phl_dev_malloc((void **)&lat->bt_table, sizeof(int) * (size_t)cap));
+        table = lat->bt_table;
         PHL_HIP(hipMemsetAsync(err, 0, sizeof(int), st));
     }
     if (host[1] & 1) {
@@ -789,7 +830,7 @@ int phl_build_device(phl_lattice *lat, const float *ref, int64_t rs, int64_t cs,
         PHL_FOR_D(PHL_CASE)
 #undef PHL_CASE
     }
-    hipLaunchKernelGGL(k_set_vid, dim3(gN), dim3(256), 0, st, table, slot_of, N, lat->replay);
+    // (replay[].vid is written at the end of phl_tiles_build, through the renamings that follow: phl_write_final_vids)
     PHL_HIP(hipGetLastError());
     if (lat->build_flags & PHL_BUILD_REFERENCE_TABLE) {
         rc = phl_apply_reference_table(lat, st);

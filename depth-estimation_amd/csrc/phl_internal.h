@@ -44,6 +44,12 @@ struct phl_lattice {
     // first-touch order.  Both maps are null when the two coincide.  The public introspection calls translate.
     int32_t *vfirst;        // [M] first-touch candidate (pixel*(d+1)+remainder) per vertex: build-time only, may be null
     int64_t vfirst_valid_for_M;   // the reference-table replay wrote vfirst for this many vertices (0: it did not)
+    // Build-time only (null outside phl_build_device ... phl_tiles_build): every candidate's slot in the build's key
+    // table and the table itself (slot -> -(clean vertex + 1)); the reference-table step's renaming (clean -> reference
+    // vertex, per-candidate segments for keys with several vertices).  replay[].vid is written ONCE, at the end, through
+    // all of them and the locality numbering (k_final_vid) instead of once per renaming.
+    int32_t *bt_slot_of, *bt_table;
+    int32_t *bt_remap, *bt_dup_ptr, *bt_seg_e, *bt_seg_id;
     int32_t *ft_of_int;     // [M] first-touch id of internal vertex i
     int32_t *int_of_ft;     // [M] internal id (row) of first-touch vertex v
 
@@ -131,6 +137,9 @@ int phl_reference_table_sim(const int16_t *keys_clean, const int32_t *efirst, in
 int phl_reference_table_fast(const int16_t *keys_clean, const int32_t *efirst, int64_t M, int d, int64_t N,
                              phl_reftable_query &q, phl_reftable_result &out, bool compact);
 int phl_apply_reference_table(phl_lattice *lat, hipStream_t st);
+// replay[].vid from the build-time tables (see bt_* above), mapped through int_of_ft if there is one; releases nothing
+int phl_write_final_vids(phl_lattice *lat, hipStream_t st);
+void phl_release_build_tables(phl_lattice *lat);          // (after a stream synchronisation)
 // Pinned, device-visible host memory for the build's read-backs (thread-local bump arena).  hipMemcpyAsync into pageable
 // memory blocks the host until the copy has run -- a stream synchronisation per read-back; into this it does not, and
 // kernels may write into it directly.  phl_pinned_reset() at the start of a build; phl_pinned_alloc() returns null when

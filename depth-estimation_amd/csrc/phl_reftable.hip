@@ -677,30 +677,23 @@ void phl_reftable_expand(const int16_t *keys_clean, int64_t M, int d, phl_reftab
 namespace {
 
 // ---- device side ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_next_occurrence(const phl_replay_t *__restrict__ replay, int N, int vid, int after,
-                                                         int *__restrict__ out)
+// candidates are known by their slot in the build's key table (phl_build_device: bt_slot_of / bt_table); a vertex id
+// is not written per candidate before the very end (k_final_vid)
+__global__ void k_vid_at(const int *__restrict__ table, const int *__restrict__ slot_of, int e, int *__restrict__ out)
 {
-    int best = 0x7FFFFFFF;
-    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < N; e += gridDim.x * blockDim.x)
-        if (e > after && replay[e].vid == vid && e < best) best = e;
-    for (int o = 32; o > 0; o >>= 1) best = min(best, __shfl_xor(best, o));
-    if ((threadIdx.x & 63) == 0 && best != 0x7FFFFFFF) atomicMin(out, best);
+    *out = -(table[slot_of[e]] + 1);
 }
 
-__global__ __launch_bounds__(256) void k_relabel(phl_replay_t *__restrict__ replay, int N, const int *__restrict__ remap,
-                                                 const int *__restrict__ dup_ptr, const int *__restrict__ seg_e,
-                                                 const int *__restrict__ seg_id)
+// first candidate after `after` with the same key as candidate e_first (= the same table slot)
+__global__ __launch_bounds__(256) void k_next_occurrence(const int *__restrict__ slot_of, int N, int e_first, int after,
+                                                         int *__restrict__ out)
 {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= N) return;
-    int r = remap[replay[e].vid];
-    if (r < 0) {                       // a key with several vertices: the last segment that starts at or before e
-        const int k = -r - 1;
-        int id = seg_id[dup_ptr[k]];
-        for (int s = dup_ptr[k]; s < dup_ptr[k + 1] && seg_e[s] <= e; s++) id = seg_id[s];
-        r = id;
-    }
-    replay[e].vid = r;
+    const int slot = slot_of[e_first];
+    int best = 0x7FFFFFFF;
+    for (int e = after + 1 + blockIdx.x * blockDim.x + threadIdx.x; e < N; e += gridDim.x * blockDim.x)
+        if (slot_of[e] == slot && e < best) best = e;
+    for (int o = 32; o > 0; o >>= 1) best = min(best, __shfl_xor(best, o));
+    if ((threadIdx.x & 63) == 0 && best != 0x7FFFFFFF) atomicMin(out, best);
 }
 
 // first-touch candidate of every REFERENCE vertex (the home cell of the locality renumbering is read from it):
@@ -1054,7 +1047,8 @@ struct device_query : phl_reftable_query {
         n_submitted = 0;
         return ok;
     }
-    const phl_replay_t *replay;
+    const int *slot_of = nullptr, *table = nullptr;      // the build's key table (bt_*)
+    const int32_t *efirst_host = nullptr;                // first-touch candidate of every clean vertex
     int N;
     int *scratch;            // one device int
     hipStream_t st;
@@ -1062,7 +1056,8 @@ struct device_query : phl_reftable_query {
     int vid_at(int64_t e) override
     {
         int v = -1;
-        hipError_t r = hipMemcpyAsync(&v, &replay[e].vid, sizeof(int), hipMemcpyDeviceToHost, st);
+        hipLaunchKernelGGL(k_vid_at, dim3(1), dim3(1), 0, st, table, slot_of, (int)e, scratch);
+        hipError_t r = hipMemcpyAsync(&v, scratch, sizeof(int), hipMemcpyDeviceToHost, st);
         if (r == hipSuccess) r = hipStreamSynchronize(st);
         if (r != hipSuccess) { err = r; return -1; }
         return v;
@@ -1072,7 +1067,7 @@ struct device_query : phl_reftable_query {
         int v = 0x7FFFFFFF;
         hipError_t r = hipMemcpyAsync(scratch, &v, sizeof(int), hipMemcpyHostToDevice, st);
         if (r == hipSuccess) {
-            hipLaunchKernelGGL(k_next_occurrence, dim3(1024), dim3(256), 0, st, replay, N, vid, (int)after, scratch);
+            hipLaunchKernelGGL(k_next_occurrence, dim3(1024), dim3(256), 0, st, slot_of, N, (int)efirst_host[vid], (int)after, scratch);
             r = hipMemcpyAsync(&v, scratch, sizeof(int), hipMemcpyDeviceToHost, st);
         }
         if (r == hipSuccess) r = hipStreamSynchronize(st);
@@ -1084,7 +1079,7 @@ struct device_query : phl_reftable_query {
 }  // namespace
 
 // Called by phl_build_device between the clean numbering and the neighbour tables.  lat->vfirst holds every clean
-// vertex's first-touch candidate, replay[].vid the clean ids.
+// vertex's first-touch candidate; the candidates' clean vertices are read through lat->bt_slot_of / bt_table.
 int phl_apply_reference_table(phl_lattice *lat, hipStream_t st)
 {
     const int d = lat->d;
@@ -1114,7 +1109,10 @@ int phl_apply_reference_table(phl_lattice *lat, hipStream_t st)
     if (dbg) fprintf(stderr, "[phl] reference table: keys + first touches on the host after %.2f ms\n", since());
 
     device_query q;
-    q.replay = lat->replay;
+    if (!lat->bt_slot_of || !lat->bt_table) { phl_set_error("reference-table replay: build tables missing"); return PHL_ERR_INVALID; }
+    q.slot_of = lat->bt_slot_of;
+    q.table = lat->bt_table;
+    q.efirst_host = efirst;
     q.N = N;
     q.scratch = scratch;
     q.st = st;
@@ -1153,10 +1151,15 @@ int phl_apply_reference_table(phl_lattice *lat, hipStream_t st)
             ex.n = (int)R.ex_id.size();
             for (int k = 0; k < ex.n; k++) { ex.id[k] = R.ex_id[(size_t)k]; ex.clean[k] = R.ex_clean[(size_t)k]; }
         }
-        PHL_HIP(tmp.get(&remap_dev, (size_t)M));
-        PHL_HIP(tmp.get(&dup_ptr_dev, R.dup_ptr.size()));
-        PHL_HIP(tmp.get(&seg_e_dev, R.seg_e.size() + 1));
-        PHL_HIP(tmp.get(&seg_id_dev, R.seg_id.size() + 1));
+        // (kept until the candidates' vertex ids are written: lat->bt_*, k_final_vid)
+        PHL_HIP(phl_dev_malloc((void **)&lat->bt_remap, sizeof(int) * (size_t)M));
+        PHL_HIP(phl_dev_malloc((void **)&lat->bt_dup_ptr, sizeof(int) * R.dup_ptr.size()));
+        PHL_HIP(phl_dev_malloc((void **)&lat->bt_seg_e, sizeof(int) * (R.seg_e.size() + 1)));
+        PHL_HIP(phl_dev_malloc((void **)&lat->bt_seg_id, sizeof(int) * (R.seg_id.size() + 1)));
+        remap_dev = lat->bt_remap;
+        dup_ptr_dev = lat->bt_dup_ptr;
+        seg_e_dev = lat->bt_seg_e;
+        seg_id_dev = lat->bt_seg_id;
         std::vector<int32_t> dup_val;                     // (alive until the synchronisation below)
         if (R.compact) {
             hipLaunchKernelGGL(k_ref_remap, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, st, (int)M, ex, remap_dev);
@@ -1178,9 +1181,6 @@ int phl_apply_reference_table(phl_lattice *lat, hipStream_t st)
             PHL_HIP(hipMemcpyAsync(seg_e_dev, R.seg_e.data(), sizeof(int) * R.seg_e.size(), hipMemcpyHostToDevice, st));
             PHL_HIP(hipMemcpyAsync(seg_id_dev, R.seg_id.data(), sizeof(int) * R.seg_id.size(), hipMemcpyHostToDevice, st));
         }
-        hipLaunchKernelGGL(k_relabel, dim3((N + 255) / 256), dim3(256), 0, st, lat->replay, N, remap_dev, dup_ptr_dev,
-                           seg_e_dev, seg_id_dev);
-        PHL_HIP(hipGetLastError());
         int16_t *vkeys_new;
         PHL_HIP(phl_dev_malloc((void **)&vkeys_new, sizeof(int16_t) * (size_t)R.M_ref * d));
         if (R.compact)
@@ -1362,7 +1362,7 @@ extern "C" int phl_debug_probe_paths(const int16_t *keys_clean, int64_t n_clean,
     PHL_HIP(tmp.get(&q.piece_map, (size_t)(cap / CL_PIECE) + 1));
     PHL_HIP(tmp.get(&q.verdicts, (size_t)device_query::MAX_Q));
     PHL_HIP(hipMemcpy(kd, keys_clean, sizeof(int16_t) * (size_t)n_clean * d, hipMemcpyHostToDevice));
-    q.replay = nullptr;
+
     q.N = 0;
     q.scratch = nullptr;
     q.st = nullptr;

@@ -1849,6 +1849,15 @@ int phl_tiles_build(phl_lattice *lat, const float *ref, int64_t rs, int64_t cs, 
     {
         static const bool renumber = !(getenv("PHL_RENUMBER") && atoi(getenv("PHL_RENUMBER")) == 0);
         const int M = (int)lat->M;
+        // fresh build (phl_build_device's tables are there): the candidates' vertex ids are written once, below,
+        // through the locality numbering -- unless the vertices' homes have to be read off replay[] first
+        bool from_tables = lat->bt_slot_of != nullptr;
+        bool wrote_vids = false;
+        if (from_tables && !lat->vfirst) {
+            rc = phl_write_final_vids(lat, st);      // (int_of_ft is null here: first-touch / reference ids)
+            if (rc) return rc;
+            from_tables = false;
+        }
         if (renumber && ncell > 8 && M > 1) {
             int *vhome, *vkey;
             PHL_HIP(tmp.get(&vhome, (size_t)M));
@@ -1872,11 +1881,21 @@ int phl_tiles_build(phl_lattice *lat, const float *ref, int64_t rs, int64_t cs, 
             PHL_HIP(phl_dev_malloc((void **)&vkeys_new, sizeof(int16_t) * (size_t)M * d));
             hipLaunchKernelGGL(k_permute_keys, dim3((unsigned)(((int64_t)M * d + 255) / 256)), dim3(256), 0, st, lat->vkeys,
                                lat->ft_of_int, M, d, vkeys_new);
-            hipLaunchKernelGGL(k_relabel_replay, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, lat->replay, (int)N,
-                               lat->int_of_ft);
+            if (from_tables) {
+                rc = phl_write_final_vids(lat, st);
+                if (rc) return rc;
+                wrote_vids = true;
+            } else {
+                hipLaunchKernelGGL(k_relabel_replay, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, lat->replay, (int)N,
+                                   lat->int_of_ft);
+            }
             PHL_HIP(hipGetLastError());
             deferred.p[0] = lat->vkeys;              // still being read by the gather above
             lat->vkeys = vkeys_new;
+        }
+        if (from_tables && !wrote_vids) {            // no locality numbering: first-touch (reference) ids as they are
+            rc = phl_write_final_vids(lat, st);
+            if (rc) return rc;
         }
         deferred.p[1] = lat->vfirst;                 // build-time only
         lat->vfirst = nullptr;
@@ -1953,6 +1972,7 @@ int phl_tiles_build(phl_lattice *lat, const float *ref, int64_t rs, int64_t cs, 
     PHL_HIP(hipGetLastError());
     PHL_HIP(hipStreamSynchronize(st));
     }
+    phl_release_build_tables(lat);                 // (read by k_final_vid: behind the synchronisation)
     rc = phl_tiles_link_vertices(lat, st);
     if (rc) return rc;
     lat->table_bytes = (int64_t)(sizeof(int16_t) * (size_t)lat->M * d + sizeof(phl_replay_t) * (size_t)N +
