@@ -92,19 +92,23 @@ __global__ __launch_bounds__(256) void k_elevate(const float *__restrict__ ref, 
 #pragma unroll
     for (int i = 0; i < D; i++) pos[i] = live ? ref[p * rs + i * cs] : 0.f;
     {   // feature ranges (the chunk grid of phl_tiles_build is laid over the two widest features): the values are in
-        // registers here, a second pass over `ref` would read them again
+        // registers here, a second pass over `ref` would read them again.  Wavefront reduction on DPP row shifts and
+        // broadcasts (VALU only); lane 63 holds the result.
         __shared__ float smin[4][D], smax[4][D];
         const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#define PHL_DPP_F(x, ctrl, rowmask, OP, IDENT) x = OP(x, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(IDENT), __float_as_int(x), ctrl, rowmask, 0xF, false)))
+#define PHL_WAVE_REDUCE(x, OP, IDENT)                                                                              \
+    PHL_DPP_F(x, 0x111, 0xF, OP, IDENT); PHL_DPP_F(x, 0x112, 0xF, OP, IDENT); PHL_DPP_F(x, 0x114, 0xF, OP, IDENT); \
+    PHL_DPP_F(x, 0x118, 0xF, OP, IDENT); PHL_DPP_F(x, 0x142, 0xA, OP, IDENT); PHL_DPP_F(x, 0x143, 0xC, OP, IDENT);
 #pragma unroll
         for (int i = 0; i < D; i++) {
             float a = live ? pos[i] : INFINITY, b = live ? pos[i] : -INFINITY;
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                a = fminf(a, __shfl_xor(a, o));
-                b = fmaxf(b, __shfl_xor(b, o));
-            }
-            if (lane == 0) { smin[w][i] = a; smax[w][i] = b; }
+            PHL_WAVE_REDUCE(a, fminf, INFINITY)
+            PHL_WAVE_REDUCE(b, fmaxf, -INFINITY)
+            if (lane == 63) { smin[w][i] = a; smax[w][i] = b; }
         }
+#undef PHL_WAVE_REDUCE
+#undef PHL_DPP_F
         __syncthreads();
         if ((int)threadIdx.x < D) {
             float a = smin[0][threadIdx.x], b = smax[0][threadIdx.x];
@@ -571,7 +575,35 @@ void launch_elevate(const float *ref, int64_t rs, int64_t cs, int64_t n, const s
     hipLaunchKernelGGL(k_elevate<D>, dim3(blocks), dim3(256), 0, st, ref, rs, cs, n, sf, recs, replay, err, mm);
 }
 
-// [nb][d][2] block ranges -> [d][2]; then the build's scalars into the host's mailbox: {M, err, lo/hi per feature}
+// [nb][d][2] block ranges -> [gridDim][d][2]: a thread takes whole blocks' records, a workgroup reduces its threads
+__global__ __launch_bounds__(256) void k_minmax_stage(const float *__restrict__ mm, int nb, int d, float *__restrict__ out)
+{
+    __shared__ float smin[256], smax[256];
+    for (int i = 0; i < d; i++) {
+        float a = INFINITY, b = -INFINITY;
+        for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < nb; k += gridDim.x * blockDim.x) {
+            a = fminf(a, mm[((int64_t)k * d + i) * 2 + 0]);
+            b = fmaxf(b, mm[((int64_t)k * d + i) * 2 + 1]);
+        }
+        smin[threadIdx.x] = a;
+        smax[threadIdx.x] = b;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if ((int)threadIdx.x < o) {
+                smin[threadIdx.x] = fminf(smin[threadIdx.x], smin[threadIdx.x + o]);
+                smax[threadIdx.x] = fmaxf(smax[threadIdx.x], smax[threadIdx.x + o]);
+            }
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) {
+            out[((int64_t)blockIdx.x * d + i) * 2 + 0] = smin[0];
+            out[((int64_t)blockIdx.x * d + i) * 2 + 1] = smax[0];
+        }
+        __syncthreads();
+    }
+}
+
+// [nb][d][2] ranges -> [d][2]; then the build's scalars into the host's mailbox: {M, err, lo/hi per feature}
 __global__ __launch_bounds__(256) void k_build_info(const float *__restrict__ mm, int nb, int d, const int *__restrict__ m_total,
                                                     const int *__restrict__ err, int *__restrict__ info)
 {
@@ -756,9 +788,11 @@ int phl_build_device(phl_lattice *lat, const float *ref, int64_t rs, int64_t cs,
     PHL_HIP(tmp.get(&wrank, (size_t)NW + 1));
     PHL_HIP(tmp.get(&tile_sums, (size_t)NW / SCAN_TILE + 2));
     PHL_HIP(tmp.get(&err, 1));
-    float *mm;                                       // [blocks of k_elevate][d][2]
+    float *mm, *mm2;                                 // [blocks of k_elevate][d][2], reduced to [MM2][d][2]
     const int nblk = (int)((n + 255) / 256);
+    constexpr int MM2 = 64;
     PHL_HIP(tmp.get(&mm, (size_t)nblk * d * 2));
+    PHL_HIP(tmp.get(&mm2, (size_t)MM2 * d * 2));
     int *info_dev;                                   // {M, err, lo/hi per feature}: written by k_build_info
     constexpr int INFO_N = 2 + 2 * PHL_MAX_D;
     phl_pinned_reset();
@@ -790,7 +824,12 @@ int phl_build_device(phl_lattice *lat, const float *ref, int64_t rs, int64_t cs,
         rc = exclusive_scan(wcount, wrank, NW, tile_sums, st);
         if (rc) return rc;
         // one read-back: the kernel writes straight into pinned host memory where there is some
-        hipLaunchKernelGGL(k_build_info, dim3(1), dim3(256), 0, st, mm, nblk, d, wrank + NW, err, info_pinned ? info_pinned : info_dev);
+        if (nblk > 4 * MM2) {
+            hipLaunchKernelGGL(k_minmax_stage, dim3(MM2), dim3(256), 0, st, mm, nblk, d, mm2);
+            hipLaunchKernelGGL(k_build_info, dim3(1), dim3(256), 0, st, mm2, MM2, d, wrank + NW, err, info_pinned ? info_pinned : info_dev);
+        } else {
+            hipLaunchKernelGGL(k_build_info, dim3(1), dim3(256), 0, st, mm, nblk, d, wrank + NW, err, info_pinned ? info_pinned : info_dev);
+        }
         PHL_HIP(hipGetLastError());
         if (!info_pinned) PHL_HIP(hipMemcpyAsync(info_host, info_dev, sizeof(int) * INFO_N, hipMemcpyDeviceToHost, st));
         PHL_HIP(hipStreamSynchronize(st));
