@@ -211,8 +211,7 @@ __global__ __launch_bounds__(256) void k_chunk_group(const int *__restrict__ pix
     constexpr int HB = SORTN == 2048 ? 12 : (SORTN == 1024 ? 11 : 10);
     static_assert(PER <= 8, "the per-thread digit histogram has 4-bit counts");
     __shared__ unsigned keys[SORTN];       // (dense id << 11) | entry
-    __shared__ int tab[HT + 8];            // slot -> vertex id, then slot -> dense id; later hpos | newidx
-    __shared__ int lvid[SORTN];            // dense id -> vertex id
+    __shared__ int tab[HT + 8];            // slot -> vertex id, then slot -> dense id; later hpos | newidx (shorts)
     __shared__ unsigned wtot[4][8];
     __shared__ int lbin[258];              // histogram over segment lengths 1..P (P <= 256)
     const int c = blockIdx.x;
@@ -260,10 +259,7 @@ __global__ __launch_bounds__(256) void k_chunk_group(const int *__restrict__ pix
         for (int j = 0; j < SPT; j++) {
             const int sidx = threadIdx.x * SPT + j;
             const int v = tab[sidx];
-            if (v >= 0) {
-                lvid[id] = v;
-                tab[sidx] = id++;
-            }
+            if (v >= 0) tab[sidx] = id++;
         }
     }
     __syncthreads();
@@ -332,8 +328,8 @@ __global__ __launch_bounds__(256) void k_chunk_group(const int *__restrict__ pix
     // Local vertices are renumbered by DESCENDING segment length (counting sort in LDS): the
     // splat kernel hands neighbouring local vertices to the lane groups of one wavefront, which
     // then run loops of nearly equal length, and takes groups longest-first.
-    int *hpos = tab;                       // [nv + 1] start position of the segment of dense id j
-    int *newidx = tab + SORTN + 1;         // [nv] dense id -> length-order index
+    unsigned short *hpos = reinterpret_cast<unsigned short *>(tab);   // [nv + 1] start of the segment of dense id j
+    unsigned short *newidx = hpos + SORTN + 2;                         // [nv] dense id -> length-order index
     const int total = nv;
     const int64_t vbase = vptr ? (int64_t)vptr[c] : (int64_t)c * stride;
     const int vcap = vptr ? SORTN : stride;
@@ -342,9 +338,9 @@ __global__ __launch_bounds__(256) void k_chunk_group(const int *__restrict__ pix
 #pragma unroll
     for (int u = 0; u < PER; u++) {
         const int i = i0 + u;
-        if (i < E && (i == 0 || (keys[i] >> 11) != (keys[i - 1] >> 11))) hpos[keys[i] >> 11] = i;
+        if (i < E && (i == 0 || (keys[i] >> 11) != (keys[i - 1] >> 11))) hpos[keys[i] >> 11] = (unsigned short)i;
     }
-    if (threadIdx.x == 0) hpos[total] = E;
+    if (threadIdx.x == 0) hpos[total] = (unsigned short)E;
     __syncthreads();
     for (int j = threadIdx.x; j < total; j += 256) atomicAdd(&lbin[256 - min(hpos[j + 1] - hpos[j], 256)], 1);   // bin 0 = longest
     __syncthreads();
@@ -365,7 +361,7 @@ __global__ __launch_bounds__(256) void k_chunk_group(const int *__restrict__ pix
     }
     __syncthreads();
     for (int j = threadIdx.x; j < total; j += 256)
-        newidx[j] = atomicAdd(&lbin[256 - min(hpos[j + 1] - hpos[j], 256)], 1);
+        newidx[j] = (unsigned short)atomicAdd(&lbin[256 - min(hpos[j + 1] - hpos[j], 256)], 1);
     __syncthreads();
 #pragma unroll
     for (int u = 0; u < PER; u++) {
@@ -374,16 +370,17 @@ __global__ __launch_bounds__(256) void k_chunk_group(const int *__restrict__ pix
         const int li = (int)(keys[i] >> 11);
         const int e = (int)(keys[i] & 2047u);
         const bool head = (i == 0) || li != (int)(keys[i - 1] >> 11);
-        if (head && newidx[li] < vcap) {
-            const int64_t sl = vbase + newidx[li];
-            slot_vert[sl] = lvid[li];
-            seg_rng[sl] = make_int2((int)(ebase + i), (int)(ebase + hpos[li + 1]));
-        }
         const int k = e / dp1, rr = e - k * dp1;
         const int p = pix_order[base + k];
+        const phl_replay_t rp = replay[(int64_t)p * dp1 + rr];
+        if (head && newidx[li] < vcap) {           // (the vertex of a segment: that of its first entry)
+            const int64_t sl = vbase + newidx[li];
+            slot_vert[sl] = rp.vid;
+            seg_rng[sl] = make_int2((int)(ebase + i), (int)(ebase + hpos[li + 1]));
+        }
         phl_contrib_t sg;
         sg.pixel = k;
-        sg.w = replay[(int64_t)p * dp1 + rr].w;
+        sg.w = rp.w;
         seg[ebase + i] = sg;
         lidx[ebase + e] = (unsigned short)newidx[li];
     }
