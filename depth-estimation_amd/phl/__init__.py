@@ -61,7 +61,8 @@ def load_library():
         lib.phl_build_ex.argtypes = [C.POINTER(vp), vp, i64, i32, i64, i64, i32, vp, u32]
         lib.phl_debug_reference_table.argtypes = [vp, vp, i64, i32, i64, vp, i64, C.POINTER(i64), vp, vp, i32,
                                                   C.POINTER(i32), C.POINTER(i32)]
-        lib.phl_debug_probe_paths.argtypes = [vp, i64, i32, vp, i32, vp, i32, C.c_uint64, vp, i32, i32, C.POINTER(i32)]
+        if hasattr(lib, "phl_debug_probe_paths"):       # (test hook; an older build loaded through PHL_LIB lacks it)
+            lib.phl_debug_probe_paths.argtypes = [vp, i64, i32, vp, i32, vp, i32, C.c_uint64, vp, i32, i32, C.POINTER(i32)]
         lib.phl_destroy.argtypes = [vp]
         for name in ("phl_num_pixels", "phl_num_vertices", "phl_device_bytes"):
             getattr(lib, name).restype = i64
