@@ -889,10 +889,19 @@ int phl_build_device(phl_lattice *lat, const float *ref, int64_t rs, int64_t cs,
 // Pixel-sorted contribution lists per vertex (the transpose of `replay`).  Only the
 // reference-exact gather splat (PHL_FILTER_EXACT / fallback shapes) and the introspection calls
 // need them, so they are built on first use, from `replay` alone.
+static int build_csr(phl_lattice *lat, hipStream_t st);
 int phl_ensure_csr(phl_lattice *lat, hipStream_t st)
 {
     std::lock_guard<std::mutex> once(*phl_csr_mutex(lat));     // several threads may filter through one lattice
-    if (lat->csr_ptr && lat->csr) return PHL_OK;
+    if (!(lat->csr_ptr && lat->csr)) {
+        const int rc = build_csr(lat, st);
+        if (rc) return rc;
+    }
+    return phl_tiles_ensure_vorder(lat, st);  // (the gather splat's vertex order: same first use, same lock)
+}
+
+static int build_csr(phl_lattice *lat, hipStream_t st)
+{
     const int M = (int)lat->M, N = (int)lat->N, dp1 = lat->d + 1;
     if (lat->csr_ptr) PHL_HIP(phl_dev_free(lat->csr_ptr));
     if (lat->csr) PHL_HIP(phl_dev_free(lat->csr));
@@ -928,7 +937,6 @@ int phl_ensure_csr(phl_lattice *lat, hipStream_t st)
     PHL_HIP(hipStreamSynchronize(st));  // temporaries go back to the scratch cache
     return PHL_OK;
 }
-
 // Append vertices that exist in a neighbouring row band ("ghosts": no local contributions, so
 // their splat lists are empty) and return the local id of every queried key.  Keys must be
 // distinct.  Used by the row-band multi-GPU path; rebuilds the table and the neighbour ids.

@@ -140,6 +140,7 @@ int phl_apply_reference_table(phl_lattice *lat, hipStream_t st);
 // replay[].vid from the build-time tables (see bt_* above), mapped through int_of_ft if there is one; releases nothing
 int phl_write_final_vids(phl_lattice *lat, hipStream_t st);
 void phl_release_build_tables(phl_lattice *lat);          // (after a stream synchronisation)
+int phl_tiles_ensure_vorder(phl_lattice *lat, hipStream_t st);   // caller holds the lattice's list lock (phl_ensure_csr)
 // Pinned, device-visible host memory for the build's read-backs (thread-local bump arena).  hipMemcpyAsync into pageable
 // memory blocks the host until the copy has run -- a stream synchronisation per read-back; into this it does not, and
 // kernels may write into it directly.  phl_pinned_reset() at the start of a build; phl_pinned_alloc() returns null when

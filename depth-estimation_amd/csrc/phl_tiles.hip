@@ -155,23 +155,6 @@ __global__ __launch_bounds__(256) void k_relabel_replay(phl_replay_t *__restrict
     if (e < N) replay[e].vid = int_of_ft[replay[e].vid];
 }
 
-// vertex of every slot without the sole mark: the sort key of the vertex -> slots lists
-__global__ __launch_bounds__(256) void k_slot_keys(const int *__restrict__ slot_vert, int S, int *__restrict__ key)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < S) key[i] = slot_vert[i] & 0x7FFFFFFF;
-}
-
-__global__ __launch_bounds__(256) void k_perm_to_contrib(const int *__restrict__ perm, int n, phl_contrib_t *__restrict__ out)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    phl_contrib_t c;
-    c.pixel = perm[i];
-    c.w = 0.f;
-    out[i] = c;
-}
-
 // ---- per-chunk structure: one workgroup groups the chunk's entries by vertex in LDS ----------------
 // entry e = k*(d+1)+r of the chunk (k-th pixel in chunk order, remainder r).  Wanted: the entries grouped by vertex
 // with ascending e inside a group, i.e. ascending pixel: exactly the per-vertex segment the splat needs.
@@ -431,16 +414,31 @@ __global__ __launch_bounds__(256) void k_count_slots(const int *__restrict__ slo
     if (s < S) atomicAdd(&cnt[slot_vert[s]], 1);
 }
 
-// mark slots whose vertex has no other chunk (sole) and flag the others for the partial buffer
-__global__ __launch_bounds__(256) void k_mark_sole(int *__restrict__ slot_vert, int S, const int *__restrict__ vs_ptr,
-                                                   int *__restrict__ multi)
+// the vertex -> slots list entries from the sort's permutation, and the slots' marks: bit 31 of slot_vert = this chunk is
+// the vertex's only contributor (sole); the others are flagged for the partial buffer
+__global__ __launch_bounds__(256) void k_contrib_and_sole(const int *__restrict__ perm, int *__restrict__ slot_vert, int S,
+                                                          const int *__restrict__ vs_ptr, phl_contrib_t *__restrict__ vs,
+                                                          int *__restrict__ multi)
 {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= S) return;
+    phl_contrib_t c;
+    c.pixel = perm[s];
+    c.w = 0.f;
+    vs[s] = c;
     const int v = slot_vert[s];
     const bool sole = (vs_ptr[v + 1] - vs_ptr[v]) == 1;
     if (sole) slot_vert[s] = v | (int)0x80000000;
     multi[s] = sole ? 0 : 1;
+}
+
+// vertices fed by more than `long_list` chunks, appended in any order (k_splat_reduce_long gives each its own
+// workgroup; the order only decides which starts first -- lists of more than 64 are sorted by length afterwards)
+__global__ __launch_bounds__(256) void k_append_long(const int *__restrict__ vs_ptr, int M, int long_list, int *__restrict__ vlong,
+                                                     int *__restrict__ count)
+{
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v < M && vs_ptr[v + 1] - vs_ptr[v] > long_list) vlong[atomicAdd(count, 1)] = v;
 }
 
 // ---- hot kernels -----------------------------------------------------------------------------
@@ -1368,19 +1366,6 @@ __global__ __launch_bounds__(256) void k_gather_i32(const int *__restrict__ src,
     if (i < n) dst[i] = src[perm[i]];
 }
 
-__global__ __launch_bounds__(256) void k_flag_long(const int *__restrict__ vs_ptr, int M, int long_list, int *__restrict__ flag)
-{
-    const int v = blockIdx.x * blockDim.x + threadIdx.x;
-    if (v < M) flag[v] = (vs_ptr[v + 1] - vs_ptr[v] > long_list) ? 1 : 0;
-}
-
-__global__ __launch_bounds__(256) void k_compact_flagged(const int *__restrict__ flag, const int *__restrict__ rank, int M,
-                                                         int *__restrict__ out)
-{
-    const int v = blockIdx.x * blockDim.x + threadIdx.x;
-    if (v < M && flag[v]) out[rank[v]] = v;
-}
-
 // vertex processing order for the gather splat: vertices sorted by the first chunk that touches
 // them, so that vertices summed at the same time read the same few chunks' pixel rows (L2 hits
 // instead of Infinity-Cache traffic).  first[s] = 1 iff slot s is the first slot of its vertex.
@@ -1665,6 +1650,34 @@ int phl_tiles_free(phl_lattice *lat)
 
 // vertex -> slots lists (ascending slot = ascending chunk), sole marks and partial-row indices.
 // Also called after ghost vertices were appended (M grew, the slots did not change).
+// Vertex processing order of the gather splat (exact arithmetic, shapes the chunk kernels do not take): made on first
+// use, under the same lock as the contribution lists (phl_ensure_csr).
+int phl_tiles_ensure_vorder(phl_lattice *lat, hipStream_t st)
+{
+    if (lat->vorder || !lat->vs_ptr || !lat->vs || !lat->slot_vert) return PHL_OK;
+    const int M = (int)lat->M, S = (int)lat->S;
+    if (M == 0 || S == 0) return PHL_OK;
+    temp_pool tmp;
+    int *first, *frank, *tile_sums;
+    PHL_HIP(tmp.get(&first, (size_t)S + 1));
+    PHL_HIP(tmp.get(&frank, (size_t)S + 2));
+    PHL_HIP(tmp.get(&tile_sums, (size_t)S / SCAN_TILE + 2));
+    int *vorder = nullptr;
+    PHL_HIP(phl_dev_malloc((void **)&vorder, sizeof(int) * ((size_t)M + 1)));
+    const unsigned gS = (unsigned)((S + 255) / 256);
+    hipLaunchKernelGGL(k_first_slot, dim3(gS), dim3(256), 0, st, lat->slot_vert, S, lat->vs_ptr, lat->vs, first);
+    PHL_HIP(hipGetLastError());
+    const int rc = exclusive_scan(first, frank, S, tile_sums, st);
+    if (rc) return rc;
+    const int span = S > M ? S : M;
+    hipLaunchKernelGGL(k_fill_vorder, dim3((span + 255) / 256), dim3(256), 0, st, lat->slot_vert, S, first, frank,
+                       (int)lat->M_local, M, vorder);
+    PHL_HIP(hipGetLastError());
+    PHL_HIP(hipStreamSynchronize(st));      // temporaries go back to the scratch cache
+    lat->vorder = vorder;
+    return PHL_OK;
+}
+
 int phl_tiles_link_vertices(phl_lattice *lat, hipStream_t st)
 {
     const int M = (int)lat->M, S = (int)lat->S;
@@ -1685,11 +1698,10 @@ int phl_tiles_link_vertices(phl_lattice *lat, hipStream_t st)
         return PHL_OK;
     }
     temp_pool tmp;
-    int *cnt, *multi, *tile_sums, *skey, *sperm;
+    int *cnt, *multi, *tile_sums, *sperm;
     PHL_HIP(tmp.get(&cnt, (size_t)M + 1));
     PHL_HIP(tmp.get(&multi, (size_t)S + 1));
     PHL_HIP(tmp.get(&tile_sums, (size_t)(S > M ? S : M) / SCAN_TILE + 2));
-    PHL_HIP(tmp.get(&skey, (size_t)S));
     PHL_HIP(tmp.get(&sperm, (size_t)S));
     PHL_HIP(hipMemsetAsync(cnt, 0, sizeof(int) * ((size_t)M + 1), st));
     const unsigned gS = (unsigned)((S + 255) / 256);
@@ -1698,13 +1710,11 @@ int phl_tiles_link_vertices(phl_lattice *lat, hipStream_t st)
     PHL_HIP(hipGetLastError());
     int rc = exclusive_scan(cnt, lat->vs_ptr, M, tile_sums, st);
     if (rc) return rc;
-    // slots grouped by vertex, ascending slot (= ascending chunk) inside a vertex: a stable sort by vertex id
-    hipLaunchKernelGGL(k_slot_keys, dim3(gS), dim3(256), 0, st, lat->slot_vert, S, skey);
-    PHL_HIP(hipGetLastError());
-    rc = stable_sort_perm(skey, S, M, sperm, tmp, st);
+    // slots grouped by vertex, ascending slot (= ascending chunk) inside a vertex: a stable sort by vertex id (the
+    // marks are stripped: slot_vert itself is the key array)
+    rc = stable_sort_perm(lat->slot_vert, S, M, sperm, tmp, st);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_perm_to_contrib, dim3(gS), dim3(256), 0, st, sperm, S, lat->vs);
-    hipLaunchKernelGGL(k_mark_sole, dim3(gS), dim3(256), 0, st, lat->slot_vert, S, lat->vs_ptr, multi);
+    hipLaunchKernelGGL(k_contrib_and_sole, dim3(gS), dim3(256), 0, st, sperm, lat->slot_vert, S, lat->vs_ptr, lat->vs, multi);
     PHL_HIP(hipGetLastError());
     rc = exclusive_scan(multi, lat->slot_pidx, S, tile_sums, st);
     if (rc) return rc;
@@ -1714,41 +1724,23 @@ int phl_tiles_link_vertices(phl_lattice *lat, hipStream_t st)
     int *counts = (int *)phl_pinned_alloc(sizeof(int) * 2);          // {S_multi, n_long}
     if (!counts) counts = pageable_counts;
     PHL_HIP(hipMemcpyAsync(&counts[0], lat->slot_pidx + S, sizeof(int), hipMemcpyDeviceToHost, st));
-    // vertices with long slot lists (k_splat_reduce_long): flag, scan, compact
+    // vertices with long slot lists (k_splat_reduce_long)
     int n_long = 0;
     if (lat->vlong) PHL_HIP(phl_dev_free(lat->vlong));
     lat->vlong = nullptr;
     lat->n_long = 0;
     {
-        int *lflag, *lrank;
-        PHL_HIP(tmp.get(&lflag, (size_t)M + 1));
-        PHL_HIP(tmp.get(&lrank, (size_t)M + 2));
-        hipLaunchKernelGGL(k_flag_long, dim3((M + 255) / 256), dim3(256), 0, st, lat->vs_ptr, M, LONG_LIST, lflag);
-        PHL_HIP(hipGetLastError());
-        rc = exclusive_scan(lflag, lrank, M, tile_sums, st);
-        if (rc) return rc;
-        PHL_HIP(hipMemcpyAsync(&counts[1], lrank + M, sizeof(int), hipMemcpyDeviceToHost, st));
+        int *lcount;
+        PHL_HIP(tmp.get(&lcount, 1));
+        PHL_HIP(hipMemsetAsync(lcount, 0, sizeof(int), st));
         PHL_HIP(phl_dev_malloc((void **)&lat->vlong, sizeof(int) * ((size_t)M + 1)));      // worst case; usually almost empty
-        hipLaunchKernelGGL(k_compact_flagged, dim3((M + 255) / 256), dim3(256), 0, st, lflag, lrank, M, lat->vlong);
+        hipLaunchKernelGGL(k_append_long, dim3((M + 255) / 256), dim3(256), 0, st, lat->vs_ptr, M, LONG_LIST, lat->vlong, lcount);
         PHL_HIP(hipGetLastError());
+        PHL_HIP(hipMemcpyAsync(&counts[1], lcount, sizeof(int), hipMemcpyDeviceToHost, st));
     }
-    // chunk-major vertex order for the gather splat
+    // (the chunk-major vertex order of the gather splat is made on first use: phl_tiles_ensure_vorder)
     if (lat->vorder) PHL_HIP(phl_dev_free(lat->vorder));
     lat->vorder = nullptr;
-    PHL_HIP(phl_dev_malloc((void **)&lat->vorder, sizeof(int) * ((size_t)M + 1)));
-    {
-        int *first, *frank;
-        PHL_HIP(tmp.get(&first, (size_t)S + 1));
-        PHL_HIP(tmp.get(&frank, (size_t)S + 2));
-        hipLaunchKernelGGL(k_first_slot, dim3(gS), dim3(256), 0, st, lat->slot_vert, S, lat->vs_ptr, lat->vs, first);
-        PHL_HIP(hipGetLastError());
-        rc = exclusive_scan(first, frank, S, tile_sums, st);
-        if (rc) return rc;
-        const int span = S > M ? S : M;
-        hipLaunchKernelGGL(k_fill_vorder, dim3((span + 255) / 256), dim3(256), 0, st, lat->slot_vert, S, first, frank,
-                           (int)lat->M_local, M, lat->vorder);
-        PHL_HIP(hipGetLastError());
-    }
     PHL_HIP(hipStreamSynchronize(st));
     const int s_multi = counts[0];
     n_long = counts[1];
