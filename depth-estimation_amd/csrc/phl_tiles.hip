@@ -195,7 +195,7 @@ __global__ __launch_bounds__(256) void k_chunk_group(const int *__restrict__ pix
     static_assert(PER <= 8, "the per-thread digit histogram has 4-bit counts");
     __shared__ unsigned keys[SORTN];       // (dense id << 11) | entry
     __shared__ int tab[HT + 8];            // slot -> vertex id, then slot -> dense id; later hpos | newidx (shorts)
-    __shared__ int cv[256];                // vertex ids in slot order (chunks with <= 256 local vertices), then their ranks
+    __shared__ int lvid[SORTN];            // dense id -> vertex id
     __shared__ unsigned wtot[4][8];
     __shared__ int lbin[258];              // histogram over segment lengths 1..P (P <= 256)
     const int c = blockIdx.x;
@@ -244,34 +244,12 @@ __global__ __launch_bounds__(256) void k_chunk_group(const int *__restrict__ pix
             const int sidx = threadIdx.x * SPT + j;
             const int v = tab[sidx];
             if (v >= 0) {
-                if (id < 256) cv[id] = v;
+                lvid[id] = v;
                 tab[sidx] = id++;
             }
         }
     }
     __syncthreads();
-    // Dense ids in ascending vertex order where that is cheap (<= 256 local vertices: every image chunk): slot order
-    // depends on which of two colliding keys reached a slot first, vertex order does not -- two builds of one `ref`
-    // give the same chunk lists -- and vertices of equal segment length keep neighbouring rows of `vert` next to each
-    // other in the splat's work list.  Rank by counting: nv broadcast reads per vertex.
-    if (nv <= 256 && nv > 1) {
-        int rank = 0;
-        if ((int)threadIdx.x < nv) {
-            const int mine = cv[threadIdx.x];
-            for (int j = 0; j < nv; j++) rank += cv[j] < mine ? 1 : 0;
-        }
-        __syncthreads();
-        if ((int)threadIdx.x < nv) cv[threadIdx.x] = rank;           // slot-order id -> vertex-order id
-        __syncthreads();
-        constexpr int SPT = HT / 256;
-#pragma unroll
-        for (int j = 0; j < SPT; j++) {
-            const int sidx = threadIdx.x * SPT + j;
-            const int v = tab[sidx];
-            if (v >= 0) tab[sidx] = cv[v];
-        }
-        __syncthreads();
-    }
     if (nv_out && threadIdx.x == 0) nv_out[c] = nv;
     if (!WRITE) return;
     unsigned r[PER];
@@ -381,15 +359,14 @@ __global__ __launch_bounds__(256) void k_chunk_group(const int *__restrict__ pix
         const bool head = (i == 0) || li != (int)(keys[i - 1] >> 11);
         const int k = e / dp1, rr = e - k * dp1;
         const int p = pix_order[base + k];
-        const phl_replay_t rp = replay[(int64_t)p * dp1 + rr];
-        if (head && newidx[li] < vcap) {           // (the vertex of a segment: that of its first entry)
+        if (head && newidx[li] < vcap) {
             const int64_t sl = vbase + newidx[li];
-            slot_vert[sl] = rp.vid;
+            slot_vert[sl] = lvid[li];
             seg_rng[sl] = make_int2((int)(ebase + i), (int)(ebase + hpos[li + 1]));
         }
         phl_contrib_t sg;
         sg.pixel = k;
-        sg.w = rp.w;
+        sg.w = replay[(int64_t)p * dp1 + rr].w;
         seg[ebase + i] = sg;
         lidx[ebase + e] = (unsigned short)newidx[li];
     }
