@@ -3,10 +3,16 @@ import collections
 import csv
 import glob
 import json
+import os
 import shutil
 import sys
 
 tag, stats_dir, exact_dir, pmc_prefix = sys.argv[1:5]
+
+
+def newest(pattern):
+    """gpurun_out/ keeps the files of earlier calls with the same tag: take the latest run's"""
+    return max(glob.glob(pattern), key=os.path.getmtime)
 
 
 def short(n):
@@ -15,7 +21,7 @@ def short(n):
 
 
 def stats(dirn, out):
-    f = glob.glob(f'gpurun_out/{dirn}/*/*kernel_stats.csv')[0]
+    f = newest(f'gpurun_out/{dirn}/*/*kernel_stats.csv')
     rows = list(csv.DictReader(open(f)))
     with open(out, 'w') as fo:
         w = csv.writer(fo)
@@ -31,7 +37,7 @@ for x in stats(exact_dir, f'profiles/{tag}_bench_c3_exact_kernel_stats.csv')[:3]
     print('exact', short(x['Name']), x['Calls'], round(float(x['AverageNs']) / 1e3, 1), 'us')
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for d in ('FETCH_SIZE', 'WRITE_SIZE', 'TCC_HIT_sum'):
-    f = glob.glob(f'gpurun_out/{pmc_prefix}_{d}/*/*counter_collection.csv')[0]
+    f = newest(f'gpurun_out/{pmc_prefix}_{d}/*/*counter_collection.csv')
     for row in csv.DictReader(open(f)):
         n = short(row['Kernel_Name'])
         if n.startswith('k_'):
@@ -61,7 +67,7 @@ if glob.glob(f'gpurun_out/prof_{tag}_mf/*/*kernel_stats.csv'):
         print('mean-field', short(x['Name']), x['Calls'], round(float(x['AverageNs']) / 1e3, 1), 'us')
     mf = collections.defaultdict(lambda: collections.defaultdict(list))
     for d in ('FETCH_SIZE', 'WRITE_SIZE'):
-        for f in glob.glob(f'gpurun_out/pmc_{tag}_mf_{d}/*/*counter_collection.csv'):
+        for f in [newest(f'gpurun_out/pmc_{tag}_mf_{d}/*/*counter_collection.csv')]:
             for row in csv.DictReader(open(f)):
                 n = short(row['Kernel_Name'])
                 if n.startswith('k_compat'):
