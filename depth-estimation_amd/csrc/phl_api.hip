@@ -291,7 +291,8 @@ struct pinned_arena {
     char *base = nullptr;
     size_t cap = 0, off = 0, wanted = 0;
 };
-thread_local pinned_arena t_pinned;     // (never freed: a thread's exit may come after the runtime has shut down)
+thread_local pinned_arena t_pinned;     // (never freed: a thread's exit may come after the runtime has shut down;
+                                        //  portable: one thread may build on several devices in turn)
 }  // namespace
 
 void phl_pinned_reset()
@@ -304,7 +305,7 @@ void phl_pinned_reset()
             a.base = nullptr;
             a.cap = 0;
             void *p = nullptr;
-            if (hipHostMalloc(&p, want, hipHostMallocMapped) == hipSuccess) {
+            if (hipHostMalloc(&p, want, hipHostMallocMapped | hipHostMallocPortable) == hipSuccess) {
                 a.base = (char *)p;
                 a.cap = want;
             } else {
