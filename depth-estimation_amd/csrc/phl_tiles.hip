@@ -183,8 +183,11 @@ __global__ __launch_bounds__(256) void k_chunk_group(const int *__restrict__ pix
                                                      const phl_replay_t *__restrict__ replay, int *__restrict__ nv_out,
                                                      const int *__restrict__ vptr, int stride, int *__restrict__ slot_vert,
                                                      int2 *__restrict__ seg_rng, phl_contrib_t *__restrict__ seg,
-                                                     unsigned short *__restrict__ lidx)
+                                                     unsigned short *__restrict__ lidx, const int *__restrict__ nv_known,
+                                                     int skip_le)
 {
+    // nv_known: the chunks' vertex counts from k_chunk_masks -- chunks with at most skip_le are done already
+    if (nv_known && nv_known[blockIdx.x] <= skip_le) return;
     // vptr != null: slots go to their final place vptr[c] + local index.  vptr == null (first and
     // normally only pass): slots go to a scratch area with a fixed `stride` per chunk (local indices
     // beyond it are dropped -- the host then repeats the pass with the real offsets), and the number of
@@ -369,6 +372,179 @@ __global__ __launch_bounds__(256) void k_chunk_group(const int *__restrict__ pix
         sg.w = replay[(int64_t)p * dp1 + rr].w;
         seg[ebase + i] = sg;
         lidx[ebase + e] = (unsigned short)newidx[li];
+    }
+}
+
+// The same grouping without a sort, for chunks with at most NVC distinct vertices (every chunk of an image): a pixel
+// holds a vertex at most once (the d+1 vertices of a simplex are distinct), so a local vertex's segment is a SET of chunk
+// pixels -- one bit per pixel, eight words per vertex (P <= 256), set with one LDS atomic per entry.  An entry's place in
+// its segment is the number of set bits below its pixel (a per-word prefix per vertex + one popcount), the segment's
+// start the scan of the segment lengths.  ~400 vector instructions a wavefront where the radix passes of k_chunk_group
+// take ~1,700 (the kernel is bound by instruction issue).  A chunk with more vertices only reports its count; the host
+// then runs k_chunk_group on those chunks.
+constexpr int NVC = 512;
+
+template <int SORTN>
+__global__ __launch_bounds__(256) void k_chunk_masks(const int *__restrict__ pix_order, int n, int P, int dp1,
+                                                     const phl_replay_t *__restrict__ replay, int *__restrict__ nv_out,
+                                                     const int *__restrict__ vptr, int stride, int *__restrict__ slot_vert,
+                                                     int2 *__restrict__ seg_rng, phl_contrib_t *__restrict__ seg,
+                                                     unsigned short *__restrict__ lidx)
+{
+    constexpr int PER = SORTN / 256;       // consecutive entries owned by a thread
+    constexpr int HT = 2 * SORTN;          // hash slots (load <= 1/2)
+    constexpr int HB = SORTN == 2048 ? 12 : (SORTN == 1024 ? 11 : 10);
+    constexpr int TABN = (HT > NVC * 8 ? HT : NVC * 8) + 8;
+    __shared__ int tab[TABN];              // slot -> vertex id, then slot -> dense id; then the pixel masks [nv][8]
+    __shared__ int lvid[NVC];              // dense id -> vertex id
+    __shared__ unsigned short cum[NVC][8]; // set bits of a vertex's mask below word w
+    __shared__ unsigned short startv[NVC + 2];   // segment start of dense id j (entries), [nv] = E
+    __shared__ unsigned short newidx[NVC]; // dense id -> length-order index
+    __shared__ int lbin[258];              // histogram over segment lengths 1..P (P <= 256)
+    const int c = blockIdx.x;
+    const int base = c * P;
+    const int cnt = min(P, n - base);
+    const int E = cnt * dp1;
+    const int i0 = threadIdx.x * PER;
+    for (int j = threadIdx.x; j < HT; j += 256) tab[j] = -1;
+    int vid[PER], kk[PER], rrr[PER];
+    float wgt[PER];
+    {
+        int k = i0 / dp1, rr = i0 - k * dp1;
+#pragma unroll
+        for (int u = 0; u < PER; u++) {
+            vid[u] = -1;
+            wgt[u] = 0.f;
+            kk[u] = k;
+            rrr[u] = rr;
+            if (i0 + u < E) {
+                const int p = pix_order[base + k];
+                const phl_replay_t rp = replay[(int64_t)p * dp1 + rr];
+                vid[u] = rp.vid;
+                wgt[u] = rp.w;
+            }
+            if (++rr == dp1) { rr = 0; k++; }
+        }
+    }
+    __syncthreads();
+    int slot[PER];
+#pragma unroll
+    for (int u = 0; u < PER; u++) {
+        slot[u] = 0;
+        if (vid[u] >= 0) {
+            unsigned h = ((unsigned)vid[u] * 2654435761u) >> (32 - HB);
+            for (;;) {
+                const int prev = atomicCAS(&tab[h], -1, vid[u]);
+                if (prev == -1 || prev == vid[u]) break;
+                h = (h + 1) & (HT - 1);
+            }
+            slot[u] = (int)h;
+        }
+    }
+    __syncthreads();
+    int nv;
+    {
+        constexpr int SPT = HT / 256;      // slots owned by a thread
+        int occ = 0;
+#pragma unroll
+        for (int j = 0; j < SPT; j++) occ += tab[threadIdx.x * SPT + j] >= 0 ? 1 : 0;
+        int id = block_exclusive_scan(occ, &nv);
+#pragma unroll
+        for (int j = 0; j < SPT; j++) {
+            const int sidx = threadIdx.x * SPT + j;
+            const int v = tab[sidx];
+            if (v >= 0) {
+                if (id < NVC) lvid[id] = v;
+                tab[sidx] = id++;
+            }
+        }
+    }
+    __syncthreads();
+    if (nv_out && threadIdx.x == 0) nv_out[c] = nv;
+    if (nv > NVC) return;                  // (workgroup-uniform) left to k_chunk_group
+    int id[PER];
+#pragma unroll
+    for (int u = 0; u < PER; u++) id[u] = vid[u] >= 0 ? tab[slot[u]] : 0;
+    __syncthreads();                       // tab is dead: the masks take its place
+    unsigned *mask = reinterpret_cast<unsigned *>(tab);
+    for (int j = threadIdx.x; j < nv * 8; j += 256) mask[j] = 0u;
+    for (int j = threadIdx.x; j < 258; j += 256) lbin[j] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < PER; u++)
+        if (vid[u] >= 0) atomicOr(&mask[id[u] * 8 + (kk[u] >> 5)], 1u << (kk[u] & 31));
+    __syncthreads();
+    // per vertex: prefix of set bits per word, segment length
+    int len2[2] = {0, 0};
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+        const int v = 2 * (int)threadIdx.x + t;            // (two consecutive vertices a thread: the scan below is over ids)
+        if (v < nv) {
+            int run = 0;
+#pragma unroll
+            for (int w = 0; w < 8; w++) {
+                cum[v][w] = (unsigned short)run;
+                run += __popc(mask[v * 8 + w]);
+            }
+            len2[t] = run;
+            atomicAdd(&lbin[256 - min(run, 256)], 1);      // bin 0 = longest
+        }
+    }
+    {
+        int tot;
+        const int ex = block_exclusive_scan(len2[0] + len2[1], &tot);
+        const int v = 2 * (int)threadIdx.x;
+        if (v < nv) startv[v] = (unsigned short)ex;
+        if (v + 1 < nv) startv[v + 1] = (unsigned short)(ex + len2[0]);
+        if (threadIdx.x == 0) startv[nv] = (unsigned short)E;
+    }
+    __syncthreads();
+    // Local vertices are renumbered by DESCENDING segment length (counting sort in LDS): the
+    // splat kernel hands neighbouring local vertices to the lane groups of one wavefront, which
+    // then run loops of nearly equal length, and takes groups longest-first.
+    if (threadIdx.x < 64) {           // exclusive scan of the 257 bins by one wavefront
+        int carry = 0;
+        for (int b0 = 0; b0 < 257; b0 += 64) {
+            const int b = b0 + (int)threadIdx.x;
+            const int x = b < 257 ? lbin[b] : 0;
+            int incl = x;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int y = __shfl_up(incl, o);
+                if ((int)threadIdx.x >= o) incl += y;
+            }
+            if (b < 257) lbin[b] = carry + incl - x;
+            carry += __shfl(incl, 63);
+        }
+    }
+    __syncthreads();
+    const int64_t vbase = vptr ? (int64_t)vptr[c] : (int64_t)c * stride;
+    const int vcap = vptr ? SORTN : stride;
+    const int64_t ebase = (int64_t)base * dp1;
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+        const int v = 2 * (int)threadIdx.x + t;
+        if (v < nv) {
+            const int ni = atomicAdd(&lbin[256 - min(len2[t], 256)], 1);
+            newidx[v] = (unsigned short)ni;
+            if (ni < vcap) {
+                const int64_t sl = vbase + ni;
+                slot_vert[sl] = lvid[v];
+                seg_rng[sl] = make_int2((int)(ebase + startv[v]), (int)(ebase + startv[v] + len2[t]));
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < PER; u++) {
+        if (vid[u] < 0) continue;
+        const int v = id[u], k = kk[u];
+        const int pos = (int)startv[v] + (int)cum[v][k >> 5] + __popc(mask[v * 8 + (k >> 5)] & ((1u << (k & 31)) - 1u));
+        phl_contrib_t sg;
+        sg.pixel = k;
+        sg.w = wgt[u];
+        seg[ebase + pos] = sg;
+        lidx[ebase + i0 + u] = newidx[v];
     }
 }
 
@@ -1901,6 +2077,12 @@ int phl_tiles_build(phl_lattice *lat, const float *ref, int64_t rs, int64_t cs, 
     int *nv;
     PHL_HIP(tmp.get(&nv, (size_t)nchunks + 1));
     PHL_HIP(phl_dev_malloc((void **)&lat->chunk_vptr, sizeof(int) * ((size_t)nchunks + 1)));
+#define PHL_CHUNK_MASKS(...)                                                                                       \
+    switch (sortn) {                                                                                                \
+        case 512: hipLaunchKernelGGL((k_chunk_masks<512>), dim3(nchunks), dim3(256), 0, st, __VA_ARGS__); break;     \
+        case 1024: hipLaunchKernelGGL((k_chunk_masks<1024>), dim3(nchunks), dim3(256), 0, st, __VA_ARGS__); break;   \
+        default: hipLaunchKernelGGL((k_chunk_masks<2048>), dim3(nchunks), dim3(256), 0, st, __VA_ARGS__); break;     \
+    }
 #define PHL_CHUNK_SORT(WRITE_, ...)                                                                                      \
     switch (sortn) {                                                                                                      \
         case 512: hipLaunchKernelGGL((k_chunk_group<512, WRITE_>), dim3(nchunks), dim3(256), 0, st, __VA_ARGS__); break;   \
@@ -1917,8 +2099,16 @@ int phl_tiles_build(phl_lattice *lat, const float *ref, int64_t rs, int64_t cs, 
     PHL_HIP(tmp.get(&t_rng, (size_t)nchunks * SLOT_STRIDE));
     PHL_HIP(phl_dev_malloc((void **)&lat->seg, sizeof(phl_contrib_t) * (size_t)N));
     PHL_HIP(phl_dev_malloc((void **)&lat->lidx, sizeof(unsigned short) * (size_t)N));
-    PHL_CHUNK_SORT(true, lat->pix_order, n, P, dp1, lat->replay, nv, (const int *)nullptr, SLOT_STRIDE, t_vert, t_rng,
-                   lat->seg, lat->lidx)
+    // k_chunk_masks does every chunk with at most NVC (> SLOT_STRIDE) local vertices; heavier ones only report their
+    // count here and are done by k_chunk_group in the repeated pass below
+    static const bool use_masks = !(getenv("PHL_CHUNK_MASKS") && atoi(getenv("PHL_CHUNK_MASKS")) == 0);
+    if (use_masks) {
+        PHL_CHUNK_MASKS(lat->pix_order, n, P, dp1, lat->replay, nv, (const int *)nullptr, SLOT_STRIDE, t_vert, t_rng, lat->seg,
+                        lat->lidx)
+    } else {
+        PHL_CHUNK_SORT(true, lat->pix_order, n, P, dp1, lat->replay, nv, (const int *)nullptr, SLOT_STRIDE, t_vert, t_rng,
+                       lat->seg, lat->lidx, (const int *)nullptr, 0)
+    }
     PHL_HIP(hipGetLastError());
     rc = exclusive_scan(nv, lat->chunk_vptr, nchunks, tile_sums, st);
     if (rc) return rc;
@@ -1957,10 +2147,20 @@ int phl_tiles_build(phl_lattice *lat, const float *ref, int64_t rs, int64_t cs, 
         hipLaunchKernelGGL(k_compact_slots, dim3(nchunks), dim3(256), 0, st, lat->chunk_vptr, nchunks, SLOT_STRIDE, t_vert,
                            t_rng, lat->slot_vert, lat->seg_rng);
     } else {
-        PHL_CHUNK_SORT(true, lat->pix_order, n, P, dp1, lat->replay, (int *)nullptr, lat->chunk_vptr, 0, lat->slot_vert,
-                       lat->seg_rng, lat->seg, lat->lidx)
+        if (use_masks) {
+            PHL_CHUNK_MASKS(lat->pix_order, n, P, dp1, lat->replay, (int *)nullptr, lat->chunk_vptr, 0, lat->slot_vert,
+                            lat->seg_rng, lat->seg, lat->lidx)
+            if (nv_max > NVC) {
+                PHL_CHUNK_SORT(true, lat->pix_order, n, P, dp1, lat->replay, (int *)nullptr, lat->chunk_vptr, 0, lat->slot_vert,
+                               lat->seg_rng, lat->seg, lat->lidx, (const int *)nv, NVC)
+            }
+        } else {
+            PHL_CHUNK_SORT(true, lat->pix_order, n, P, dp1, lat->replay, (int *)nullptr, lat->chunk_vptr, 0, lat->slot_vert,
+                           lat->seg_rng, lat->seg, lat->lidx, (const int *)nullptr, 0)
+        }
     }
 #undef PHL_CHUNK_SORT
+#undef PHL_CHUNK_MASKS
     PHL_HIP(hipGetLastError());
     PHL_HIP(hipStreamSynchronize(st));
     }
