@@ -382,9 +382,9 @@ __global__ __launch_bounds__(256) void k_chunk_group(const int *__restrict__ pix
 // start the scan of the segment lengths.  ~400 vector instructions a wavefront where the radix passes of k_chunk_group
 // take ~1,700 (the kernel is bound by instruction issue).  A chunk with more vertices only reports its count; the host
 // then runs k_chunk_group on those chunks.
-constexpr int NVC = 512;
+constexpr int NVC = 256;               // (the kernel waits on LDS / L2 round trips: a small footprint buys workgroups per CU)
 
-template <int SORTN>
+template <int SORTN, int HTX>
 __global__ __launch_bounds__(256) void k_chunk_masks(const int *__restrict__ pix_order, int n, int P, int dp1,
                                                      const phl_replay_t *__restrict__ replay, int *__restrict__ nv_out,
                                                      const int *__restrict__ vptr, int stride, int *__restrict__ slot_vert,
@@ -392,12 +392,12 @@ __global__ __launch_bounds__(256) void k_chunk_masks(const int *__restrict__ pix
                                                      unsigned short *__restrict__ lidx)
 {
     constexpr int PER = SORTN / 256;       // consecutive entries owned by a thread
-    constexpr int HT = 2 * SORTN;          // hash slots (load <= 1/2)
-    constexpr int HB = SORTN == 2048 ? 12 : (SORTN == 1024 ? 11 : 10);
+    constexpr int HT = HTX * SORTN;        // hash slots: load <= 3/4 (the host picks HTX = 2 where P(d+1) > 3/4 SORTN)
+    constexpr int HB = (SORTN == 2048 ? 11 : (SORTN == 1024 ? 10 : 9)) + (HTX == 2 ? 1 : 0);
     constexpr int TABN = (HT > NVC * 8 ? HT : NVC * 8) + 8;
-    __shared__ int tab[TABN];              // slot -> vertex id, then slot -> dense id; then the pixel masks [nv][8]
+    __shared__ __attribute__((aligned(16))) int tab[TABN];   // slot -> vertex id, then slot -> dense id; then the pixel masks [nv][8]
     __shared__ int lvid[NVC];              // dense id -> vertex id
-    __shared__ unsigned short cum[NVC][8]; // set bits of a vertex's mask below word w
+    __shared__ __attribute__((aligned(8))) unsigned char cum[NVC][8];   // set bits of a vertex's mask below word w (<= 224)
     __shared__ unsigned short startv[NVC + 2];   // segment start of dense id j (entries), [nv] = E
     __shared__ unsigned short newidx[NVC]; // dense id -> length-order index
     __shared__ int lbin[258];              // histogram over segment lengths 1..P (P <= 256)
@@ -474,28 +474,25 @@ __global__ __launch_bounds__(256) void k_chunk_masks(const int *__restrict__ pix
     for (int u = 0; u < PER; u++)
         if (vid[u] >= 0) atomicOr(&mask[id[u] * 8 + (kk[u] >> 5)], 1u << (kk[u] & 31));
     __syncthreads();
-    // per vertex: prefix of set bits per word, segment length
-    int len2[2] = {0, 0};
+    // per vertex (thread v): prefix of set bits per word, segment length
+    int len = 0;
+    if ((int)threadIdx.x < nv) {
+        const int v = threadIdx.x;
+        const uint4 m0 = *reinterpret_cast<const uint4 *>(mask + v * 8), m1 = *reinterpret_cast<const uint4 *>(mask + v * 8 + 4);
+        const unsigned mw[8] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w};
+        unsigned c4[2] = {0u, 0u};
 #pragma unroll
-    for (int t = 0; t < 2; t++) {
-        const int v = 2 * (int)threadIdx.x + t;            // (two consecutive vertices a thread: the scan below is over ids)
-        if (v < nv) {
-            int run = 0;
-#pragma unroll
-            for (int w = 0; w < 8; w++) {
-                cum[v][w] = (unsigned short)run;
-                run += __popc(mask[v * 8 + w]);
-            }
-            len2[t] = run;
-            atomicAdd(&lbin[256 - min(run, 256)], 1);      // bin 0 = longest
+        for (int w = 0; w < 8; w++) {
+            c4[w >> 2] |= (unsigned)len << (8 * (w & 3));
+            len += __popc(mw[w]);
         }
+        *reinterpret_cast<uint2 *>(&cum[v][0]) = make_uint2(c4[0], c4[1]);
+        atomicAdd(&lbin[256 - min(len, 256)], 1);          // bin 0 = longest
     }
     {
         int tot;
-        const int ex = block_exclusive_scan(len2[0] + len2[1], &tot);
-        const int v = 2 * (int)threadIdx.x;
-        if (v < nv) startv[v] = (unsigned short)ex;
-        if (v + 1 < nv) startv[v + 1] = (unsigned short)(ex + len2[0]);
+        const int ex = block_exclusive_scan(len, &tot);
+        if ((int)threadIdx.x < nv) startv[threadIdx.x] = (unsigned short)ex;
         if (threadIdx.x == 0) startv[nv] = (unsigned short)E;
     }
     __syncthreads();
@@ -521,17 +518,14 @@ __global__ __launch_bounds__(256) void k_chunk_masks(const int *__restrict__ pix
     const int64_t vbase = vptr ? (int64_t)vptr[c] : (int64_t)c * stride;
     const int vcap = vptr ? SORTN : stride;
     const int64_t ebase = (int64_t)base * dp1;
-#pragma unroll
-    for (int t = 0; t < 2; t++) {
-        const int v = 2 * (int)threadIdx.x + t;
-        if (v < nv) {
-            const int ni = atomicAdd(&lbin[256 - min(len2[t], 256)], 1);
-            newidx[v] = (unsigned short)ni;
-            if (ni < vcap) {
-                const int64_t sl = vbase + ni;
-                slot_vert[sl] = lvid[v];
-                seg_rng[sl] = make_int2((int)(ebase + startv[v]), (int)(ebase + startv[v] + len2[t]));
-            }
+    if ((int)threadIdx.x < nv) {
+        const int v = threadIdx.x;
+        const int ni = atomicAdd(&lbin[256 - min(len, 256)], 1);
+        newidx[v] = (unsigned short)ni;
+        if (ni < vcap) {
+            const int64_t sl = vbase + ni;
+            slot_vert[sl] = lvid[v];
+            seg_rng[sl] = make_int2((int)(ebase + startv[v]), (int)(ebase + startv[v] + len));
         }
     }
     __syncthreads();
@@ -2077,12 +2071,15 @@ int phl_tiles_build(phl_lattice *lat, const float *ref, int64_t rs, int64_t cs, 
     int *nv;
     PHL_HIP(tmp.get(&nv, (size_t)nchunks + 1));
     PHL_HIP(phl_dev_malloc((void **)&lat->chunk_vptr, sizeof(int) * ((size_t)nchunks + 1)));
-#define PHL_CHUNK_MASKS(...)                                                                                       \
-    switch (sortn) {                                                                                                \
-        case 512: hipLaunchKernelGGL((k_chunk_masks<512>), dim3(nchunks), dim3(256), 0, st, __VA_ARGS__); break;     \
-        case 1024: hipLaunchKernelGGL((k_chunk_masks<1024>), dim3(nchunks), dim3(256), 0, st, __VA_ARGS__); break;   \
-        default: hipLaunchKernelGGL((k_chunk_masks<2048>), dim3(nchunks), dim3(256), 0, st, __VA_ARGS__); break;     \
+#define PHL_CHUNK_MASKS_X(HTX_, ...)                                                                                    \
+    switch (sortn) {                                                                                                     \
+        case 512: hipLaunchKernelGGL((k_chunk_masks<512, HTX_>), dim3(nchunks), dim3(256), 0, st, __VA_ARGS__); break;    \
+        case 1024: hipLaunchKernelGGL((k_chunk_masks<1024, HTX_>), dim3(nchunks), dim3(256), 0, st, __VA_ARGS__); break;  \
+        default: hipLaunchKernelGGL((k_chunk_masks<2048, HTX_>), dim3(nchunks), dim3(256), 0, st, __VA_ARGS__); break;    \
     }
+#define PHL_CHUNK_MASKS(...)                                           \
+    if (P * dp1 * 4 > sortn * 3) { PHL_CHUNK_MASKS_X(2, __VA_ARGS__) } \
+    else { PHL_CHUNK_MASKS_X(1, __VA_ARGS__) }
 #define PHL_CHUNK_SORT(WRITE_, ...)                                                                                      \
     switch (sortn) {                                                                                                      \
         case 512: hipLaunchKernelGGL((k_chunk_group<512, WRITE_>), dim3(nchunks), dim3(256), 0, st, __VA_ARGS__); break;   \
@@ -2099,8 +2096,8 @@ int phl_tiles_build(phl_lattice *lat, const float *ref, int64_t rs, int64_t cs, 
     PHL_HIP(tmp.get(&t_rng, (size_t)nchunks * SLOT_STRIDE));
     PHL_HIP(phl_dev_malloc((void **)&lat->seg, sizeof(phl_contrib_t) * (size_t)N));
     PHL_HIP(phl_dev_malloc((void **)&lat->lidx, sizeof(unsigned short) * (size_t)N));
-    // k_chunk_masks does every chunk with at most NVC (> SLOT_STRIDE) local vertices; heavier ones only report their
-    // count here and are done by k_chunk_group in the repeated pass below
+    // k_chunk_masks does every chunk with at most NVC local vertices; heavier ones only report their count here and
+    // are done by k_chunk_group below, once the counts are on the host
     static const bool use_masks = !(getenv("PHL_CHUNK_MASKS") && atoi(getenv("PHL_CHUNK_MASKS")) == 0);
     if (use_masks) {
         PHL_CHUNK_MASKS(lat->pix_order, n, P, dp1, lat->replay, nv, (const int *)nullptr, SLOT_STRIDE, t_vert, t_rng, lat->seg,
@@ -2144,6 +2141,10 @@ int phl_tiles_build(phl_lattice *lat, const float *ref, int64_t rs, int64_t cs, 
     PHL_HIP(phl_dev_malloc((void **)&lat->slot_vert, sizeof(int) * ((size_t)S + 1)));
     PHL_HIP(phl_dev_malloc((void **)&lat->seg_rng, sizeof(int2) * ((size_t)S + 1)));
     if (nv_max <= SLOT_STRIDE) {
+        if (use_masks && nv_max > NVC) {     // the chunks k_chunk_masks left out (first-pass form: slot records to the scratch)
+            PHL_CHUNK_SORT(true, lat->pix_order, n, P, dp1, lat->replay, (int *)nullptr, (const int *)nullptr, SLOT_STRIDE, t_vert,
+                           t_rng, lat->seg, lat->lidx, (const int *)nv, NVC)
+        }
         hipLaunchKernelGGL(k_compact_slots, dim3(nchunks), dim3(256), 0, st, lat->chunk_vptr, nchunks, SLOT_STRIDE, t_vert,
                            t_rng, lat->slot_vert, lat->seg_rng);
     } else {
@@ -2161,6 +2162,7 @@ int phl_tiles_build(phl_lattice *lat, const float *ref, int64_t rs, int64_t cs, 
     }
 #undef PHL_CHUNK_SORT
 #undef PHL_CHUNK_MASKS
+#undef PHL_CHUNK_MASKS_X
     PHL_HIP(hipGetLastError());
     PHL_HIP(hipStreamSynchronize(st));
     }
