@@ -1053,26 +1053,29 @@ struct device_query : phl_reftable_query {
     int *scratch;            // one device int
     hipStream_t st;
     hipError_t err = hipSuccess;
+    int *mailbox = nullptr;                              // pinned host int (null: answers come back through pageable memory)
     int vid_at(int64_t e) override
     {
         int v = -1;
+        int *dst = mailbox ? mailbox : &v;
         hipLaunchKernelGGL(k_vid_at, dim3(1), dim3(1), 0, st, table, slot_of, (int)e, scratch);
-        hipError_t r = hipMemcpyAsync(&v, scratch, sizeof(int), hipMemcpyDeviceToHost, st);
+        hipError_t r = hipMemcpyAsync(dst, scratch, sizeof(int), hipMemcpyDeviceToHost, st);
         if (r == hipSuccess) r = hipStreamSynchronize(st);
         if (r != hipSuccess) { err = r; return -1; }
-        return v;
+        return *dst;
     }
     int64_t next_occurrence(int vid, int64_t after) override
     {
         int v = 0x7FFFFFFF;
-        hipError_t r = hipMemcpyAsync(scratch, &v, sizeof(int), hipMemcpyHostToDevice, st);
+        int *dst = mailbox ? mailbox : &v;
+        hipError_t r = hipMemsetD32Async((hipDeviceptr_t)scratch, 0x7FFFFFFF, 1, st);
         if (r == hipSuccess) {
             hipLaunchKernelGGL(k_next_occurrence, dim3(1024), dim3(256), 0, st, slot_of, N, (int)efirst_host[vid], (int)after, scratch);
-            r = hipMemcpyAsync(&v, scratch, sizeof(int), hipMemcpyDeviceToHost, st);
+            r = hipMemcpyAsync(dst, scratch, sizeof(int), hipMemcpyDeviceToHost, st);
         }
         if (r == hipSuccess) r = hipStreamSynchronize(st);
         if (r != hipSuccess) { err = r; return -1; }
-        return v == 0x7FFFFFFF ? -1 : v;
+        return *dst == 0x7FFFFFFF ? -1 : *dst;
     }
 };
 
@@ -1113,6 +1116,7 @@ int phl_apply_reference_table(phl_lattice *lat, hipStream_t st)
     q.slot_of = lat->bt_slot_of;
     q.table = lat->bt_table;
     q.efirst_host = efirst;
+    q.mailbox = (int *)phl_pinned_alloc(sizeof(int));
     q.N = N;
     q.scratch = scratch;
     q.st = st;
