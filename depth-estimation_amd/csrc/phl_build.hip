@@ -239,18 +239,20 @@ __global__ __launch_bounds__(256) void k_insert(const uint32_t *__restrict__ rec
     const int lane = threadIdx.x & 63;
     // the small table has been found too small: the host will repeat the insertion, nothing of this launch is kept
     if (max_probe != 0x7FFFFFFF && (*reinterpret_cast<volatile int *>(err) & 2)) return;
-    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int r = (int)(wave % dp1);
-    const int64_t p = (wave / dp1) * 64 + lane;
+    // (the wavefront's index and remainder are scalars; the hash runs over the key's packed words)
+    const unsigned wave = (unsigned)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4u + (threadIdx.x >> 6)));   // < 2^31
+    const unsigned wq = wave / (unsigned)dp1;
+    const int r = (int)(wave - wq * (unsigned)dp1);
+    const int p = (int)(wq * 64u) + lane;                  // (n(d+1) < 2^31)
     const bool active = p < n;
-    const int64_t pc = active ? p : (int64_t)n - 1;
-    const int e = (int)(pc * dp1 + r);
+    const int pc = active ? p : n - 1;
+    const int e = pc * dp1 + r;
     uint32_t rec[R::W], key[R::GW];
-    R::load(recs + pc * R::W, rec);
+    R::load(recs + (int64_t)pc * R::W, rec);
     R::key(rec, r, key);
     uint32_t h = mix_begin();
 #pragma unroll
-    for (int i = 0; i < D; i++) h = mix_step(h, (int)(int16_t)(uint16_t)(key[i >> 1] >> (16 * (i & 1))));
+    for (int j = 0; j < R::GW; j++) h = (h ^ key[j]) * 0x01000193u;
     h = mix_end(h);
     // same key as the previous lane?
     bool same_prev = active && lane > 0;
