@@ -9,6 +9,7 @@
 #include <string.h>
 
 #include <map>
+#include <chrono>
 #include <mutex>
 #include <utility>
 #include <vector>
@@ -460,8 +461,14 @@ int phl_build_ex(phl_lattice **out, const float *ref_dev, int64_t n, int d, int6
     lat->build_flags = build_flags;
     lat->nbr00_override = -2;
     lat->shared = new phl_shared();
+    static const bool dbg_t = getenv("PHL_DEBUG") != nullptr;
+    const auto tb0 = std::chrono::steady_clock::now();
     int rc = phl_build_device(lat, ref_dev, rs, cs, (hipStream_t)stream);
+    const auto tb1 = std::chrono::steady_clock::now();
     if (rc == PHL_OK) rc = phl_tiles_build(lat, ref_dev, rs, cs, (hipStream_t)stream);
+    if (dbg_t)
+        fprintf(stderr, "[phl] build: vertices %.2f ms, chunks %.2f ms\n", std::chrono::duration<double, std::milli>(tb1 - tb0).count(),
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tb1).count());
     if (rc != PHL_OK) {
         phl_destroy(lat);
         return rc;

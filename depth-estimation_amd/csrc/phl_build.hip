@@ -874,7 +874,12 @@ int phl_build_device(phl_lattice *lat, const float *ref, int64_t rs, int64_t cs,
     // (replay[].vid is written at the end of phl_tiles_build, through the renamings that follow: phl_write_final_vids)
     PHL_HIP(hipGetLastError());
     if (lat->build_flags & PHL_BUILD_REFERENCE_TABLE) {
-        rc = phl_apply_reference_table(lat, st);
+        void *arena = nullptr;
+        char *arena_c = nullptr;
+        const size_t arena_bytes = phl_reftable_scratch_bytes(M);
+        if (tmp.get(&arena_c, arena_bytes) == hipSuccess) arena = arena_c;
+        else (void)hipGetLastError();
+        rc = phl_apply_reference_table(lat, st, arena, arena ? arena_bytes : 0);
         if (rc) return rc;
     }
     if (lat->M != M && lat->vfirst_valid_for_M != lat->M) {     // duplicate vertices inserted without a list of their own

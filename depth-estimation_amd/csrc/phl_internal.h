@@ -136,7 +136,10 @@ int phl_reference_table_sim(const int16_t *keys_clean, const int32_t *efirst, in
 // the same result without simulating the table (phl_reftable.hip, "analytic replay"); 1 = not applicable here, use the sim
 int phl_reference_table_fast(const int16_t *keys_clean, const int32_t *efirst, int64_t M, int d, int64_t N,
                              phl_reftable_query &q, phl_reftable_result &out, bool compact);
-int phl_apply_reference_table(phl_lattice *lat, hipStream_t st);
+// (arena: device bytes from the caller's pool of build temporaries, phl_reftable_scratch_bytes(M) of them -- a second
+//  pool would find the scratch block taken and hipMalloc / hipFree each of its requests; may be null)
+size_t phl_reftable_scratch_bytes(int64_t M);
+int phl_apply_reference_table(phl_lattice *lat, hipStream_t st, void *arena, size_t arena_bytes);
 // replay[].vid from the build-time tables (see bt_* above), mapped through int_of_ft if there is one; releases nothing
 int phl_write_final_vids(phl_lattice *lat, hipStream_t st);
 void phl_release_build_tables(phl_lattice *lat);          // (after a stream synchronisation)

@@ -1083,7 +1083,41 @@ struct device_query : phl_reftable_query {
 
 // Called by phl_build_device between the clean numbering and the neighbour tables.  lat->vfirst holds every clean
 // vertex's first-touch candidate; the candidates' clean vertices are read through lat->bt_slot_of / bt_table.
-int phl_apply_reference_table(phl_lattice *lat, hipStream_t st)
+namespace {
+uint64_t replay_cap_max(int64_t M)
+{
+    uint64_t cap_max = (uint64_t)1 << 15;
+    while (cap_max / 2 - 1 <= (uint64_t)M + 128) cap_max <<= 1;
+    return cap_max;
+}
+// requests served from the caller's arena first, from a pool of its own (hipMalloc while the caller holds the scratch
+// block) when that is missing or full
+struct arena_pool {
+    char *base;
+    size_t cap, off = 0;
+    temp_pool fallback;
+    arena_pool(void *b, size_t c) : base((char *)b), cap(b ? c : 0) {}
+    template <typename T>
+    hipError_t get(T **out, size_t count)
+    {
+        const size_t bytes = (((count ? count : 1) * sizeof(T)) + 255) & ~(size_t)255;
+        if (base && off + bytes <= cap) {
+            *out = (T *)(base + off);
+            off += bytes;
+            return hipSuccess;
+        }
+        return fallback.get(out, count);
+    }
+};
+}  // namespace
+
+size_t phl_reftable_scratch_bytes(int64_t M)
+{
+    const uint64_t cap_max = replay_cap_max(M);
+    return (size_t)(cap_max * sizeof(int) + (cap_max / CL_PIECE + 1) * sizeof(int2) + 32 * 1024);
+}
+
+int phl_apply_reference_table(phl_lattice *lat, hipStream_t st, void *arena, size_t arena_bytes)
 {
     const int d = lat->d;
     const int64_t M = lat->M;
@@ -1094,7 +1128,7 @@ int phl_apply_reference_table(phl_lattice *lat, hipStream_t st)
     const auto t_begin = std::chrono::steady_clock::now();
     auto since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count(); };
     static const bool dbg = getenv("PHL_DEBUG") != nullptr;
-    temp_pool tmp;
+    arena_pool tmp(arena, arena_bytes);
     int *scratch;
     const int *efirst_dev = lat->vfirst;
     if (!efirst_dev) { phl_set_error("reference-table replay: first touches missing"); return PHL_ERR_INVALID; }
@@ -1128,8 +1162,7 @@ int phl_apply_reference_table(phl_lattice *lat, hipStream_t st)
     int rc = 1;
     const char *envf = getenv("PHL_REPLAY_FAST");
     if (!(envf && atoi(envf) == 0)) {
-        uint64_t cap_max = (uint64_t)1 << 15;
-        while (cap_max / 2 - 1 <= (uint64_t)M + 128) cap_max <<= 1;
+        const uint64_t cap_max = replay_cap_max(M);
         q.verdicts = (int *)phl_pinned_alloc(sizeof(int) * device_query::MAX_Q);
         q.verdicts_on_host = q.verdicts != nullptr;
         if (tmp.get(&q.hist, (size_t)cap_max) == hipSuccess && tmp.get(&q.small, 256) == hipSuccess &&
