@@ -12,7 +12,9 @@
 //              runs of equal keys along a wavefront (neighbouring pixels) probe once
 //   flag+scan  representative candidates as a bit mask, scan of its word counts => vertex id =
 //              first-touch rank, i.e. exactly the reference's insertion order (:70-77)
-//   assign     vertex keys [M][d]; table now maps key -> vertex id
+//   assign     vertex keys [M][d], first touches; table now maps key -> vertex id
+//   final_vid  (from phl_tiles_build, once the locality numbering is known) replay[].vid, written once:
+//              candidate -> table slot -> clean vertex -> [reference vertex] -> row
 //   (on demand) count/scan/fill/sort   transpose of the replay matrix: per vertex the (pixel,
 //              weight) list in ascending pixel order for the reference-exact gather splat
 //              (phl_ensure_csr); the default chunk kernels do not need it
