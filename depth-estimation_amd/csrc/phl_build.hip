@@ -722,7 +722,7 @@ int phl_rebuild_table_and_neighbors(phl_lattice *lat, hipStream_t st, void **scr
 
 void phl_release_build_tables(phl_lattice *lat)
 {
-    int32_t **p[] = {&lat->bt_slot_of, &lat->bt_table, &lat->bt_remap, &lat->bt_dup_ptr, &lat->bt_seg_e, &lat->bt_seg_id};
+    int32_t **p[] = {&lat->bt_slot_of, &lat->bt_table, &lat->bt_remap, &lat->bt_dup_ptr, &lat->bt_seg_e, &lat->bt_seg_id, &lat->bt_cell};
     for (int32_t **q : p) {
         if (*q) (void)phl_dev_free(*q);
         *q = nullptr;
@@ -881,7 +881,62 @@ int phl_build_device(phl_lattice *lat, const float *ref, int64_t rs, int64_t cs,
         const size_t arena_bytes = phl_reftable_scratch_bytes(M);
         if (tmp.get(&arena_c, arena_bytes) == hipSuccess) arena = arena_c;
         else (void)hipGetLastError();
-        rc = phl_apply_reference_table(lat, st, arena, arena ? arena_bytes : 0);
+        // the pixel order of the chunk build does not depend on the table: its launches go in under the replay, which is
+        // the host waiting for device answers a few bytes at a time
+        struct under_t {
+            phl_lattice *lat;
+            const float *ref;
+            int64_t rs, cs;
+            void *arena;
+            size_t bytes;
+            hipStream_t st, aux;
+            hipEvent_t fork, join;
+            bool launched;
+        } under = {lat, ref, rs, cs, nullptr, 0, st, nullptr, nullptr, nullptr, false};
+        static const bool early = !(getenv("PHL_EARLY_PIXEL_ORDER") && atoi(getenv("PHL_EARLY_PIXEL_ORDER")) == 0);
+        char *arena2 = nullptr;
+        under.bytes = phl_tiles_pixel_order_scratch_bytes(n);
+        // (a second stream: on the caller's the replay's device queries would queue behind these launches)
+        struct side_t {
+            int dev = -1;
+            hipStream_t s = nullptr;
+            hipEvent_t fork = nullptr, join = nullptr;
+        };
+        thread_local side_t side;        // (never destroyed: a thread's exit may come after the runtime has shut down)
+        if (early) {
+            int dev = -1;
+            if (hipGetDevice(&dev) == hipSuccess && dev != side.dev) {
+                side = side_t();
+                if (hipStreamCreateWithFlags(&side.s, hipStreamNonBlocking) == hipSuccess &&
+                    hipEventCreateWithFlags(&side.fork, hipEventDisableTiming) == hipSuccess &&
+                    hipEventCreateWithFlags(&side.join, hipEventDisableTiming) == hipSuccess)
+                    side.dev = dev;
+                else
+                    (void)hipGetLastError();
+            }
+            if (side.dev == dev && dev >= 0 && tmp.get(&arena2, under.bytes) == hipSuccess) {
+                under.arena = arena2;
+                under.aux = side.s;
+                under.fork = side.fork;
+                under.join = side.join;
+            } else {
+                (void)hipGetLastError();
+            }
+        }
+        auto hook = [](void *a) -> int {
+            under_t *u = (under_t *)a;
+            PHL_HIP(hipEventRecord(u->fork, u->st));                 // everything enqueued so far (vertex keys, first touches)
+            PHL_HIP(hipStreamWaitEvent(u->aux, u->fork, 0));
+            const int rcp = phl_tiles_pixel_order(u->lat, u->ref, u->rs, u->cs, u->arena, u->bytes, u->aux);
+            PHL_HIP(hipEventRecord(u->join, u->aux));
+            u->launched = true;
+            return rcp;
+        };
+        rc = phl_apply_reference_table(lat, st, arena, arena ? arena_bytes : 0, under.arena ? +hook : nullptr, &under);
+        if (under.launched) {
+            if (rc) (void)hipStreamSynchronize(under.aux);      // (their temporaries die with this function)
+            else PHL_HIP(hipStreamWaitEvent(st, under.join, 0));   // the caller's stream carries on behind them
+        }
         if (rc) return rc;
     }
     if (lat->M != M && lat->vfirst_valid_for_M != lat->M) {     // duplicate vertices inserted without a list of their own

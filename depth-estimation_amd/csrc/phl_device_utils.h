@@ -121,7 +121,7 @@ __global__ __launch_bounds__(SCAN_T) void k_scan_add(int *__restrict__ out, cons
         if ((base + i) < n) out[base + i] += add;
 }
 
-int exclusive_scan(const int *in, int *out /* n+1 */, int n, int *tile_sums, hipStream_t st)
+__attribute__((unused)) int exclusive_scan(const int *in, int *out /* n+1 */, int n, int *tile_sums, hipStream_t st)
 {
     if (n <= 0) {
         PHL_HIP(hipMemsetAsync(out, 0, sizeof(int), st));
@@ -177,7 +177,7 @@ struct temp_pool {
 // the lanes of its wavefront with the same digit comes from eight ballots).
 constexpr int RS_TILE = 2048;
 
-__global__ __launch_bounds__(256) void k_radix_hist(const int *__restrict__ keys, int n, int shift, int nblocks,
+__attribute__((unused)) __global__ __launch_bounds__(256) void k_radix_hist(const int *__restrict__ keys, int n, int shift, int nblocks,
                                                     int *__restrict__ hist)
 {
     __shared__ int h[256];
@@ -192,7 +192,7 @@ __global__ __launch_bounds__(256) void k_radix_hist(const int *__restrict__ keys
     hist[threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
 }
 
-__global__ __launch_bounds__(256) void k_radix_scatter(const int *__restrict__ keys, const int *__restrict__ idx, int n,
+__attribute__((unused)) __global__ __launch_bounds__(256) void k_radix_scatter(const int *__restrict__ keys, const int *__restrict__ idx, int n,
                                                        int shift, int nblocks, const int *__restrict__ base,
                                                        int *__restrict__ keys_out, int *__restrict__ idx_out)
 {
@@ -231,13 +231,35 @@ __global__ __launch_bounds__(256) void k_radix_scatter(const int *__restrict__ k
     }
 }
 
-__global__ __launch_bounds__(256) void k_iota(int *p, int n)
+__attribute__((unused)) __global__ __launch_bounds__(256) void k_iota(int *p, int n)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = i;
 }
 
-__attribute__((unused)) int stable_sort_perm(const int *keys, int n, int64_t key_bound, int *perm_out, temp_pool &tmp, hipStream_t st)
+// Requests served from a caller's arena first (device bytes out of the caller's temp_pool, handed across translation
+// units as a plain pointer), from a pool of its own when that is missing or full -- which means hipMalloc / hipFree
+// while the caller holds the scratch block.
+struct arena_pool {
+    char *base;
+    size_t cap, off = 0;
+    temp_pool fallback;
+    arena_pool(void *b, size_t c) : base((char *)b), cap(b ? c : 0) {}
+    template <typename T>
+    hipError_t get(T **out, size_t count)
+    {
+        const size_t bytes = (((count ? count : 1) * sizeof(T)) + 255) & ~(size_t)255;
+        if (base && off + bytes <= cap) {
+            *out = (T *)(base + off);
+            off += bytes;
+            return hipSuccess;
+        }
+        return fallback.get(out, count);
+    }
+};
+
+template <typename Pool>
+__attribute__((unused)) int stable_sort_perm(const int *keys, int n, int64_t key_bound, int *perm_out, Pool &tmp, hipStream_t st)
 {
     if (n <= 0) return PHL_OK;
     int passes = 0;

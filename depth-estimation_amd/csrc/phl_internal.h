@@ -50,6 +50,10 @@ struct phl_lattice {
     // all of them and the locality numbering (k_final_vid) instead of once per renaming.
     int32_t *bt_slot_of, *bt_table;
     int32_t *bt_remap, *bt_dup_ptr, *bt_seg_e, *bt_seg_id;
+    // ... and the grid cell of every pixel + the grid the chunk order was made on, when the pixel order has been made
+    // ahead of phl_tiles_build (phl_tiles_pixel_order, launched under the host's table replay); else null
+    int32_t *bt_cell;
+    int grid_nca, grid_ncb;
     int32_t *ft_of_int;     // [M] first-touch id of internal vertex i
     int32_t *int_of_ft;     // [M] internal id (row) of first-touch vertex v
 
@@ -139,10 +143,17 @@ int phl_reference_table_fast(const int16_t *keys_clean, const int32_t *efirst, i
 // (arena: device bytes from the caller's pool of build temporaries, phl_reftable_scratch_bytes(M) of them -- a second
 //  pool would find the scratch block taken and hipMalloc / hipFree each of its requests; may be null)
 size_t phl_reftable_scratch_bytes(int64_t M);
-int phl_apply_reference_table(phl_lattice *lat, hipStream_t st, void *arena, size_t arena_bytes);
+int phl_apply_reference_table(phl_lattice *lat, hipStream_t st, void *arena, size_t arena_bytes,
+                              int (*under_replay)(void *), void *under_replay_arg);
+// (under_replay: called once the first-touch / key copies are enqueued, before the host waits for them: launches that
+//  do not depend on the replay run under it)
 // replay[].vid from the build-time tables (see bt_* above), mapped through int_of_ft if there is one; releases nothing
 int phl_write_final_vids(phl_lattice *lat, hipStream_t st);
 void phl_release_build_tables(phl_lattice *lat);          // (after a stream synchronisation)
+// steps 1-2 of phl_tiles_build (grid over the two widest features, pixels in cell-major order), launches only:
+// lat->pix_order, bt_cell, grid_*.  Temporaries out of `arena` (phl_tiles_pixel_order_scratch_bytes(n) device bytes).
+size_t phl_tiles_pixel_order_scratch_bytes(int64_t n);
+int phl_tiles_pixel_order(phl_lattice *lat, const float *ref, int64_t rs, int64_t cs, void *arena, size_t arena_bytes, hipStream_t st);
 int phl_tiles_ensure_vorder(phl_lattice *lat, hipStream_t st);   // caller holds the lattice's list lock (phl_ensure_csr)
 // Pinned, device-visible host memory for the build's read-backs (thread-local bump arena).  hipMemcpyAsync into pageable
 // memory blocks the host until the copy has run -- a stream synchronisation per read-back; into this it does not, and

@@ -1090,25 +1090,6 @@ uint64_t replay_cap_max(int64_t M)
     while (cap_max / 2 - 1 <= (uint64_t)M + 128) cap_max <<= 1;
     return cap_max;
 }
-// requests served from the caller's arena first, from a pool of its own (hipMalloc while the caller holds the scratch
-// block) when that is missing or full
-struct arena_pool {
-    char *base;
-    size_t cap, off = 0;
-    temp_pool fallback;
-    arena_pool(void *b, size_t c) : base((char *)b), cap(b ? c : 0) {}
-    template <typename T>
-    hipError_t get(T **out, size_t count)
-    {
-        const size_t bytes = (((count ? count : 1) * sizeof(T)) + 255) & ~(size_t)255;
-        if (base && off + bytes <= cap) {
-            *out = (T *)(base + off);
-            off += bytes;
-            return hipSuccess;
-        }
-        return fallback.get(out, count);
-    }
-};
 }  // namespace
 
 size_t phl_reftable_scratch_bytes(int64_t M)
@@ -1117,7 +1098,8 @@ size_t phl_reftable_scratch_bytes(int64_t M)
     return (size_t)(cap_max * sizeof(int) + (cap_max / CL_PIECE + 1) * sizeof(int2) + 32 * 1024);
 }
 
-int phl_apply_reference_table(phl_lattice *lat, hipStream_t st, void *arena, size_t arena_bytes)
+int phl_apply_reference_table(phl_lattice *lat, hipStream_t st, void *arena, size_t arena_bytes,
+                              int (*under_replay)(void *), void *under_replay_arg)
 {
     const int d = lat->d;
     const int64_t M = lat->M;
@@ -1142,7 +1124,20 @@ int phl_apply_reference_table(phl_lattice *lat, hipStream_t st, void *arena, siz
     if (!efirst) { efirst_pageable.resize((size_t)M); efirst = efirst_pageable.data(); }
     PHL_HIP(hipMemcpyAsync(keys, lat->vkeys, sizeof(int16_t) * (size_t)M * d, hipMemcpyDeviceToHost, st));
     PHL_HIP(hipMemcpyAsync(efirst, efirst_dev, sizeof(int32_t) * (size_t)M, hipMemcpyDeviceToHost, st));
-    PHL_HIP(hipStreamSynchronize(st));
+    if (under_replay) {
+        // wait for the copies only: what the caller launches now runs while the host replays
+        hipEvent_t copied;
+        PHL_HIP(hipEventCreateWithFlags(&copied, hipEventDisableTiming));
+        hipError_t er = hipEventRecord(copied, st);
+        int rcu = PHL_OK;
+        if (er == hipSuccess) rcu = under_replay(under_replay_arg);
+        if (er == hipSuccess) er = hipEventSynchronize(copied);
+        (void)hipEventDestroy(copied);
+        if (er != hipSuccess) return phl_hip_fail(er, "reference-table replay: copies", __FILE__, __LINE__);
+        if (rcu) return rcu;
+    } else {
+        PHL_HIP(hipStreamSynchronize(st));
+    }
     if (dbg) fprintf(stderr, "[phl] reference table: keys + first touches on the host after %.2f ms\n", since());
 
     device_query q;

@@ -1914,11 +1914,9 @@ int phl_tiles_link_vertices(phl_lattice *lat, hipStream_t st)
     return PHL_OK;
 }
 
-int phl_tiles_build(phl_lattice *lat, const float *ref, int64_t rs, int64_t cs, hipStream_t st)
+namespace {
+int tile_pixels(int dp1)
 {
-    phl_tiles_free(lat);
-    const int d = lat->d, dp1 = d + 1;
-    const int n = (int)lat->n;
     int P = 2048 / dp1;
     if (P > 256) P = 256;
     P &= ~15;
@@ -1926,48 +1924,19 @@ int phl_tiles_build(phl_lattice *lat, const float *ref, int64_t rs, int64_t cs, 
         const int v = atoi(e) & ~15;
         if (v >= 16 && v <= P) P = v;
     }
-    lat->P = P;
-    if (n == 0) {
-        void *scratch = nullptr;
-        const int rc0 = phl_rebuild_table_and_neighbors(lat, st, &scratch);
-        const int rc1 = rc0 ? rc0 : phl_tiles_link_vertices(lat, st);      // (synchronises the stream)
-        if (scratch) { (void)hipStreamSynchronize(st); (void)phl_dev_free(scratch); }
-        return rc1;
-    }
-    int sortn = 512;
-    while (sortn < P * dp1) sortn <<= 1;
+    return P;
+}
 
-    int rc = PHL_OK;
-    int nchunks = 0;
-    int64_t S = 0;
-    const int64_t N = lat->N;
-    // arrays replaced while launches that read them may still be in flight: released only behind the stream
-    // synchronisation at the end of this phase (the block cache may hand a freed block to another thread's build)
-    struct deferred_t {
-        void *p[3] = {nullptr, nullptr, nullptr};
-        ~deferred_t() { for (void *q : p) if (q) (void)phl_dev_free(q); }
-    } deferred;
-    {   // temporaries of the chunk build go back to the scratch cache before the vertex lists are linked
-    temp_pool tmp;
-    // 1. feature ranges -> the two widest dimensions -> uniform grid with ~P pixels per cell
-    std::vector<float> lo(d, INFINITY), hi(d, -INFINITY);
-    if (lat->feat_range_valid) {          // found while elevating (phl_build_device)
-        for (int i = 0; i < d; i++) { lo[i] = lat->feat_lo[i]; hi[i] = lat->feat_hi[i]; }
-    } else {
-        constexpr int MMB = 1024;
-        float *mm_dev;
-        PHL_HIP(tmp.get(&mm_dev, (size_t)MMB * d * 2));
-        hipLaunchKernelGGL(k_minmax, dim3(MMB), dim3(256), 0, st, ref, rs, cs, (int64_t)n, d, mm_dev);
-        PHL_HIP(hipGetLastError());
-        std::vector<float> mm((size_t)MMB * d * 2);
-        PHL_HIP(hipMemcpyAsync(mm.data(), mm_dev, sizeof(float) * mm.size(), hipMemcpyDeviceToHost, st));
-        PHL_HIP(hipStreamSynchronize(st));
-        for (int b = 0; b < MMB; b++)
-            for (int i = 0; i < d; i++) {
-                lo[i] = fminf(lo[i], mm[((size_t)b * d + i) * 2]);
-                hi[i] = fmaxf(hi[i], mm[((size_t)b * d + i) * 2 + 1]);
-            }
-    }
+// 1. feature ranges -> the two widest dimensions -> uniform grid with ~P pixels per cell
+// 2. pixels in cell-major order (ascending pixel inside a cell): a stable sort of the pixels by cell id.
+//    O(n) whatever the features look like -- a constant or heavily clustered `ref` puts (nearly) all
+//    pixels into one cell
+// Launches only (given the ranges): lat->pix_order, `cell` [n], the grid's cell counts.
+template <typename Pool>
+int pixel_order(phl_lattice *lat, const float *ref, int64_t rs, int64_t cs, int P, const float *lo, const float *hi, int *cell,
+                int *nca_out, int *ncb_out, Pool &tmp, hipStream_t st)
+{
+    const int d = lat->d, n = (int)lat->n;
     int da = 0, db = -1;
     for (int i = 1; i < d; i++)
         if (hi[i] - lo[i] > hi[da] - lo[da]) da = i;
@@ -1992,20 +1961,98 @@ int phl_tiles_build(phl_lattice *lat, const float *ref, int64_t rs, int64_t cs, 
         }
     }
     const int ncell = nca * ncb;
-
-    // 2. pixels in cell-major order (ascending pixel inside a cell): a stable sort of the pixels by cell id.
-    //    O(n) whatever the features look like -- a constant or heavily clustered `ref` puts (nearly) all
-    //    pixels into one cell
-    int *cell, *tile_sums;
-    PHL_HIP(tmp.get(&cell, (size_t)n));
-    PHL_HIP(tmp.get(&tile_sums, (size_t)n / SCAN_TILE + 2));
     const unsigned gn = (unsigned)((n + 255) / 256);
     hipLaunchKernelGGL(k_cell_ids, dim3(gn), dim3(256), 0, st, ref, rs, cs, (int64_t)n, da, db, lo[da],
                        db >= 0 ? lo[db] : 0.f, inv_t, nca, ncb, cell);
     PHL_HIP(hipGetLastError());
     PHL_HIP(phl_dev_malloc((void **)&lat->pix_order, sizeof(int) * (size_t)n));
-    rc = stable_sort_perm(cell, n, ncell, lat->pix_order, tmp, st);
-    if (rc) return rc;
+    *nca_out = nca;
+    *ncb_out = ncb;
+    return stable_sort_perm(cell, n, ncell, lat->pix_order, tmp, st);
+}
+}  // namespace
+
+size_t phl_tiles_pixel_order_scratch_bytes(int64_t n)
+{
+    // stable_sort_perm: two [256][blocks] histograms, a scan workspace, three [n] arrays (+ alignment slack)
+    const size_t nblocks = ((size_t)n + RS_TILE - 1) / RS_TILE;
+    return sizeof(int) * (2 * 256 * nblocks + 256 * nblocks / SCAN_TILE + 3 * (size_t)n) + 16 * 1024;
+}
+
+int phl_tiles_pixel_order(phl_lattice *lat, const float *ref, int64_t rs, int64_t cs, void *arena, size_t arena_bytes, hipStream_t st)
+{
+    const int n = (int)lat->n;
+    if (n == 0 || !lat->feat_range_valid || lat->pix_order || lat->bt_cell) return PHL_OK;     // (phl_tiles_build does it)
+    arena_pool tmp(arena, arena_bytes);
+    PHL_HIP(phl_dev_malloc((void **)&lat->bt_cell, sizeof(int) * (size_t)n));
+    return pixel_order(lat, ref, rs, cs, tile_pixels(lat->d + 1), lat->feat_lo, lat->feat_hi, lat->bt_cell, &lat->grid_nca,
+                       &lat->grid_ncb, tmp, st);
+}
+
+int phl_tiles_build(phl_lattice *lat, const float *ref, int64_t rs, int64_t cs, hipStream_t st)
+{
+    int *pix_ready = lat->bt_cell ? lat->pix_order : nullptr;        // made ahead (phl_tiles_pixel_order): keep it
+    if (pix_ready) lat->pix_order = nullptr;
+    phl_tiles_free(lat);
+    lat->pix_order = pix_ready;
+    const int d = lat->d, dp1 = d + 1;
+    const int n = (int)lat->n;
+    const int P = tile_pixels(dp1);
+    lat->P = P;
+    if (n == 0) {
+        void *scratch = nullptr;
+        const int rc0 = phl_rebuild_table_and_neighbors(lat, st, &scratch);
+        const int rc1 = rc0 ? rc0 : phl_tiles_link_vertices(lat, st);      // (synchronises the stream)
+        if (scratch) { (void)hipStreamSynchronize(st); (void)phl_dev_free(scratch); }
+        return rc1;
+    }
+    int sortn = 512;
+    while (sortn < P * dp1) sortn <<= 1;
+
+    int rc = PHL_OK;
+    int nchunks = 0;
+    int64_t S = 0;
+    const int64_t N = lat->N;
+    // arrays replaced while launches that read them may still be in flight: released only behind the stream
+    // synchronisation at the end of this phase (the block cache may hand a freed block to another thread's build)
+    struct deferred_t {
+        void *p[3] = {nullptr, nullptr, nullptr};
+        ~deferred_t() { for (void *q : p) if (q) (void)phl_dev_free(q); }
+    } deferred;
+    {   // temporaries of the chunk build go back to the scratch cache before the vertex lists are linked
+    temp_pool tmp;
+    // 1.-2. the pixel order (pixel_order above), unless it has been made under the table replay already
+    int nca = 1, ncb = 1;
+    int *cell, *tile_sums;
+    PHL_HIP(tmp.get(&tile_sums, (size_t)n / SCAN_TILE + 2));
+    if (pix_ready) {
+        cell = lat->bt_cell;
+        nca = lat->grid_nca;
+        ncb = lat->grid_ncb;
+    } else {
+        std::vector<float> lo(d, INFINITY), hi(d, -INFINITY);
+        if (lat->feat_range_valid) {          // found while elevating (phl_build_device)
+            for (int i = 0; i < d; i++) { lo[i] = lat->feat_lo[i]; hi[i] = lat->feat_hi[i]; }
+        } else {
+            constexpr int MMB = 1024;
+            float *mm_dev;
+            PHL_HIP(tmp.get(&mm_dev, (size_t)MMB * d * 2));
+            hipLaunchKernelGGL(k_minmax, dim3(MMB), dim3(256), 0, st, ref, rs, cs, (int64_t)n, d, mm_dev);
+            PHL_HIP(hipGetLastError());
+            std::vector<float> mm((size_t)MMB * d * 2);
+            PHL_HIP(hipMemcpyAsync(mm.data(), mm_dev, sizeof(float) * mm.size(), hipMemcpyDeviceToHost, st));
+            PHL_HIP(hipStreamSynchronize(st));
+            for (int b = 0; b < MMB; b++)
+                for (int i = 0; i < d; i++) {
+                    lo[i] = fminf(lo[i], mm[((size_t)b * d + i) * 2]);
+                    hi[i] = fmaxf(hi[i], mm[((size_t)b * d + i) * 2 + 1]);
+                }
+        }
+        PHL_HIP(tmp.get(&cell, (size_t)n));
+        rc = pixel_order(lat, ref, rs, cs, P, lo.data(), hi.data(), cell, &nca, &ncb, tmp, st);
+        if (rc) return rc;
+    }
+    const int ncell = nca * ncb;
 
     // 2b. internal vertex numbering (see k_vertex_home), then the key -> vertex table and the blur neighbours
     {
