@@ -850,3 +850,45 @@ def test_occupancy_check_on_the_device_equals_the_host(phl):
         for c in (0, len(sel) - 1):
             want = probe_paths(keys[sel], len(sel), extra, [], cap, [c], on_device=0)
             assert probe_paths(keys[sel], len(sel), extra, [], cap, [c], on_device=1) == want, (pile_n, c)
+
+
+def test_concurrent_builds_from_threads(phl):
+    """Several host threads build (reference-table) lattices and filter through them at the same time, each on its own
+    stream: the build's per-thread state (pinned read-back arena, side stream of the pixel order), the shared block
+    cache and the one scratch block (a second builder falls back to plain allocations) must not get in each other's
+    way -- every result bit-identical to the same build done alone."""
+    import threading
+
+    import bench
+
+    H, W, L = 256, 384, 16
+    refs = [torch.from_numpy(bench.synthetic_features(H, W, sigma_xy=sx).reshape(-1, 5)).cuda() for sx in (8.0, 5.0, 3.0)]
+    src = torch.rand((H * W, L), device="cuda")
+    alone = []
+    for r in refs:
+        lat = phl.Lattice(r, reference_table=True)
+        alone.append((lat.M, lat.filter(src).cpu().numpy()))
+        lat.close()
+    assert max(m for m, _ in alone) > 16383, "at least one lattice should go through the table replay"
+    errs = []
+
+    def work(i):
+        try:
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st):
+                for it in range(6):
+                    lat = phl.Lattice(refs[i], reference_table=True)
+                    out = lat.filter(src)
+                    st.synchronize()
+                    if lat.M != alone[i][0] or not np.array_equal(out.cpu().numpy().view(np.uint32), alone[i][1].view(np.uint32)):
+                        errs.append((i, it))
+                    lat.close()
+        except Exception as e:  # noqa: BLE001
+            errs.append((i, repr(e)))
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(len(refs))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errs, errs
