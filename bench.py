@@ -200,6 +200,19 @@ def algorithmic_bytes(n, M, L, d):
     }
 
 
+def hot_source_sha():
+    """sha256 (first 16 hex digits) over the sources of the hot kernels: stored next to the PMC traffic figures when they
+    are condensed (tools/save_profiles.py), so that a bench line can tell whether the committed counters were taken on the
+    kernels it has just timed."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for name in ("phl_tiles.hip", "phl_filter.hip", "phl_device_utils.h"):
+        with open(os.path.join(ROOT, "depth-estimation_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 def pmc_traffic(kernel_names, workload):
     """HBM bytes per launch of the named kernel(s) from the committed rocprofv3 --pmc summary
     (counters cannot be collected from inside the timed process; FETCH_SIZE is doubled there as
@@ -210,7 +223,10 @@ def pmc_traffic(kernel_names, workload):
     if workload != "c3" or not found:
         return None, None
     path = found[-1]
-    k = json.load(open(path))["kernels"]
+    doc = json.load(open(path))
+    k = doc["kernels"]
+    stored = doc.get("hot_kernel_source_sha")
+    stale = None if stored is None else (stored != hot_source_sha())
     total = 0
     for name in kernel_names.split("+"):
         count, _, name = name.rpartition("*")
@@ -218,7 +234,10 @@ def pmc_traffic(kernel_names, workload):
         if not hit:
             return None, None
         total += int(count or 1) * hit[0]["hbm_bytes_per_launch"]
-    return int(total), f"profiles/{os.path.basename(path)} (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, same command)"
+    note = ("; TAKEN ON OTHER KERNEL SOURCES than this run's (hot_kernel_source_sha differs): refresh with tools/profile_round.sh"
+            if stale else ("" if stale is False else "; source hash of the profiled kernels not recorded"))
+    # a figure measured on other kernels than the ones just timed is not reported as this run's traffic
+    return (None if stale else int(total)), f"profiles/{os.path.basename(path)} (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, same command){note}"
 
 
 def _cpu_model():
@@ -669,6 +688,10 @@ def main():
     if args.mean_field and rank == 0 and not rowtiled:
         mean_field = mean_field_iteration(torch, phl, lat, src, L, device)
 
+    backward = None
+    if args.mean_field and rank == 0 and not rowtiled and not (args.exact or args.no_tiles):
+        backward = backward_pass(torch, lat, src, ref, args.workload)
+
     regimes = None
     default_features = tsu is None and not args.iid and args.sigma_xy == SIGMA_XY and args.sigma_c == SIGMA_C
     if (rank == 0 and world == 1 and not rowtiled and not args.no_regimes and default_features
@@ -717,6 +740,8 @@ def main():
         }
         if mean_field is not None:
             line["mean_field_iteration"] = mean_field
+        if backward is not None:
+            line["backward"] = backward
         if regimes is not None:
             line["regimes"] = regimes
         if small is not None:
@@ -777,6 +802,25 @@ def self_check(torch, phl, dist, backend, rank, world, device, rowtiled, job, la
             err = float("inf")
         res.update(what="default path vs gather kernels (reference summation order) on this rank's volume; run-to-run bit equality",
                    repeatable=repeat)
+        # ... and, since both of those walk ONE data structure, a crop against the CPU checker (its own lattice, its own
+        # arithmetic) when oracle/ travelled with the tree: exact mode must be bit-identical, the default within tolerance
+        try:
+            from oracle import phl_oracle as po
+
+            po.build_oracle()
+            ch, cw = min(H, 96), min(W, 128)
+            idx = (torch.arange(ch, device=device)[:, None] * W + torch.arange(cw, device=device)[None, :]).flatten()
+            ref_c = np.ascontiguousarray(feat[:ch, :cw].reshape(-1, d))
+            src_c = src[idx].contiguous()
+            want = torch.from_numpy(po.Oracle(ref_c, faithful_table=True).filter(src_c.cpu().numpy())).to(device)
+            small = phl.Lattice(torch.from_numpy(ref_c).to(device), reference_table=True)
+            bit = bool(torch.equal(small.filter(src_c, exact=True), want))
+            e2 = rel(small.filter(src_c), want)
+            small.close()
+            res.update(oracle_crop=f"{cw}x{ch}x{L}", oracle_crop_exact_bit_equal=bit, oracle_crop_default_max_rel=e2)
+            err = max(err, e2) if bit else float("inf")
+        except (ImportError, OSError, RuntimeError) as e:
+            res["oracle_crop"] = f"not run ({type(e).__name__}: oracle/ not usable on this box)"
     t = torch.tensor([err], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -869,7 +913,39 @@ def small_image(torch, phl, device):
         cm.mean_field_infer(E0, Wop, Mu, niters)
     res["mean_field_ms_graph"] = round(wall(g2.replay, 50), 4)
     res["Mpixel_labels_per_s_per_iter_graph"] = round(H * W * L * niters / (res["mean_field_ms_graph"] * 1e-3) / 1e6, 1)
+    # the notebook's own call shape (DenseCrf.ipynb:142-152,173): E_0, ref and Mu are CPU tensors.  Staged once, iterated
+    # on the device, Q copied back once (crf_module._mean_field_infer_staged): PCIe-inclusive wall time of the whole call.
+    E0c, Muc, Wc = E0.cpu(), Mu.cpu(), LatticeGaussian(ref.cpu())
+    res["mean_field_ms_cpu_tensors"] = round(wall(lambda: cm.mean_field_infer(E0c, Wc, Muc, niters), 20), 4)
+    res["cpu_tensors_what"] = (f"E_0 [{H * W}, {L}] pageable host memory -> device (pinned pieces), {niters} iterations on the "
+                               "device, Q -> host (pinned); includes both PCIe crossings")
     return res
+
+
+def backward_pass(torch, lat, src, ref, workload):
+    """LatticeFilter.backward (crf/gaussian_matrix.py:435-468) through the fused kernels (phl_filter_grad): both gradients
+    of sum(g * filter(src, ref)) on the bench workload, HIP events around back-to-back calls.  Extra key (the time used to
+    be asserted inside the parity suite)."""
+    import phl
+
+    g = torch.randn(src.shape, device=src.device, generator=torch.Generator(device=src.device).manual_seed(3))
+    try:
+        for _ in range(2):
+            lat.filter_grad(src, g, ref)
+    except phl.PhlError as e:
+        return {"unsupported": str(e)}
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 5
+    e0.record()
+    for _ in range(reps):
+        lat.filter_grad(src, g, ref)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    n, L = src.shape
+    return {"ms": round(ms, 3), "workload": workload, "what": "grad wrt source and features, two fused passes of wide splat -> blur -> contracting slice",
+            "wide_operand_GB_the_reference_formulation_would_move": round(2 * n * 2 * L * (1 + ref.shape[1]) * 4 / 1e9, 1),
+            "lattice_plus_workspaces_GB": round(lat.device_bytes / 1e9, 2)}
 
 
 def mean_field_iteration(torch, phl, lat, Q, L, device):

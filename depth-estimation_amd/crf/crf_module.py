@@ -96,10 +96,42 @@ def mean_field_infer(E_0, W, Mu, niters=10):
             else:
                 Q = F.softmax(-(E_0 + (W @ Q) @ Mu), dim=1)
         return Q
+    if _staged_ok(E_0, W, Mu):
+        return _mean_field_infer_staged(E_0, W, Mu, niters)
     Q = F.softmax(-E_0, dim=1)
     for _ in range(niters):
         Q = F.softmax(-(E_0 + (W @ Q) @ Mu), dim=1)
     return Q
+
+
+def _staged_ok(E_0, W, Mu):
+    """The notebook's own call shape (Experiments/DenseCrf.ipynb:142-152,173: CPU tensors, W = LatticeGaussian(ref) on
+    the CPU, no autograd) -- everything the device loop needs can be staged once."""
+    from crf.gaussian_matrix import LatticeGaussian
+
+    if not (type(W) is LatticeGaussian and torch.is_tensor(W.ref) and torch.cuda.is_available()):
+        return False
+    no_grad = not (torch.is_grad_enabled() and (E_0.requires_grad or Mu.requires_grad or W.ref.requires_grad))
+    return (no_grad and not E_0.is_cuda and E_0.dtype == torch.float32 and E_0.dim() == 2 and W.ref.dtype == torch.float32
+            and Mu.dtype == torch.float32 and W.ref.dim() == 2 and W.ref.shape[0] == E_0.shape[0])
+
+
+def _mean_field_infer_staged(E_0, W, Mu, niters):
+    """CPU tensors in, CPU tensor out, the iterations on the device: E_0 crosses PCIe once (pinned pieces, phl.to_device),
+    the lattice of ``W.ref`` is built once (cached per ``ref``), every iteration is one lattice filter with ``- Q`` fused
+    and one fused compatibility + softmax kernel, and Q crosses PCIe once at the end -- instead of Q making the round
+    trip inside every ``W @ Q`` with the compatibility product and the softmax on the host."""
+    import phl
+
+    dev = torch.device("cuda", torch.cuda.current_device())
+    lat = phl.lattice_for(W.ref.detach())                 # CPU ref: built on the current device
+    E0d = phl.to_device(E_0.detach().contiguous(), dev)
+    Q = phl.softmax_neg_add(E0d)
+    X = torch.empty_like(Q) if niters > 0 else None
+    for _ in range(niters):
+        lat.filter(Q, subtract_input=True, out=X)
+        Q = phl.compat_softmax(E0d, X, Mu.detach(), out=Q)   # (Mu^T is cached per Mu tensor, wherever it lives)
+    return phl.to_host(Q)
 
 
 def potts(num_classes):

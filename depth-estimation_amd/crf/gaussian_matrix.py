@@ -49,25 +49,29 @@ def _ref_gradient(src, ref, g, wall):
     return -2 * inner.sum(-2)
 
 
+def _fused_shape_ok(src, ref, g):
+    return (g.shape == src.shape and src.shape[-1] % 4 == 0 and ref.shape[-1] <= 7 and torch.cuda.is_available()
+            and src.dtype == torch.float32 and ref.dtype == torch.float32
+            and os.environ.get("PHL_FUSED_GRAD", "1") != "0")         # A/B switch: the reference's formulation
+
+
 def _fused_grad(src, ref, g, need_src):
     """(grad_src | None, grad_ref) through phl_filter_grad: the products with ``ref`` are formed on the splat
     weights and the contraction happens inside the slice, so the 2L(1+d)-channel operand and result of :450-463
     (19 GB each at 1390x1110x256) never exist.  None when the fused path does not take the shape (then the caller
-    filters the wide operand, as the reference does)."""
-    if os.environ.get("PHL_FUSED_GRAD", "1") == "0":         # A/B switch: the reference's formulation
+    filters the wide operand, as the reference does).  ``src`` / ``ref`` may be [n, .] (one image) or [bs, n, .]
+    (a batch: items dealt over the devices and lattices of the batched forward pass)."""
+    if not _fused_shape_ok(src, ref, g) or src.dim() != ref.dim() or src.dim() not in (2, 3):
         return None
-    if not (src.dim() == 2 and ref.dim() == 2 and g.shape == src.shape and src.shape[1] % 4 == 0 and ref.shape[1] <= 7
-            and torch.cuda.is_available() and src.dtype == torch.float32 and ref.dtype == torch.float32):
-        return None
-    lat = phl.lattice_for(ref.detach())
     try:
-        gs, gr = lat.filter_grad(src, g, ref, need_src=need_src)
+        if src.dim() == 3:
+            return phl.batched_filter_grad(src, ref, g, need_src=need_src)
+        gs, gr = phl.lattice_for(ref.detach()).filter_grad(src, g, ref, need_src=need_src)
     except phl.PhlError as e:
         if e.status != 7:          # PHL_ERR_UNSUPPORTED: shape outside the fused path
             raise
         return None
-    dev = src.device
-    return (gs.to(dev) if gs is not None else None), gr.to(ref.device)
+    return (gs.to(src.device) if gs is not None else None), gr.to(ref.device)
 
 
 def _wide_operand(src, ref, g):
@@ -139,13 +143,11 @@ class BatchedLatticeFilter(Function):
         with torch.no_grad():
             g = grad_output
             if need_ref:
-                # item by item through the fused kernels (phl_filter_grad) where they take the shape
-                fused = [_fused_grad(srcs[i].contiguous(), refs[i].contiguous(), g[i].contiguous(), need_src)
-                         for i in range(srcs.shape[0])] if srcs.dim() == 3 else [None]
-                if all(f is not None for f in fused):
-                    grad_reference = torch.stack([f[1] for f in fused])
-                    if need_src:
-                        grad_source = torch.stack([f[0] for f in fused])
+                # item by item through the fused kernels (phl_filter_grad) where they take the shape, on the devices
+                # and cached lattices of the forward pass
+                fused = _fused_grad(srcs, refs, g, need_src)
+                if fused is not None:
+                    grad_source, grad_reference = fused
                 else:
                     wall = batched_filter(_wide_operand(srcs, refs, g), refs, ctx.num_threads)
                     grad_reference = _ref_gradient(srcs, refs, g, wall)

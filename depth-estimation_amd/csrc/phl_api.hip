@@ -777,23 +777,47 @@ int phl_filter_grad(phl_lattice *lat, const float *src, int64_t src_rs, const fl
                       "chunk splat available); filter the 2L(1+d)-channel operand instead");
         return PHL_ERR_UNSUPPORTED;
     }
+    // Workspace: the wide vertex rows (two ping-pong buffers) and the wide partial rows, (2M + S_multi) * (1+d) * Lg floats
+    // for a group of Lg channels.  The contraction is a sum over channels, so the call runs in CHANNEL GROUPS whenever
+    // all L at once would exceed the budget (PHL_GRAD_WS_MB, default 24576): features with little sharing push S_multi
+    // towards 2n, and (2M + S_multi)(1+d)L floats would then be as large as the reference's wide operand that this
+    // path exists to avoid.  Groups are multiples of 64 channels (the wide splat's slab) where L allows.
+    const char *ws_env = getenv("PHL_GRAD_WS_MB");      // (read per call: a backward pass is milliseconds, and tests vary it)
+    const int64_t ws_budget = (int64_t)(ws_env && atoll(ws_env) > 0 ? atoll(ws_env) : 24576) << 20;
+    const int64_t rows_ws = 2 * lat->M + lat->S_multi;
+    int Lg = L;
+    if (rows_ws * vdw * (int64_t)sizeof(float) > ws_budget) {
+        const int64_t per_ch = rows_ws * (d + 1) * (int64_t)sizeof(float);
+        int64_t fit = ws_budget / (per_ch > 0 ? per_ch : 1);
+        fit = fit >= 64 ? fit / 64 * 64 : fit / 4 * 4;
+        if (fit < 4) {
+            phl_set_error("phl_filter_grad: %lld vertex + partial rows do not fit the workspace budget even four channels at a time "
+                          "(PHL_GRAD_WS_MB)", (long long)rows_ws);
+            return PHL_ERR_UNSUPPORTED;
+        }
+        Lg = (int)(fit < L ? fit : L);
+    }
+    const int64_t vdg = (int64_t)Lg * (d + 1);
     phl_workspace *w = nullptr;
-    int rc = phl_ws_acquire(lat, st, lat->M * vdw, lat->S_multi * vdw, 0, &w);
+    int rc = phl_ws_acquire(lat, st, lat->M * vdg, lat->S_multi * vdg, 0, &w);
     if (rc) return rc;
     // Two passes of the same three stages, each over (1+d) L channels instead of the reference's 2 (1+d) L at once:
     //   pass 1  x = g,   y = src:  T  = -2 sum_l src (f Wg - W(g f))      (+ Wg itself = the gradient w.r.t. src)
     //   pass 2  x = src, y = g:    T += -2 sum_l g   (f Ws - W(s f))
     const float *xs[2] = {g, src}, *ys[2] = {src, g};
     const int64_t xrs[2] = {g_rs, src_rs}, yrs[2] = {src_rs, g_rs};
-    for (int pass = 0; pass < 2 && rc == PHL_OK; pass++) {
-        phl_splat_wide wide = {d + 1, ref, ref_rs, ref_cs};
-        rc = phl_launch_splat_tiled(lat, xs[pass], xrs[pass], L, w->buf[0], w->partial, st, false, nullptr, 0, nullptr, 0, &wide);
-        if (rc) break;
-        int cur = 0;
-        rc = blur_all(lat, w->buf, (int)vdw, st, &cur);
-        if (rc) break;
-        rc = phl_launch_slice_grad(lat, w->buf[cur], L, ys[pass], yrs[pass], ref, ref_rs, ref_cs, grad_ref, pass,
-                                   pass == 0 ? grad_src : nullptr, grad_src_rs, st);
+    for (int c0 = 0; c0 < L && rc == PHL_OK; c0 += Lg) {
+        const int Lc = L - c0 < Lg ? L - c0 : Lg;
+        for (int pass = 0; pass < 2 && rc == PHL_OK; pass++) {
+            phl_splat_wide wide = {d + 1, ref, ref_rs, ref_cs};
+            rc = phl_launch_splat_tiled(lat, xs[pass] + c0, xrs[pass], Lc, w->buf[0], w->partial, st, false, nullptr, 0, nullptr, 0, &wide);
+            if (rc) break;
+            int cur = 0;
+            rc = blur_all(lat, w->buf, Lc * (d + 1), st, &cur);
+            if (rc) break;
+            rc = phl_launch_slice_grad(lat, w->buf[cur], Lc, ys[pass] + c0, yrs[pass], ref, ref_rs, ref_cs, grad_ref, (pass || c0) ? 1 : 0,
+                                       (pass == 0 && grad_src) ? grad_src + c0 : nullptr, grad_src_rs, st);
+        }
     }
     phl_ws_release(lat, w, st, false);
     return rc;

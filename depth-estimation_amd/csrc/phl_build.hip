@@ -741,6 +741,25 @@ int phl_write_final_vids(phl_lattice *lat, hipStream_t st)
     return PHL_OK;
 }
 
+namespace {
+// side stream of the early pixel order (below), one per (thread, device)
+struct side_t {
+    int dev = -1;
+    hipStream_t s = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;
+};
+constexpr int MAX_SIDE_DEV = 64;
+thread_local side_t t_sides[MAX_SIDE_DEV];
+}  // namespace
+
+// test hook: side streams the calling thread holds (one per device it has built reference-table lattices on)
+extern "C" int phl_debug_side_streams(void)
+{
+    int k = 0;
+    for (int i = 0; i < MAX_SIDE_DEV; i++) k += t_sides[i].dev >= 0;
+    return k;
+}
+
 int phl_build_device(phl_lattice *lat, const float *ref, int64_t rs, int64_t cs, hipStream_t st)
 {
     const int d = lat->d;
@@ -897,23 +916,34 @@ int phl_build_device(phl_lattice *lat, const float *ref, int64_t rs, int64_t cs,
         char *arena2 = nullptr;
         under.bytes = phl_tiles_pixel_order_scratch_bytes(n);
         // (a second stream: on the caller's the replay's device queries would queue behind these launches)
-        struct side_t {
-            int dev = -1;
-            hipStream_t s = nullptr;
-            hipEvent_t fork = nullptr, join = nullptr;
-        };
-        thread_local side_t side;        // (never destroyed: a thread's exit may come after the runtime has shut down)
+        // one side stream per (thread, device): a thread that deals builds over several GPUs (phl.batched_filter, the NCHW
+        // mean field) comes back to each device's own stream instead of dropping and re-creating it
+        // (never destroyed: a thread's exit may come after the runtime has shut down)
+        side_t *const sides = t_sides;
+        side_t none;
+        side_t *sidep = &none;
         if (early) {
             int dev = -1;
-            if (hipGetDevice(&dev) == hipSuccess && dev != side.dev) {
-                side = side_t();
-                if (hipStreamCreateWithFlags(&side.s, hipStreamNonBlocking) == hipSuccess &&
-                    hipEventCreateWithFlags(&side.fork, hipEventDisableTiming) == hipSuccess &&
-                    hipEventCreateWithFlags(&side.join, hipEventDisableTiming) == hipSuccess)
-                    side.dev = dev;
-                else
-                    (void)hipGetLastError();
+            if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < MAX_SIDE_DEV) {
+                sidep = &sides[dev];
+                if (sidep->dev != dev) {                 // first build of this thread on this device
+                    side_t fresh;
+                    if (hipStreamCreateWithFlags(&fresh.s, hipStreamNonBlocking) == hipSuccess &&
+                        hipEventCreateWithFlags(&fresh.fork, hipEventDisableTiming) == hipSuccess &&
+                        hipEventCreateWithFlags(&fresh.join, hipEventDisableTiming) == hipSuccess) {
+                        fresh.dev = dev;
+                        *sidep = fresh;
+                    } else {                             // nothing half-made is kept
+                        (void)hipGetLastError();
+                        if (fresh.s) (void)hipStreamDestroy(fresh.s);
+                        if (fresh.fork) (void)hipEventDestroy(fresh.fork);
+                        if (fresh.join) (void)hipEventDestroy(fresh.join);
+                    }
+                }
+            } else {
+                (void)hipGetLastError();
             }
+            side_t &side = *sidep;
             if (side.dev == dev && dev >= 0 && tmp.get(&arena2, under.bytes) == hipSuccess) {
                 under.arena = arena2;
                 under.aux = side.s;

@@ -1059,7 +1059,8 @@ struct device_query : phl_reftable_query {
         int v = -1;
         int *dst = mailbox ? mailbox : &v;
         hipLaunchKernelGGL(k_vid_at, dim3(1), dim3(1), 0, st, table, slot_of, (int)e, scratch);
-        hipError_t r = hipMemcpyAsync(dst, scratch, sizeof(int), hipMemcpyDeviceToHost, st);
+        hipError_t r = hipGetLastError();
+        if (r == hipSuccess) r = hipMemcpyAsync(dst, scratch, sizeof(int), hipMemcpyDeviceToHost, st);
         if (r == hipSuccess) r = hipStreamSynchronize(st);
         if (r != hipSuccess) { err = r; return -1; }
         return *dst;
@@ -1071,7 +1072,8 @@ struct device_query : phl_reftable_query {
         hipError_t r = hipMemsetD32Async((hipDeviceptr_t)scratch, 0x7FFFFFFF, 1, st);
         if (r == hipSuccess) {
             hipLaunchKernelGGL(k_next_occurrence, dim3(1024), dim3(256), 0, st, slot_of, N, (int)efirst_host[vid], (int)after, scratch);
-            r = hipMemcpyAsync(dst, scratch, sizeof(int), hipMemcpyDeviceToHost, st);
+            r = hipGetLastError();
+            if (r == hipSuccess) r = hipMemcpyAsync(dst, scratch, sizeof(int), hipMemcpyDeviceToHost, st);
         }
         if (r == hipSuccess) r = hipStreamSynchronize(st);
         if (r != hipSuccess) { err = r; return -1; }
@@ -1192,7 +1194,23 @@ int phl_apply_reference_table(phl_lattice *lat, hipStream_t st, void *arena, siz
         dup_ptr_dev = lat->bt_dup_ptr;
         seg_e_dev = lat->bt_seg_e;
         seg_id_dev = lat->bt_seg_id;
-        std::vector<int32_t> dup_val;                     // (alive until the synchronisation below)
+        // Host vectors whose copies may still be queued, then the guard: on ANY early return it synchronises the stream
+        // first (it is destroyed before the vectors) and releases what the lattice does not own yet.
+        std::vector<int32_t> dup_val, dv_id, dv_e;
+        struct apply_guard {
+            hipStream_t st;
+            int16_t *vkeys_new = nullptr;
+            int *vfirst_clean = nullptr;
+            bool done = false;
+            ~apply_guard()
+            {
+                if (done) return;
+                (void)hipStreamSynchronize(st);
+                (void)hipGetLastError();
+                if (vkeys_new) (void)phl_dev_free(vkeys_new);
+                if (vfirst_clean) (void)phl_dev_free(vfirst_clean);
+            }
+        } guard{st};
         if (R.compact) {
             hipLaunchKernelGGL(k_ref_remap, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, st, (int)M, ex, remap_dev);
             if (!R.dup_clean.empty()) {                   // tracked keys: -(k+1), resolved per candidate by k_relabel
@@ -1215,13 +1233,13 @@ int phl_apply_reference_table(phl_lattice *lat, hipStream_t st, void *arena, siz
         }
         int16_t *vkeys_new;
         PHL_HIP(phl_dev_malloc((void **)&vkeys_new, sizeof(int16_t) * (size_t)R.M_ref * d));
+        guard.vkeys_new = vkeys_new;
         if (R.compact)
             hipLaunchKernelGGL(k_ref_keys, dim3((unsigned)((R.M_ref + 255) / 256)), dim3(256), 0, st, lat->vkeys, d, (int)R.M_ref, ex, vkeys_new);
         else
             PHL_HIP(hipMemcpyAsync(vkeys_new, R.keys.data(), sizeof(int16_t) * (size_t)R.M_ref * d, hipMemcpyHostToDevice, st));
         // first touches in the reference's numbering (phl_build_device would otherwise have to find every vertex's home
         // cell with an atomicMin over all N candidates: 1.1 ms at C3)
-        std::vector<int32_t> dv_id, dv_e;
         for (size_t k = 0; k + 1 < R.dup_ptr.size(); k++)
             for (int32_t sidx = R.dup_ptr[k]; sidx < R.dup_ptr[k + 1]; sidx++) {
                 size_t j = 0;
@@ -1236,6 +1254,7 @@ int phl_apply_reference_table(phl_lattice *lat, hipStream_t st, void *arena, siz
         PHL_HIP(tmp.get(&dv_e_dev, dv_e.size() + 1));
         int *vfirst_clean = lat->vfirst;              // (= efirst_dev: read by the launch below, released behind the sync)
         lat->vfirst = nullptr;
+        guard.vfirst_clean = vfirst_clean;
         PHL_HIP(phl_dev_malloc((void **)&lat->vfirst, sizeof(int) * (size_t)R.M_ref));
         PHL_HIP(hipMemsetAsync(lat->vfirst, 0, sizeof(int) * (size_t)R.M_ref, st));
         hipLaunchKernelGGL(k_vfirst_ref, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, st, remap_dev, efirst_dev, (int)M, lat->vfirst);
@@ -1246,8 +1265,9 @@ int phl_apply_reference_table(phl_lattice *lat, hipStream_t st, void *arena, siz
         }
         PHL_HIP(hipGetLastError());
         PHL_HIP(hipStreamSynchronize(st));            // host vectors and pool temporaries die on return
-        PHL_HIP(phl_dev_free(vfirst_clean));
-        PHL_HIP(phl_dev_free(lat->vkeys));
+        guard.done = true;                            // from here on the lattice owns vkeys_new; vfirst_clean goes now
+        (void)phl_dev_free(vfirst_clean);
+        (void)phl_dev_free(lat->vkeys);
         lat->vkeys = vkeys_new;
         lat->M = R.M_ref;
         lat->vfirst_valid_for_M = R.M_ref;

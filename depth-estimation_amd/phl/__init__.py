@@ -119,11 +119,48 @@ def _stream(device):
     return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
+_STAGE_BYTES = 8 << 20       # pinned staging piece of the host <-> device copies below
+
+
+def to_device(t, device):
+    """``t.to(device)`` for the reference's calling convention -- pageable CPU tensors (DenseCrf.ipynb:142-152 hands
+    CPU tensors to mean_field_infer): large contiguous fp32 tensors go through pinned staging pieces from torch's
+    caching host allocator, so that the host-side memcpy of piece k+1 runs under the DMA of piece k (a plain
+    ``.to(device)`` of pageable memory stages serially inside the runtime).  Enqueued on the current stream."""
+    device = torch.device(device)
+    if t.device == device:
+        return t
+    if t.is_cuda or t.is_pinned() or not t.is_contiguous() or t.numel() * t.element_size() < (1 << 20):
+        return t.to(device, non_blocking=(not t.is_cuda and t.is_pinned()))
+    out = torch.empty(t.shape, dtype=t.dtype, device=device)
+    src, dst = t.reshape(-1), out.view(-1)
+    step = max(1, _STAGE_BYTES // t.element_size())
+    for a in range(0, src.numel(), step):
+        b = min(src.numel(), a + step)
+        stage = torch.empty(b - a, dtype=t.dtype, pin_memory=True)
+        stage.copy_(src[a:b])
+        dst[a:b].copy_(stage, non_blocking=True)     # (the host allocator keeps the piece until this copy has run)
+    return out
+
+
+def to_host(t):
+    """Device tensor -> CPU tensor in pinned memory (one DMA, no bounce through the runtime's staging buffers);
+    returns after the copy has completed."""
+    if not t.is_cuda:
+        return t
+    if t.numel() * t.element_size() < (1 << 20):
+        return t.cpu()
+    out = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+    out.copy_(t, non_blocking=True)
+    torch.cuda.current_stream(t.device).synchronize()
+    return out
+
+
 def _as_device(t, device):
     if t.dtype != torch.float32:
         # the reference extension is float-only (accessor<float,2>, permutohedral.h:214-215)
         raise TypeError(f"phl: expected float32 tensor, got {t.dtype}")
-    return t if t.device == device else t.to(device)
+    return t if t.device == device else to_device(t, device)
 
 
 _parked = []    # lattice handles whose owner died during a stream capture; freed by the next close()
@@ -208,7 +245,9 @@ class Lattice:
         if out is not None and out is not res:
             out.copy_(res)
             return out
-        return res if src.device == self.device else res.to(src.device)
+        if src.device == self.device:
+            return res
+        return to_host(res) if src.device.type == "cpu" else res.to(src.device)
 
     # ---- stages (profiling / parity of intermediates) ---------------------------------------
     def splat(self, src, exact=False, no_tiles=False, out=None):
@@ -564,14 +603,21 @@ _REFERENCE_TABLE = os.environ.get("PHL_REFERENCE_TABLE", "1") not in ("", "0")
 
 
 def _cache_key(ref, device=None):
-    dev = None if device is None else (torch.device(device).type, torch.device(device).index)
-    return (ref.device.type, ref.device.index, ref.data_ptr(), tuple(ref.shape), tuple(ref.stride()), ref._version, dev)
+    # device=None means what Lattice() resolves it to (ref's own GPU, or the current one for a CPU tensor): the same
+    # lattice must be found whether a caller names that device or not (forward with device=dev, backward without)
+    if device is None:
+        device = ref.device if ref.is_cuda else torch.device("cuda", torch.cuda.current_device())
+    device = torch.device(device)
+    idx = device.index if device.index is not None else (torch.cuda.current_device() if device.type == "cuda" else None)
+    return (ref.device.type, ref.device.index, ref.data_ptr(), tuple(ref.shape), tuple(ref.stride()), ref._version,
+            (device.type, idx))
 
 
 def lattice_for(ref, device=None):
     """Cached Lattice for ``ref`` (built on ``device``; default: ref's own device, or the current one for a CPU
     tensor).  The entry keeps ``ref`` alive, so its storage address cannot be recycled while cached; an in-place
     update bumps ``ref._version`` and misses."""
+    _require_gpu()
     if _CACHE_SIZE <= 0:
         return Lattice(ref, device=device, reference_table=_REFERENCE_TABLE)
     key = _cache_key(ref, device)
@@ -647,6 +693,44 @@ def batched_filter(srcs, refs, devices=None, subtract_input=False):
         else:
             st.synchronize()
     return out
+
+
+def batched_filter_grad(srcs, refs, g, need_src=True, devices=None):
+    """Per-item Lattice.filter_grad for a batch (the body of BatchedLatticeFilter.backward, crf/gaussian_matrix.py:402-421):
+    srcs, g [bs, n, L], refs [bs, n, d] (any strides) -> (grad_srcs [bs, n, L] or None, grad_refs [bs, n, d]) on the
+    inputs' devices.  Items are dealt over the same devices and side streams as batched_filter, so every item meets the
+    lattice its forward pass cached.  Raises PhlError(status 7) if the fused kernels do not take the shape."""
+    bs = srcs.shape[0]
+    devices = [torch.device(d) for d in (devices or batch_devices(srcs))]
+    home = srcs.device
+    grad_refs = torch.empty(tuple(refs.shape), dtype=torch.float32, device=refs.device)
+    grad_srcs = torch.empty(tuple(srcs.shape), dtype=torch.float32, device=home) if need_src else None
+    used = []
+    for i in range(bs):
+        dev = devices[i % len(devices)]
+        st = _batch_streams.get(dev)
+        if st is None:
+            st = _batch_streams[dev] = torch.cuda.Stream(device=dev)
+        for t in (srcs, refs, g):
+            if t.is_cuda:
+                st.wait_stream(torch.cuda.current_stream(t.device))
+        with torch.cuda.device(dev), torch.cuda.stream(st):
+            r = refs[i].detach()
+            lat = lattice_for(r, device=dev)
+            gs, gr = lat.filter_grad(srcs[i].detach().to(dev, non_blocking=True), g[i].detach().to(dev, non_blocking=True),
+                                     r.to(dev, non_blocking=True), need_src=need_src)
+            grad_refs[i].copy_(gr, non_blocking=True)
+            if need_src:
+                grad_srcs[i].copy_(gs, non_blocking=True)
+        used.append((dev, st))
+    outs = [t for t in (grad_refs, grad_srcs) if t is not None]
+    for dev, st in used:
+        for t in outs:
+            if t.is_cuda:
+                torch.cuda.current_stream(t.device).wait_stream(st)
+        if any(not t.is_cuda for t in outs):
+            st.synchronize()
+    return grad_srcs, grad_refs
 
 
 def filter(src, ref):

@@ -305,6 +305,10 @@ int phl_debug_probe_paths(const int16_t *keys_clean, int64_t n_clean, int d, con
                           const int32_t *stale_clean, int n_stale, uint64_t cap, const int32_t *check, int n_check,
                           int on_device, int *result_out);
 
+/* Test hook: side streams the calling thread holds for the reference-table build (one per device the thread has
+ * built such a lattice on; building on devices A, B, A, B ... must not create more than two). */
+int phl_debug_side_streams(void);
+
 #ifdef __cplusplus
 }
 #endif

@@ -316,6 +316,60 @@ def mean_field_wide_cases(report):
     report.append(dict(case="crfasrnn_nchw", shape=list(logits.shape), niters=3))
 
 
+def round4_cases(report):
+    """Round 4: (i) a reference-autograd vector INSIDE the fused backward's envelope at a width that takes k_splat_wide
+    (d = 5, L = 64, image-like features: 48 x 64 pixels), (ii) the flat mean field at the notebook's own label count
+    L = 384 // 6 = 64 (DenseCrf.ipynb:95-115, crf/depth.py:40) on a Tsukuba crop, 1 and 5 iterations.  Inputs of (i) are
+    stored as float16 (the values are rounded to float16 first, so the stored inputs are exact)."""
+    import torch
+
+    torch.manual_seed(2)
+    torch.set_num_threads(1)
+    crf_module, gm = import_reference_python()
+    imL = read_image(os.path.join(REFERENCE, "Experiments", "imL.png"))
+    imR = read_image(os.path.join(REFERENCE, "Experiments", "imR.png"))
+    H, W_ = imL.shape[:2]
+    position = np.mgrid[:H, :W_].transpose((1, 2, 0)) / np.sqrt(H ** 2 + W_ ** 2)
+
+    # (i) gradient through the lattice, image-like features
+    r0, c0, h, w, Lc = 130, 200, 48, 64, 64
+    refimg = np.zeros((h, w, 5))
+    refimg[..., :3] = imL[r0:r0 + h, c0:c0 + w] / 0.125
+    refimg[..., 3:] = position[r0:r0 + h, c0:c0 + w] / 0.01
+    rng = np.random.default_rng(404)
+    ref_np = refimg.reshape(h * w, 5).astype(np.float32)
+    src_np = rng.random((h * w, Lc)).astype(np.float16).astype(np.float32)
+    gout_np = rng.standard_normal((h * w, Lc)).astype(np.float16).astype(np.float32)
+    ref = torch.from_numpy(ref_np).requires_grad_(True)
+    src = torch.from_numpy(src_np).requires_grad_(True)
+    out = gm.LatticeFilter.apply(src, ref)
+    out.backward(torch.from_numpy(gout_np))
+    np.savez_compressed(os.path.join(HERE, "grad_image_48x64_d5_L64.npz"), ref=ref_np, src_f16=src_np.astype(np.float16),
+                        gout_f16=gout_np.astype(np.float16), grad_src=src.grad.numpy(), grad_ref=ref.grad.numpy(),
+                        h=np.int64(h), w=np.int64(w))
+    report.append(dict(case="grad_image_48x64_d5_L64", n=h * w, d=5, L=Lc))
+
+    # (ii) flat mean field at L = 64
+    L, sigma_c, sigma_p, gamma = 64, 0.1, 0.1, 3
+    full = disparity_badness(imL, imR, L)
+    r0, c0, h, w = 150, 240, 32, 48
+    E0 = torch.from_numpy(full[r0:r0 + h, c0:c0 + w].reshape(-1, L)).float()
+    refimg = np.zeros((h, w, 5))
+    refimg[..., :3] = imL[r0:r0 + h, c0:c0 + w] / sigma_c
+    refimg[..., 3:] = position[r0:r0 + h, c0:c0 + w] / sigma_p
+    flat_ref = torch.from_numpy(refimg.reshape(h * w, -1).astype(np.float32))
+    labels = torch.arange(L).float()
+    Mu = crf_module.compatibility_matrix(lambda a, b: crf_module.charbonneir(a, b, gamma), labels)
+    Wop = gm.LatticeGaussian(flat_ref)
+    with torch.no_grad():
+        Q1 = crf_module.mean_field_infer(E0, Wop, Mu, 1)
+        Q5 = crf_module.mean_field_infer(E0, Wop, Mu, 5)
+    np.savez_compressed(os.path.join(HERE, "meanfield_tsukuba_L64.npz"), E0=E0.numpy(), ref=flat_ref.numpy(),
+                        labels=labels.numpy(), gamma=np.float32(gamma), Q1=Q1.numpy(), Q5=Q5.numpy(),
+                        disp1=(Q1 @ labels).numpy(), disp5=(Q5 @ labels).numpy(), h=np.int64(h), w=np.int64(w))
+    report.append(dict(case="meanfield_tsukuba_L64", n=h * w, L=L, d=5))
+
+
 def import_reference_depth():
     import importlib.util
 
@@ -383,6 +437,14 @@ def main():
         with open(os.path.join(HERE, "PIN_REPORT.json"), "w") as f:
             json.dump(report, f, indent=1)
         return
+    if sys.argv[1:] == ["round4"]:
+        assert po.build_reference(), "reference engine not built"
+        report = json.load(open(os.path.join(HERE, "PIN_REPORT.json")))
+        report = [r for r in report if r.get("case") not in ("grad_image_48x64_d5_L64", "meanfield_tsukuba_L64")]
+        round4_cases(report)
+        with open(os.path.join(HERE, "PIN_REPORT.json"), "w") as f:
+            json.dump(report, f, indent=1)
+        return
     if sys.argv[1:] == ["growth"]:           # add / refresh the stored table-growth cases only
         po.build_oracle(force=True)
         assert po.build_reference(), "reference engine not built"
@@ -404,6 +466,7 @@ def main():
     growth_cases(report)
     python_layer_cases(report)
     mean_field_wide_cases(report)
+    round4_cases(report)
     cost_volume_cases(report)
     with open(os.path.join(HERE, "PIN_REPORT.json"), "w") as f:
         json.dump(report, f, indent=1)

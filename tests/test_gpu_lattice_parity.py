@@ -346,6 +346,42 @@ def test_wide_crop_of_c2_against_oracle(phl):
     assert e <= 1e-5
 
 
+@pytest.mark.parametrize("vd", [1, 3])
+def test_narrow_values_at_c2_geometry(phl, vd):
+    """Value tensors that are not a multiple of four channels wide -- the degree vector of RbfLaplacian (vd = 1,
+    crf/gaussian_matrix.py:311-312) and RGB (vd = 3, crf/lattice/lite/test_bilateral.ipynb) -- on configs[1]'s geometry:
+    the full-size call for determinism and timing, a 250 x 330 crop against the CPU oracle (bit-identical in exact
+    mode).  These widths run on the scalar-lane gather kernels (the staged kernels move 16-byte pieces)."""
+    import time
+
+    sys_path_bench = __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__)))
+    __import__("sys").path.insert(0, sys_path_bench)
+    import bench
+    from oracle import phl_oracle as po
+
+    H, W, _, _ = bench.WORKLOADS["c2"]
+    feat = bench.synthetic_features(H, W)
+    dev = torch.device("cuda")
+    Lat = phl.Lattice(torch.from_numpy(feat.reshape(-1, 5)).to(dev), reference_table=True)
+    x = torch.rand((H * W, vd), device=dev, generator=torch.Generator(device=dev).manual_seed(vd))
+    a = Lat.filter(x)
+    assert torch.equal(a, Lat.filter(x)) and torch.isfinite(a).all()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(20):
+        Lat.filter(x, out=a)
+    torch.cuda.synchronize()
+    print(f"[measured] c2 geometry, vd = {vd}: {(time.perf_counter() - t0) / 20 * 1e3:.3f} ms per filter call")
+    crop = np.ascontiguousarray(feat[H - 250:, W - 330:].reshape(-1, 5))
+    xs = np.random.default_rng(vd).random((crop.shape[0], vd), dtype=np.float32)
+    want = po.Oracle(crop, faithful_table=True).filter(xs)
+    cl = phl.Lattice(torch.from_numpy(crop).to(dev), reference_table=True)
+    got = cl.filter(torch.from_numpy(xs).to(dev)).cpu().numpy()
+    assert rel_err(got, want) <= 1e-5
+    gote = cl.filter(torch.from_numpy(xs).to(dev), exact=True).cpu().numpy()
+    assert np.array_equal(gote.view(np.uint32), want.view(np.uint32))
+
+
 GROWTH = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "growth_*.npz")))
 
 
@@ -892,3 +928,35 @@ def test_concurrent_builds_from_threads(phl):
     for t in threads:
         t.join()
     assert not errs, errs
+
+
+def test_side_stream_of_the_table_replay_is_kept_per_device(phl):
+    """The reference-table build launches the chunk build's pixel order on a side stream under the host's table replay.
+    A thread keeps ONE such stream per device it builds on (a thread that deals batch items over several GPUs used to
+    drop and re-create it at every device switch: one leaked stream and two events per build).  On one GPU: any number
+    of builds hold one stream; with more than one GPU visible, builds alternating between two devices hold two."""
+    import ctypes
+    import threading
+
+    import bench
+
+    lib = phl.load_library()
+    lib.phl_debug_side_streams.restype = ctypes.c_int
+    feat = bench.synthetic_features(192, 512, sigma_xy=3.0).reshape(-1, 5)
+    ndev = torch.cuda.device_count()
+    seen = {}
+
+    def work():
+        devs = [torch.device("cuda", i) for i in range(min(ndev, 2))]
+        for it in range(6):
+            dev = devs[it % len(devs)]
+            lat = phl.Lattice(torch.from_numpy(feat).to(dev), reference_table=True)
+            assert lat.M > 16383                      # goes through the replay
+            lat.close()
+        seen["count"] = lib.phl_debug_side_streams()
+        seen["devs"] = len(devs)
+
+    t = threading.Thread(target=work)                 # a fresh thread: its own thread-local table
+    t.start()
+    t.join()
+    assert seen["count"] == seen["devs"], seen

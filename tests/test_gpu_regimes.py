@@ -110,6 +110,9 @@ def test_flat_smooth_and_noisy_regions_in_one_image(phl, L):
     def expect(lat, stats):
         # one image holds chunks the 256-channel slab takes whole and chunks nothing can stage
         assert stats["max_local_vertices"] > 1000, stats
+        # ... and still runs on the staged kernels: per-workgroup slab widths in the slice, chunk
+        # classes in the splat -- no chunk forces the whole image onto the gather kernels
+        assert stats["staged_splat"] == 1 and stats["staged_slice"] == 1, stats
 
     lat, stats = _check_against_oracle(phl, feat, L, 3, expect)
     print(f"mixed image L={L}: M/n {lat.M / (H * W):.3f} tiles {stats}")
