@@ -522,6 +522,7 @@ int phl_add_vertices(phl_lattice *lat, const int16_t *keys_host, int64_t count, 
     device_guard g(lat->device);
     const int64_t M_before = lat->M;
     int rc = phl_add_vertices_device(lat, keys_host, count, vid_host, (hipStream_t)stream);
+    lat->blur_rows_set = 0;            // row ranges are rows of the old vertex array
     if (rc == PHL_OK && lat->M != M_before) {
         rc = phl_tiles_link_vertices(lat, (hipStream_t)stream);
         // the value workspaces are sized by M and S_multi: drop them (not a concurrent operation: the lattice is
@@ -530,6 +531,35 @@ int phl_add_vertices(phl_lattice *lat, const int16_t *keys_host, int64_t count, 
         for (phl_workspace *w : lat->shared->ws) ws_free_buffers(w);
     }
     return rc;
+}
+
+int phl_set_blur_rows(phl_lattice *lat, const int64_t *ranges, int naxes)
+{
+    if (!lat) { phl_set_error("phl_set_blur_rows: bad arguments"); return PHL_ERR_INVALID; }
+    if (!ranges || naxes == 0) {        // back to all rows on every axis
+        lat->blur_rows_set = 0;
+        return PHL_OK;
+    }
+    if (naxes != lat->d + 1) { phl_set_error("phl_set_blur_rows: %d axes given, the lattice has %d", naxes, lat->d + 1); return PHL_ERR_INVALID; }
+    for (int a = 0; a < naxes; a++) {
+        int64_t prev_end = 0;
+        for (int k = 0; k < 3; k++) {
+            const int64_t b = ranges[(a * 3 + k) * 2], e = ranges[(a * 3 + k) * 2 + 1];
+            if (b < prev_end || e < b || e > lat->M) {
+                phl_set_error("phl_set_blur_rows: axis %d range %d = [%lld, %lld) is not ascending / inside [0, %lld)", a, k, (long long)b,
+                              (long long)e, (long long)lat->M);
+                return PHL_ERR_INVALID;
+            }
+            prev_end = e;
+        }
+    }
+    for (int a = 0; a < naxes; a++)
+        for (int k = 0; k < 3; k++) {
+            lat->blur_rows[a][k][0] = (int32_t)ranges[(a * 3 + k) * 2];
+            lat->blur_rows[a][k][1] = (int32_t)ranges[(a * 3 + k) * 2 + 1];
+        }
+    lat->blur_rows_set = 1;
+    return PHL_OK;
 }
 
 namespace {
@@ -636,6 +666,25 @@ int phl_splat_part(phl_lattice *lat, const float *src, int vd, int64_t src_rs, f
                                   (int)nchunks_sel, rows_dev, nrows);
 }
 
+int phl_splat_part_pack(phl_lattice *lat, const float *src, int vd, int64_t src_rs, float *vert, float *partial_dev,
+                        const int32_t *chunks_dev, int64_t nchunks_sel, const int32_t *rows_dev, int64_t nrows,
+                        const int32_t *pack_pos_dev, float *pack_dev, int64_t pack_rs, phl_stream st)
+{
+    if (!lat || vd < 0 || nchunks_sel < 0 || nrows < 0 || !vert || (nchunks_sel > 0 && (!chunks_dev || !src)) || (nrows > 0 && !rows_dev) ||
+        (lat->S_multi > 0 && !partial_dev) || (pack_pos_dev && (!pack_dev || pack_rs < vd || pack_rs % 4 ||
+                                                                   (reinterpret_cast<uintptr_t>(pack_dev) & 15)))) {
+        phl_set_error("phl_splat_part_pack: bad arguments");
+        return PHL_ERR_INVALID;
+    }
+    device_guard g(lat->device);
+    if (!use_tiled_splat(lat, vd, 0, src, vert, src_rs) || (reinterpret_cast<uintptr_t>(partial_dev) & 15)) {
+        phl_set_error("phl_splat_part_pack: the chunk splat is not available for this shape (vd %% 4, alignment, sharing)");
+        return PHL_ERR_UNSUPPORTED;
+    }
+    return phl_launch_splat_tiled(lat, src, src_rs, vd, vert, partial_dev, (hipStream_t)st, /*subset=*/true, chunks_dev,
+                                  (int)nchunks_sel, rows_dev, nrows, nullptr, pack_pos_dev, pack_dev, pack_rs);
+}
+
 int phl_blur_axis(phl_lattice *lat, int axis, const float *vin, float *vout, int vd, phl_stream st)
 {
     if (!lat || axis < 0 || axis > lat->d || vd < 0 || vin == vout) { phl_set_error("phl_blur_axis: bad arguments"); return PHL_ERR_INVALID; }
@@ -651,10 +700,10 @@ static int blur_all(const phl_lattice *lat, float *const buf[2], int vd, hipStre
     for (int axis = 0; axis <= lat->d;) {  // axis order 0..d, Jacobi ping-pong (:498, :530-532)
         int rc;
         if (pairs && axis + 1 <= lat->d && lat->nbr2) {
-            rc = phl_launch_blur2(lat, axis / 2, buf[cur], buf[cur ^ 1], vd, st);
+            rc = phl_launch_blur2(lat, axis / 2, buf[cur], buf[cur ^ 1], vd, st, /*restricted=*/true);
             axis += 2;
         } else {
-            rc = phl_launch_blur(lat, axis, buf[cur], buf[cur ^ 1], vd, st);
+            rc = phl_launch_blur(lat, axis, buf[cur], buf[cur ^ 1], vd, st, /*restricted=*/true);
             axis += 1;
         }
         if (rc) return rc;

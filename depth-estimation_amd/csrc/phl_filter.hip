@@ -156,12 +156,21 @@ __global__ __launch_bounds__(256) void k_splat(const float *__restrict__ src, in
     }
 }
 
+// Rows a blur launch computes: logical index j in [0, total) -> row, over up to three ascending row ranges (a row-band
+// lattice computes, per axis, only the rows whose output something later reads: phl_set_blur_rows).  Unrestricted:
+// one range [0, M).  M stays the array extent (neighbour ids are rows of the whole array).
+struct blur_rows_t {
+    int n0, n01, total;     // rows in range 0, in ranges 0 + 1, in all
+    int b0, b1, b2;         // first row of each range
+    __device__ __forceinline__ int64_t row(int64_t j) const { return j < n0 ? b0 + j : (j < n01 ? b1 + (j - n0) : b2 + (j - n01)); }
+};
+
 // ------------------------------------------------------------------------------------------
 // blur along one lattice axis (Jacobi): out[v] = 2*(1/4 in[n1(v)] + 1/2 in[v] + 1/4 in[n2(v)]),
 // absent neighbour = 0 (the reference never creates vertices in blur, :516-522).
 template <int VEC, int LPR>
 __global__ __launch_bounds__(256) void k_blur(const float *__restrict__ vin, float *__restrict__ vout,
-                                              const int2 *__restrict__ nbr, int M, int vd, int xcd_chunk)
+                                              const int2 *__restrict__ nbr, int M, int vd, int xcd_chunk, const blur_rows_t rr)
 {
     using V = typename vec_of<VEC>::type;
     constexpr int G = 64 / LPR;
@@ -176,13 +185,14 @@ __global__ __launch_bounds__(256) void k_blur(const float *__restrict__ vin, flo
     const int lb = xcd_chunk > 0 ? (int)(blockIdx.x & 7) * xcd_chunk + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
     const int wv = lb * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     {
-        const int64_t v0 = (int64_t)wv * G * U;
-        if (v0 >= M) return;
-        int64_t v[U];
+        const int64_t j0 = (int64_t)wv * G * U;
+        if (j0 >= rr.total) return;
+        int64_t v[U];                 // row of each group's vertex; M = none (past the end)
         int2 nb[U];
 #pragma unroll
         for (int u = 0; u < U; u++) {
-            v[u] = v0 + u * G + sub;
+            const int64_t j = j0 + u * G + sub;
+            v[u] = j < rr.total ? rr.row(j) : (int64_t)M;
             nb[u] = v[u] < M ? nbr[v[u]] : make_int2(-1, -1);
         }
         for (int c = l * VEC; c < vd; c += LPR * VEC) {
@@ -216,7 +226,7 @@ __global__ __launch_bounds__(256) void k_blur(const float *__restrict__ vin, flo
 // ids per vertex (k_compose_pairs): { a-(b-), b-, a+(b-), a-(v) | a+(v), a-(b+), b+, a+(b+) }.
 template <int VEC, int LPR, int U>
 __global__ __launch_bounds__(256) void k_blur2(const float *__restrict__ vin, float *__restrict__ vout,
-                                               const int4 *__restrict__ nb2, int M, int vd, int xcd_chunk)
+                                               const int4 *__restrict__ nb2, int M, int vd, int xcd_chunk, const blur_rows_t rr)
 {
     using V = typename vec_of<VEC>::type;
     constexpr int G = 64 / LPR;
@@ -225,13 +235,14 @@ __global__ __launch_bounds__(256) void k_blur2(const float *__restrict__ vin, fl
     const int l = lane % LPR;
     const int lb = xcd_chunk > 0 ? (int)(blockIdx.x & 7) * xcd_chunk + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
     const int wv = lb * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int64_t v0 = (int64_t)wv * G * U;
-    if (v0 >= M) return;
-    int64_t v[U];
+    const int64_t j0 = (int64_t)wv * G * U;
+    if (j0 >= rr.total) return;
+    int64_t v[U];                     // row of each group's vertex; M = none (past the end)
     int id[U][8];
 #pragma unroll
     for (int u = 0; u < U; u++) {
-        v[u] = v0 + u * G + sub;
+        const int64_t j = j0 + u * G + sub;
+        v[u] = j < rr.total ? rr.row(j) : (int64_t)M;
         const int64_t vc = v[u] < M ? v[u] : (int64_t)M - 1;
         const int4 i0 = nb2[vc * 2], i1 = nb2[vc * 2 + 1];
         id[u][0] = i0.x; id[u][1] = i0.y; id[u][2] = i0.z; id[u][3] = i0.w;
@@ -448,15 +459,35 @@ int phl_launch_splat(phl_lattice *lat, const float *src, int64_t src_rs, int vd,
     return PHL_OK;
 }
 
-int phl_launch_blur(const phl_lattice *lat, int axis, const float *vin, float *vout, int vd, hipStream_t st)
+// the rows a pass whose last axis is `axis` computes
+static blur_rows_t rows_of(const phl_lattice *lat, int axis, bool restricted)
+{
+    blur_rows_t r;
+    const int M = (int)lat->M;
+    if (!restricted || !lat->blur_rows_set) {
+        r.n0 = r.n01 = r.total = M;
+        r.b0 = r.b1 = r.b2 = 0;
+        return r;
+    }
+    const int32_t(*g)[2] = lat->blur_rows[axis];
+    r.b0 = g[0][0]; r.b1 = g[1][0]; r.b2 = g[2][0];
+    r.n0 = g[0][1] - g[0][0];
+    r.n01 = r.n0 + (g[1][1] - g[1][0]);
+    r.total = r.n01 + (g[2][1] - g[2][0]);
+    return r;
+}
+
+int phl_launch_blur(const phl_lattice *lat, int axis, const float *vin, float *vout, int vd, hipStream_t st, bool restricted)
 {
     const int M = (int)lat->M;
     if (M == 0 || vd == 0) return PHL_OK;
+    const blur_rows_t rr = rows_of(lat, axis, restricted);
+    if (rr.total == 0) return PHL_OK;
     const int2 *nbr = reinterpret_cast<const int2 *>(lat->nbr) + (int64_t)axis * M;
     const bool v4 = (vd % 4 == 0) && aligned16(vin) && aligned16(vout);
     const int lpr = pick_lpr(vd, v4 ? 4 : 1);
     const int rows_per_block = (64 / lpr) * 4 * 4;
-    int64_t blocks = ((int64_t)M + rows_per_block - 1) / rows_per_block;
+    int64_t blocks = ((int64_t)rr.total + rows_per_block - 1) / rows_per_block;
     static const bool xcd = !(getenv("PHL_XCD") && atoi(getenv("PHL_XCD")) == 0);
     int xcd_chunk = 0;
     if (xcd && blocks >= 64) {
@@ -466,8 +497,8 @@ int phl_launch_blur(const phl_lattice *lat, int axis, const float *vin, float *v
     const unsigned grid = (unsigned)blocks;
     dispatch_lpr(lpr, [&](auto L) {
         constexpr int LPR = decltype(L)::value;
-        if (v4) k_blur<4, LPR><<<dim3(grid), dim3(256), 0, st>>>(vin, vout, nbr, M, vd, xcd_chunk);
-        else k_blur<1, LPR><<<dim3(grid), dim3(256), 0, st>>>(vin, vout, nbr, M, vd, xcd_chunk);
+        if (v4) k_blur<4, LPR><<<dim3(grid), dim3(256), 0, st>>>(vin, vout, nbr, M, vd, xcd_chunk, rr);
+        else k_blur<1, LPR><<<dim3(grid), dim3(256), 0, st>>>(vin, vout, nbr, M, vd, xcd_chunk, rr);
     });
     PHL_HIP(hipGetLastError());
     return PHL_OK;
@@ -491,16 +522,18 @@ int phl_launch_rows(bool scatter, float *vert, int vd, const int64_t *idx, int64
     return PHL_OK;
 }
 
-int phl_launch_blur2(const phl_lattice *lat, int pair, const float *vin, float *vout, int vd, hipStream_t st)
+int phl_launch_blur2(const phl_lattice *lat, int pair, const float *vin, float *vout, int vd, hipStream_t st, bool restricted)
 {
     const int M = (int)lat->M;
     if (M == 0 || vd == 0) return PHL_OK;
+    const blur_rows_t rr = rows_of(lat, 2 * pair + 1, restricted);      // out = blur_b(blur_a(in)): the rows axis b's output is read at
+    if (rr.total == 0) return PHL_OK;
     const int4 *nb2 = reinterpret_cast<const int4 *>(lat->nbr2) + (int64_t)pair * M * 2;
     const bool v4 = (vd % 4 == 0) && aligned16(vin) && aligned16(vout);
     const int lpr = pick_lpr(vd, v4 ? 4 : 1);
     constexpr int U2 = 1;   // row groups in flight per wave: 9 row loads each; 1 measured best (2: +3 %, 4: +15 %)
     const int rows_per_block = (64 / lpr) * U2 * 4;
-    int64_t blocks = ((int64_t)M + rows_per_block - 1) / rows_per_block;
+    int64_t blocks = ((int64_t)rr.total + rows_per_block - 1) / rows_per_block;
     static const bool xcd = !(getenv("PHL_XCD") && atoi(getenv("PHL_XCD")) == 0);
     int xcd_chunk = 0;
     if (xcd && blocks >= 64) {
@@ -510,8 +543,8 @@ int phl_launch_blur2(const phl_lattice *lat, int pair, const float *vin, float *
     const unsigned grid = (unsigned)blocks;
     dispatch_lpr(lpr, [&](auto L) {
         constexpr int LPR = decltype(L)::value;
-        if (v4) k_blur2<4, LPR, U2><<<dim3(grid), dim3(256), 0, st>>>(vin, vout, nb2, M, vd, xcd_chunk);
-        else k_blur2<1, LPR, U2><<<dim3(grid), dim3(256), 0, st>>>(vin, vout, nb2, M, vd, xcd_chunk);
+        if (v4) k_blur2<4, LPR, U2><<<dim3(grid), dim3(256), 0, st>>>(vin, vout, nb2, M, vd, xcd_chunk, rr);
+        else k_blur2<1, LPR, U2><<<dim3(grid), dim3(256), 0, st>>>(vin, vout, nb2, M, vd, xcd_chunk, rr);
     });
     PHL_HIP(hipGetLastError());
     return PHL_OK;

@@ -91,6 +91,10 @@ struct phl_lattice {
     // PHL_BUILD_REFERENCE_TABLE (phl_reftable.hip): vertices the reference's final hash table cannot reach
     // (duplicates of a key; never anybody's blur neighbour), and the one neighbour entry a doubling inside
     // blur() decides (-2 = none)
+    // Row-band lattices (phl_set_blur_rows): for every blur axis the rows whose OUTPUT of that axis anything later
+    // reads, as up to three ascending row ranges {begin, end}; blur_rows_set = 0: all M rows on every axis.
+    int blur_rows_set;
+    int32_t blur_rows[PHL_MAX_D + 1][3][2];
     unsigned build_flags;
     int n_hidden;
     int32_t hidden[PHL_MAX_HIDDEN];
@@ -224,7 +228,9 @@ struct phl_splat_wide {
 };
 int phl_launch_splat_tiled(phl_lattice *lat, const float *src, int64_t src_rs, int vd, float *vert, float *partial,
                            hipStream_t st, bool subset = false, const int *chunk_list = nullptr, int nlist = 0,
-                           const int *vlist = nullptr, int64_t nvl = 0, const phl_splat_wide *wide = nullptr);
+                           const int *vlist = nullptr, int64_t nvl = 0, const phl_splat_wide *wide = nullptr,
+                           const int *pack_pos = nullptr, float *pack = nullptr, int64_t pack_rs = 0);
+// (pack_pos / pack: subset calls only -- listed row i is also written to pack[pack_pos[i]] (pack_pos[i] < 0: not))
 // slice of a wide vertex buffer contracted to the feature gradient (phl_tiles.hip, k_slice_grad)
 int phl_launch_slice_grad(const phl_lattice *lat, const float *vertw, int L, const float *y, int64_t y_rs, const float *ref,
                           int64_t ref_rs, int64_t ref_cs, float *grad_ref, int accumulate, float *wx_out, int64_t wx_rs,
@@ -235,8 +241,9 @@ int phl_launch_slice_tiled(const phl_lattice *lat, const float *vert, int vd, fl
 
 // ---- launchers implemented in phl_filter.hip ----
 int phl_launch_splat(phl_lattice *lat, const float *src, int64_t src_rs, int vd, float *vert, hipStream_t st);
-int phl_launch_blur(const phl_lattice *lat, int axis, const float *vin, float *vout, int vd, hipStream_t st);
-int phl_launch_blur2(const phl_lattice *lat, int pair, const float *vin, float *vout, int vd, hipStream_t st);
+// (restricted: only the rows phl_set_blur_rows named for the pass's last axis are computed)
+int phl_launch_blur(const phl_lattice *lat, int axis, const float *vin, float *vout, int vd, hipStream_t st, bool restricted = false);
+int phl_launch_blur2(const phl_lattice *lat, int pair, const float *vin, float *vout, int vd, hipStream_t st, bool restricted = false);
 int phl_launch_rows(bool scatter, float *vert, int vd, const int64_t *idx, int64_t k, float *buf, int64_t buf_rs, hipStream_t st);
 int phl_launch_slice(const phl_lattice *lat, const float *vert, int vd, float *out, int64_t out_rs,
                      const float *sub, int64_t sub_rs, unsigned flags, hipStream_t st);

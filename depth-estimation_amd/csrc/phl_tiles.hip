@@ -1093,9 +1093,11 @@ template <int LPR>
 __global__ __launch_bounds__(256) void k_splat_reduce(const float *__restrict__ partial, const int *__restrict__ vs_ptr,
                                                       const phl_contrib_t *__restrict__ vs,
                                                       const int *__restrict__ slot_pidx, int M, int vd,
-                                                      float *__restrict__ vert, const int *__restrict__ vlist, int long_list)
+                                                      float *__restrict__ vert, const int *__restrict__ vlist, int long_list,
+                                                      const int *__restrict__ pack_pos, float *__restrict__ pack, int64_t pack_rs)
 {
-    // vlist (optional): only these M vertex rows (phl_splat_part)
+    // vlist (optional): only these M vertex rows (phl_splat_part); pack_pos (optional, with vlist): listed row i is also
+    // written to pack[pack_pos[i]] -- the row-band exchange's send buffer filled by the kernel that completes the rows
     constexpr int Gw = 64 / LPR;
     const int lane = threadIdx.x & 63;
     const int sub = lane / LPR, l = lane % LPR;
@@ -1106,7 +1108,14 @@ __global__ __launch_bounds__(256) void k_splat_reduce(const float *__restrict__ 
         if (v0 + sub >= M) continue;
         const int64_t v = vlist ? vlist[v0 + sub] : v0 + sub;
         const int beg = vs_ptr[v], end = vs_ptr[v + 1];
-        if (end - beg == 1 || end - beg > long_list) continue;
+        const int pp = pack_pos ? pack_pos[v0 + sub] : -1;
+        if (end - beg > long_list) continue;
+        if (end - beg == 1) {
+            // the chunk kernel wrote the row itself (launches before this one): only the copy into the send buffer is left
+            if (pp >= 0)
+                for (int ch = l * 4; ch < vd; ch += LPR * 4) st4(pack + (int64_t)pp * pack_rs + ch, ld4(vert + v * vd + ch));
+            continue;
+        }
         for (int ch = l * 4; ch < vd; ch += LPR * 4) {
             float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
             int e = beg;
@@ -1119,6 +1128,7 @@ __global__ __launch_bounds__(256) void k_splat_reduce(const float *__restrict__ 
             }
             for (; e < end; e++) acc = add4(acc, ld4(partial + (int64_t)__float_as_int(vs[e].w) * vd + ch));
             st4(vert + v * vd + ch, acc);
+            if (pp >= 0) st4(pack + (int64_t)pp * pack_rs + ch, acc);
         }
     }
 }
@@ -1132,7 +1142,8 @@ template <int LPR>
 __global__ __launch_bounds__(256) void k_splat_reduce_long(const float *__restrict__ partial, const int *__restrict__ vs_ptr,
                                                            const phl_contrib_t *__restrict__ vs,
                                                            const int *__restrict__ slot_pidx, int vd,
-                                                           float *__restrict__ vert, const int *__restrict__ list, int long_list)
+                                                           float *__restrict__ vert, const int *__restrict__ list, int long_list,
+                                                           const int *__restrict__ pack_pos, float *__restrict__ pack, int64_t pack_rs)
 {
     constexpr int NG = 256 / LPR;
     __shared__ float4 red[256];
@@ -1160,6 +1171,7 @@ __global__ __launch_bounds__(256) void k_splat_reduce_long(const float *__restri
             float4 t = red[l];
             for (int k = 1; k < NG; k++) t = add4(t, red[k * LPR + l]);
             st4(vert + v * vd + ch, t);
+            if (pack_pos && pack_pos[blockIdx.x] >= 0) st4(pack + (int64_t)pack_pos[blockIdx.x] * pack_rs + ch, t);
         }
         __syncthreads();
     }
@@ -2272,8 +2284,9 @@ int phl_tiles_chunks_touching(phl_lattice *lat, const int64_t *rows_dev, int64_t
 
 int phl_launch_splat_tiled(phl_lattice *lat, const float *src, int64_t src_rs, int vd, float *vert, float *partial,
                            hipStream_t st, bool subset, const int *chunk_list, int nlist, const int *vlist, int64_t nvl,
-                           const phl_splat_wide *wide)
+                           const phl_splat_wide *wide, const int *pack_pos, float *pack, int64_t pack_rs)
 {
+    if (pack_pos && (!subset || wide)) { phl_set_error("tiled splat: row packing needs a row list and a plain splat"); return PHL_ERR_INVALID; }
     // wide: vertex / partial rows of wide->nsets * vd floats, block k+1 = splat of src (x) fref[:, k] (k_splat_tiled)
     const int64_t out_rs = (int64_t)vd * (wide ? wide->nsets : 1);
     // subset: run only the listed chunks, then complete only the listed vertex rows (either list may be empty)
@@ -2351,15 +2364,19 @@ int phl_launch_splat_tiled(phl_lattice *lat, const float *src, int64_t src_rs, i
     // long slot lists: the lattice's own list of such vertices, or (subset) the caller's rows, short ones exiting
     // (a subset call walks its own rows only if the lattice has long vertices at all: one workgroup per listed row is
     //  tens of thousands of empty workgroups on the row-band path otherwise)
+    // (with a send buffer to fill, the long kernel walks the caller's rows even when ... see above: n_long == 0 means no
+    //  listed row can be long, so nothing is lost by skipping it)
     const int *llist = subset ? vlist : lat->vlong;
     const int64_t nl = lat->n_long == 0 ? 0 : (subset ? nvl : lat->n_long);
     const int long_list = llist ? LONG_LIST : 0x7FFFFFFF;
 #define PHL_RED(LPR_)                                                                                                  \
     k_splat_reduce<LPR_><<<dim3((unsigned)blocks), dim3(256), 0, st>>>(partial, lat->vs_ptr, lat->vs, lat->slot_pidx, \
-                                                                       M, (int)out_rs, vert, vlist, long_list);      \
+                                                                       M, (int)out_rs, vert, vlist, long_list,       \
+                                                                       pack_pos, pack, pack_rs);                     \
     if (llist && nl > 0)                                                                                               \
         k_splat_reduce_long<LPR_><<<dim3((unsigned)nl), dim3(256), 0, st>>>(partial, lat->vs_ptr, lat->vs,            \
-                                                                            lat->slot_pidx, (int)out_rs, vert, llist, long_list)
+                                                                            lat->slot_pidx, (int)out_rs, vert, llist, long_list, \
+                                                                            subset ? pack_pos : nullptr, pack, pack_rs)
     switch (lpr) {
         case 64: PHL_RED(64); break;
         case 16: PHL_RED(16); break;

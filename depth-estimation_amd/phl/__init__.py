@@ -84,6 +84,9 @@ def load_library():
             getattr(lib, name).argtypes = [vp]
         lib.phl_chunks_touching.argtypes = [vp, vp, i64, vp, vp]
         lib.phl_splat_part.argtypes = [vp, vp, i32, i64, vp, vp, vp, i64, vp, i64, vp]
+        if hasattr(lib, "phl_splat_part_pack"):         # (an older build loaded through PHL_LIB lacks these)
+            lib.phl_splat_part_pack.argtypes = [vp, vp, i32, i64, vp, vp, vp, i64, vp, i64, vp, vp, i64, vp]
+            lib.phl_set_blur_rows.argtypes = [vp, vp, i32]
         lib.phl_blur_axis.argtypes = [vp, i32, vp, vp, i32, vp]
         lib.phl_blur.argtypes = [vp, vp, vp, i32, C.POINTER(i32), vp]
         lib.phl_gather_rows.argtypes = [vp, i32, vp, i64, vp, i64, vp]
@@ -278,18 +281,40 @@ class Lattice:
     def partial_rows(self):
         return int(load_library().phl_partial_rows(self._h))
 
-    def splat_part(self, src, out, partial, chunks, rows):
+    def splat_part(self, src, out, partial, chunks, rows, pack_pos=None, pack=None):
         """Run the chunk splat for the listed chunks (int32 device tensor) and complete the listed vertex rows
-        (int32 device tensor) of ``out`` [M, vd]; ``partial`` [partial_rows, vd] is shared by the parts of one splat."""
+        (int32 device tensor) of ``out`` [M, vd]; ``partial`` [partial_rows, vd] is shared by the parts of one splat.
+        pack_pos (int32 device tensor, one per listed row) / pack [*, vd]: listed row i is also written to
+        pack[pack_pos[i]] by the kernel that completes it (the row-band exchange's send buffer)."""
         vd = int(src.shape[1])
         assert src.stride(1) == 1 and out.is_contiguous() and out.shape == (self.M, vd)
         assert chunks.dtype == torch.int32 and rows.dtype == torch.int32 and chunks.is_contiguous() and rows.is_contiguous()
         assert partial.is_contiguous() and partial.shape[0] >= self.partial_rows and partial.shape[1] == vd
+        lib = load_library()
         with torch.cuda.device(self.device):
-            _check(load_library().phl_splat_part(self._h, C.c_void_p(src.data_ptr()), vd, src.stride(0), C.c_void_p(out.data_ptr()),
-                                                 C.c_void_p(partial.data_ptr()), C.c_void_p(chunks.data_ptr()), int(chunks.numel()),
-                                                 C.c_void_p(rows.data_ptr()), int(rows.numel()), _stream(self.device)))
+            if pack_pos is None:
+                _check(lib.phl_splat_part(self._h, C.c_void_p(src.data_ptr()), vd, src.stride(0), C.c_void_p(out.data_ptr()),
+                                          C.c_void_p(partial.data_ptr()), C.c_void_p(chunks.data_ptr()), int(chunks.numel()),
+                                          C.c_void_p(rows.data_ptr()), int(rows.numel()), _stream(self.device)))
+            else:
+                assert pack_pos.dtype == torch.int32 and pack_pos.is_contiguous() and pack_pos.numel() == rows.numel()
+                assert pack.stride(1) == 1 and pack.shape[1] == vd and pack.dtype == torch.float32
+                _check(lib.phl_splat_part_pack(self._h, C.c_void_p(src.data_ptr()), vd, src.stride(0), C.c_void_p(out.data_ptr()),
+                                               C.c_void_p(partial.data_ptr()), C.c_void_p(chunks.data_ptr()), int(chunks.numel()),
+                                               C.c_void_p(rows.data_ptr()), int(rows.numel()), C.c_void_p(pack_pos.data_ptr()),
+                                               C.c_void_p(pack.data_ptr()), pack.stride(0), _stream(self.device)))
         return out
+
+    def set_blur_rows(self, ranges):
+        """Row-band lattices: per blur axis the rows whose output of that axis is read later, as three ascending
+        {begin, end} row ranges (numpy / list [d+1][3][2]); None: all rows.  See phl_set_blur_rows in include/phl.h."""
+        lib = load_library()
+        if ranges is None:
+            _check(lib.phl_set_blur_rows(self._h, None, 0))
+            return
+        r = np.ascontiguousarray(ranges, np.int64)
+        assert r.shape == (self.d + 1, 3, 2), r.shape
+        _check(lib.phl_set_blur_rows(self._h, r.ctypes.data_as(C.c_void_p), self.d + 1))
 
     def blur_axis(self, axis, vin, vout=None):
         vd = int(vin.shape[1])

@@ -11,7 +11,10 @@ Decomposition (one process per GPU, rank r owns image rows [row0, row1)):
           vertex near a cut gets contributions from two bands, and blur reaches vertices that
           only the neighbouring band creates.  Each rank therefore sends the KEYS of the
           vertices the rank across a cut can need (selected by lattice coordinate, below) to that rank,
-          which files them as ghost vertices (phl_add_vertices) and remembers the index map.
+          which files them as ghost vertices (phl_add_vertices) and answers with the ORDER it wants
+          their rows in: first the vertices it has itself (their rows are added to its own sums),
+          then the ghosts in the order of its vertex buffer -- nearest to the cut first -- so that
+          a ghost row is received straight into its place.
   filter  splat own pixels -> exchange the partial sums of those boundary vertices with the
           <= 2 neighbouring ranks (point-to-point, RCCL over xGMI) -> add -> blur -> slice own
           pixels.  One exchange per filter call; message = (#boundary vertices) x L floats.
@@ -34,6 +37,11 @@ be separated by more than 2a_k + b_k (checked at build; S = ceil((2a_k+b_k)/g)+1
 same bound in image rows for a feature growing by g per row).  Results equal the
 single-lattice filter up to fp32 summation order (own partial + neighbour partial instead of
 one pixel-ordered sum): ~1e-7 relative, asserted at 1e-4 in tests.
+
+Ghost rows cost blur work, so each blur axis computes only the rows something later reads
+(RowBand._plan_blur_rows: the sets are derived from the neighbour tables themselves, going back
+from "slice reads the band's own vertices" through the axes; with the ghosts ordered by distance
+from the cut every set is the own rows plus a PREFIX of each neighbour's ghosts).
 
 The class is engine-agnostic (anything with the phl.Lattice stage surface) and phase-structured
 (outbox / inbox), so the same code runs under torch.distributed (NCCL on GPUs, gloo on CPU in the
@@ -108,8 +116,8 @@ def band_rows(H, world):
 
 
 class RowBand:
-    """One rank's share.  Phases: build_outbox -> build_inbox, then per call splat_outbox ->
-    finish.  Tensors live on the engine's device."""
+    """One rank's share.  Build phases: build_outbox -> build_inbox -> order_outbox -> order_inbox; then per call
+    splat_outbox -> finish.  Tensors live on the engine's device."""
 
     def __init__(self, feat, rank, world, engine_factory, device):
         H, W, d = feat.shape
@@ -120,18 +128,20 @@ class RowBand:
         self.n_local = self.own_rows * W
         k, sign, g, a_k, b_k = band_axis(feat)
         self.S = int(math.ceil((2 * a_k + b_k) / g - 1e-9)) + 1
-        self.axis, self.reach = k, a_k + b_k
+        self.axis, self.reach, self._sign = k, a_k + b_k, sign
         y = sign * feat[..., k]
         span = [(float(y[r0:r1].min()), float(y[r0:r1].max())) for r0, r1 in zip(cuts[:-1], cuts[1:])]
         for r in range(world - 2):
             if span[r + 2][0] - span[r][1] <= 2 * a_k + b_k:
                 raise ValueError(f"row bands ({min(r1 - r0 for r0, r1 in zip(cuts[:-1], cuts[1:]))} rows) are shorter than the "
                                  f"lattice support ({self.S} rows): use fewer ranks")
+        self._span = span[rank]
         self.device = device
         own = np.ascontiguousarray(feat[self.row0:self.row1].reshape(-1, d), dtype=np.float32)
         t0 = time.time()
         self.eng = engine_factory(torch.from_numpy(own).to(device))
-        self.sides = {}   # peer -> dict(send_idx, map_idx)
+        self.M_own = int(self.eng.M)          # before any ghost is filed
+        self.sides = {}   # peer -> dict(send_idx, ...)
         keys = self.eng.keys()
         ypos = sign * vertex_coordinate(keys, d, k)
         reach = (a_k + b_k) * _REACH_SCALE + 1e-3 * (1.0 + max(abs(span[0][0]), abs(span[-1][1])))   # + fp32 elevate slack
@@ -144,6 +154,8 @@ class RowBand:
                 self.sides[peer] = dict(send_idx=torch.from_numpy(np.asarray(rows).astype(np.int64)).to(device))
                 self._send_keys[peer] = torch.from_numpy(np.ascontiguousarray(keys[v]))
         self._t_build = time.time() - t0
+        self.peers = sorted(self.sides)
+        self._ready = False
 
     # -- build phases ---------------------------------------------------------------------------
     def build_outbox(self):
@@ -151,24 +163,93 @@ class RowBand:
         return dict(self._send_keys)
 
     def build_inbox(self, inbox):
+        """File the neighbours' vertices: ghosts of one neighbour get consecutive rows, nearest to my band first."""
+        t0 = time.time()
+        lo, hi = self._span
+        self._order_out = {}
+        for peer in sorted(inbox):
+            keys = inbox[peer].cpu().numpy().reshape(-1, self.d)
+            y = self._sign * vertex_coordinate(keys, self.d, self.axis)
+            dist = np.maximum(0.0, np.maximum(lo - y, y - hi))
+            order = np.argsort(dist, kind="stable")
+            before = int(self.eng.M)
+            ids = np.asarray(self.eng.add_vertices(keys[order])).astype(np.int64)
+            ghost = ids >= before
+            # rows of new vertices follow the order they were handed in: ghost rows of this peer = [before, before + ng)
+            assert np.array_equal(ids[ghost], before + np.arange(int(ghost.sum()))), "engine must append new vertices in call order"
+            perm = np.concatenate([order[~ghost], order[ghost]]).astype(np.int32)
+            ns = int((~ghost).sum())
+            s = self.sides[peer]
+            s["n_shared"], s["n_ghost"], s["ghost_row0"] = ns, int(ghost.sum()), before
+            s["shared_map"] = torch.from_numpy(ids[~ghost]).to(self.device)
+            s["map_idx"] = torch.from_numpy(np.concatenate([ids[~ghost], ids[ghost]])).to(self.device)
+            self._order_out[peer] = torch.from_numpy(np.concatenate([[ns], perm]).astype(np.int32))
+        self._t_build += time.time() - t0
+        self._send_keys = None
+
+    def order_outbox(self):
+        """{peer: int32 [1 + K]}: how many of the K rows the peer sends me are vertices I have myself, then the order I
+        want all K in (indices into the key list it sent: shared first, then ghosts in the order of my rows)."""
+        return dict(self._order_out)
+
+    def order_inbox(self, inbox):
         t0 = time.time()
         for peer in sorted(inbox):
-            ids = self.eng.add_vertices(inbox[peer].cpu().numpy())
-            self.sides[peer]["map_idx"] = torch.from_numpy(ids.astype(np.int64)).to(self.device)
-        # packed forms for the engine's fused row kernels: one gather for all peers' send rows, one
-        # scatter-add for all received rows (only if no vertex receives from both sides: no atomics)
-        self.peers = sorted(self.sides)
+            msg = inbox[peer].cpu().numpy().astype(np.int64)
+            s = self.sides[peer]
+            s["send_shared"] = int(msg[0])
+            s["send_idx"] = s["send_idx"][torch.from_numpy(msg[1:]).to(self.device)]
+        # packed forms for the engine's fused row kernels: one gather for all peers' send rows, one scatter-add for
+        # all received rows of shared vertices (only if no vertex receives from both sides: no atomics)
         if self.peers:
             self._send_all = torch.cat([self.sides[p]["send_idx"] for p in self.peers])
             self._map_all = torch.cat([self.sides[p]["map_idx"] for p in self.peers])
+            self._shared_all = torch.cat([self.sides[p]["shared_map"] for p in self.peers])
             self._map_disjoint = int(torch.unique(self._map_all).numel()) == int(self._map_all.numel())
-            self._send_rng, self._recv_rng, so, ro = {}, {}, 0, 0
+            self._send_unique = int(torch.unique(self._send_all).numel()) == int(self._send_all.numel())
+            self._send_rng, self._recv_rng, self._shared_rng, so, ro, sh = {}, {}, {}, 0, 0, 0
             for p in self.peers:
-                ks, kr = int(self.sides[p]["send_idx"].numel()), int(self.sides[p]["map_idx"].numel())
+                s = self.sides[p]
+                ks, kr = int(s["send_idx"].numel()), int(s["map_idx"].numel())
                 self._send_rng[p], self._recv_rng[p] = (so, so + ks), (ro, ro + kr)
-                so, ro = so + ks, ro + kr
+                self._shared_rng[p] = (sh, sh + s["n_shared"])
+                so, ro, sh = so + ks, ro + kr, sh + s["n_shared"]
+        self._plan_blur_rows()
         self._t_build += time.time() - t0
-        self._send_keys = None
+        self._ready = True
+
+    def _plan_blur_rows(self):
+        """Which rows each blur axis has to produce.  Slice reads the band's own vertices (rows [0, M_own)); axis j's
+        output at row v is read by axis j+1 at v and at v's two neighbours along j+1.  Going back from the last axis gives,
+        per axis, the exact set of rows whose output is ever used; ghosts are ordered by distance from the band, so each
+        set is the own rows plus a prefix of every neighbour's ghost rows (the prefix up to the farthest needed one)."""
+        eng = self.eng
+        self.blur_rows = None
+        if not (hasattr(eng, "set_blur_rows") and self.peers and int(eng.M) > self.M_own):
+            return
+        if os.environ.get("PHL_ROWTILE_BLUR_ROWS", "1") == "0":
+            return
+        M, d = int(eng.M), self.d
+        nb = np.asarray(eng.neighbors()).astype(np.int64)            # [d+1, M, 2], first-touch ids, -1 absent
+        rows = eng.vertex_rows().cpu().numpy().astype(np.int64)      # first-touch id -> row
+        nbr = np.empty_like(nb)
+        nbr[:, rows, :] = np.where(nb >= 0, rows[np.clip(nb, 0, None)], -1)     # row -> neighbour rows
+        need = np.zeros(M, bool)
+        need[:self.M_own] = True
+        ranges = np.zeros((d + 1, 3, 2), np.int64)
+        for axis in range(d, -1, -1):
+            ranges[axis, 0] = (0, self.M_own)
+            for k, p in enumerate(self.peers):
+                s = self.sides[p]
+                g0, ng = s["ghost_row0"], s["n_ghost"]
+                hit = np.nonzero(need[g0:g0 + ng])[0]
+                ranges[axis, 1 + k] = (g0, g0 + (int(hit[-1]) + 1 if hit.size else 0))
+            if len(self.peers) == 1:
+                ranges[axis, 2] = (ranges[axis, 1, 1], ranges[axis, 1, 1])
+            nn = nbr[axis, need].ravel()
+            need[nn[nn >= 0]] = True
+        eng.set_blur_rows(ranges)
+        self.blur_rows = ranges
 
     # -- filter phases --------------------------------------------------------------------------
     def splat_outbox(self, src, vert=None, sendbuf=None):
@@ -192,18 +273,28 @@ class RowBand:
         """Row range of `peer`'s rows inside a packed receive buffer (peers in ascending order)."""
         return self._recv_rng[peer]
 
-    def finish(self, vert, inbox, out=None, packed=None, scratch=None):
-        """inbox: {peer: rows}; packed: the same rows as ONE [sum of rows, C] tensor in ascending peer order
-        (lets the engine add them in a single launch); scratch: optional second [M, C] buffer for the blur."""
+    def place(self, vert, inbox):
+        """Received rows -> the vertex buffer: rows of vertices this band has itself are added, ghost rows (no local
+        contribution: the splat left zeros there) are copied into their consecutive rows.  Peers in ascending order."""
         fused = hasattr(self.eng, "scatter_add_rows") and vert.shape[1] % 4 == 0
-        if fused and packed is not None and self.sides and self._map_disjoint:
-            self.eng.scatter_add_rows(vert, self._map_all, packed)
-        else:
-            for peer in sorted(inbox):      # distinct rows per peer, peers in a fixed order: deterministic
+        for peer in sorted(inbox):
+            s, rows = self.sides[peer], inbox[peer]
+            ns, ng, g0 = s["n_shared"], s["n_ghost"], s["ghost_row0"]
+            if ng:
+                vert[g0:g0 + ng].copy_(rows[ns:ns + ng])
+            if ns:
                 if fused:
-                    self.eng.scatter_add_rows(vert, self.sides[peer]["map_idx"], inbox[peer])
+                    self.eng.scatter_add_rows(vert, s["shared_map"], rows[:ns])
                 else:
-                    vert.index_add_(0, self.sides[peer]["map_idx"], inbox[peer])
+                    vert.index_add_(0, s["shared_map"], rows[:ns].to(vert.device))
+        return vert
+
+    def finish(self, vert, inbox, out=None, scratch=None):
+        """inbox: {peer: rows in the order asked for}; scratch: optional second [M, C] buffer for the blur."""
+        self.place(vert, inbox)
+        return self.blur_slice(vert, out=out, scratch=scratch)
+
+    def blur_slice(self, vert, out=None, scratch=None):
         vert = self.eng.blur(vert) if scratch is None else self.eng.blur(vert, scratch)
         return self.eng.slice(vert) if out is None else self.eng.slice(vert, out=out)
 
@@ -218,9 +309,15 @@ class RowBand:
 class RowTileFilter:
     """torch.distributed driver: one RowBand per rank, exchanges by batched isend/irecv.
 
-    The filter is channel-wise, so a call is pipelined over `groups` channel groups: the boundary
-    rows of group g travel over xGMI (RCCL runs on its own stream) while group g+1 is being
-    splatted, and group g is blurred/sliced while group g+1's rows are still in flight."""
+    Schedules, best first:
+      * edge chunks first (one channel group; engines with the chunk splat): the pixel chunks that feed this rank's
+        boundary vertices are splatted first, the interior chunks right behind them; a SIDE stream completes the
+        boundary rows into the send buffer (one kernel: sums + pack) as soon as the edge chunks are done and hands them
+        to the exchange, which then runs under the interior chunks and the completion of all other rows.  Ghost rows
+        are received straight into the vertex buffer, shared rows are added, blur (restricted rows) and slice follow.
+        Payloads stay in HBM under RCCL; under gloo they are staged through pinned host buffers -- same schedule.
+      * channel groups pipelined (device payloads): the boundary rows of group g travel while group g+1 is splatted.
+      * plain: any engine, any backend."""
 
     def __init__(self, feat, L, rank, world, device, dist, engine_factory=None, groups=None):
         if engine_factory is None:
@@ -230,76 +327,107 @@ class RowTileFilter:
         # P2P payloads must live where the backend can reach them
         self.comm_device = device if dist.get_backend() == "nccl" else torch.device("cpu")
         t0 = time.time()
-        self.band = RowBand(feat, rank, world, engine_factory, device)
-        out = self.band.build_outbox()
+        self.band = band = RowBand(feat, rank, world, engine_factory, device)
+        out = band.build_outbox()
         counts = self._exchange({p: torch.tensor([k.shape[0]], dtype=torch.int64) for p, k in out.items()},
                                 {p: ((1,), torch.int64) for p in out})
-        inbox = self._exchange(out, {p: ((int(c.item()), self.band.d), torch.int16) for p, c in counts.items()})
-        self.band.build_inbox(inbox)
+        inbox = self._exchange(out, {p: ((int(c.item()), band.d), torch.int16) for p, c in counts.items()})
+        band.build_inbox(inbox)
+        band.order_inbox(self._exchange(band.order_outbox(), {p: ((1 + int(k.shape[0]),), torch.int32) for p, k in out.items()}))
         if device.type == "cuda":
             torch.cuda.synchronize(device)
         self.build_ms = (time.time() - t0) * 1e3
-        self.row0, self.own_rows, self.n_local = self.band.row0, self.band.own_rows, self.band.n_local
+        self.row0, self.own_rows, self.n_local = band.row0, band.own_rows, band.n_local
+        self._direct = self.comm_device == device                        # payloads stay on the engine's device
+        self._rows_engine = hasattr(band.eng, "gather_rows") and device.type == "cuda"
+        want_edge = (os.environ.get("PHL_ROWTILE_EDGE_FIRST", "1") != "0" and self._rows_engine and hasattr(band.eng, "splat_part")
+                     and L % 4 == 0 and bool(band.sides) and band._map_disjoint)
         if groups is None:
             groups = int(os.environ.get("PHL_ROWTILE_GROUPS", "0"))
             if not groups:
-                # device-resident payloads (RCCL): one group with the edge-first schedule (_make_edge_plan); payloads
-                # staged through host memory (gloo): two channel groups pipelined
-                edge_first = (self.comm_device == device and os.environ.get("PHL_ROWTILE_EDGE_FIRST", "1") != "0"
-                              and hasattr(engine_factory, "splat_part"))
-                groups = 1 if (edge_first or not (world > 1 and L % 8 == 0 and L >= 64)) else 2
+                groups = 1 if (want_edge or not (world > 1 and L % 8 == 0 and L >= 64)) else 2
         self.groups = [(g * L // groups, (g + 1) * L // groups) for g in range(groups)]
-        total = sum(self.band.recv_rows(p) for p in self.band.sides)
-        self._rpack = [torch.empty((total, c1 - c0), dtype=torch.float32, device=self.comm_device) for c0, c1 in self.groups]
-        self._rbuf = [{p: pack[slice(*self.band.recv_range(p))] for p in self.band.sides} for pack in self._rpack]
-        # Steady state allocates nothing and rebuilds nothing: vertex buffers, blur scratch, send buffers and the
-        # point-to-point op lists of every channel group exist once (the host side of a 0.35 ms band step must
-        # not be on the critical path).
-        self._fused = hasattr(self.band.eng, "gather_rows") and self.comm_device == self.band.device
-        self._vert = self._scratch = self._sbuf = self._ops = None
+        self._fused = self._rows_engine and self._direct and (not band.sides or band._map_disjoint) and all((c1 - c0) % 4 == 0 for c0, c1 in self.groups)
         self._plan, self._edge_first = None, False
         self._stub_exchange = False      # timing probes only: run the step without its point-to-point exchange
-        if self._fused:
-            M = self.band.M
-            self._vert = [torch.empty((M, c1 - c0), dtype=torch.float32, device=device) for c0, c1 in self.groups]
-            self._scratch = [torch.empty((M, c1 - c0), dtype=torch.float32, device=device) for c0, c1 in self.groups[:1]]
-            self._scratch += [self._scratch[0] if (c1 - c0) == self._scratch[0].shape[1] else
-                              torch.empty((M, c1 - c0), dtype=torch.float32, device=device) for c0, c1 in self.groups[1:]]
-            self._sbuf = [torch.empty((self.band.send_rows(), c1 - c0), dtype=torch.float32, device=device) for c0, c1 in self.groups]
-            self._ops = []
-            for gi in range(len(self.groups)):
-                ops = []
-                for peer in sorted(self.band.sides):
-                    a, b = self.band._send_rng[peer]
-                    ops.append(dist.P2POp(dist.isend, self._sbuf[gi][a:b], peer))
-                    ops.append(dist.P2POp(dist.irecv, self._rbuf[gi][peer], peer))
-                self._ops.append(ops)
-        if hasattr(self.band.eng, "reserve"):
-            self.band.eng.reserve(max(c1 - c0 for c0, c1 in self.groups))
-        self._make_edge_plan()
+        self._vert = self._scratch = self._sbuf = self._ops = self._rshared = None
+        if hasattr(band.eng, "reserve"):
+            band.eng.reserve(max(c1 - c0 for c0, c1 in self.groups))
+        if want_edge and groups == 1:
+            self._make_edge_plan()
+        if self._fused or self._edge_first:
+            self._make_buffers()
+        if not (self._fused or self._edge_first):
+            total = sum(band.recv_rows(p) for p in band.sides)
+            self._rpack = [torch.empty((total, c1 - c0), dtype=torch.float32, device=self.comm_device) for c0, c1 in self.groups]
+            self._rbuf = [{p: pack[slice(*band.recv_range(p))] for p in band.sides} for pack in self._rpack]
+
+    # ---- steady-state buffers and op lists (nothing is allocated or rebuilt per call) -------------------------
+    def _make_buffers(self):
+        band, dev, dist = self.band, self.device, self.dist
+        M = band.M
+        pin = dict(pin_memory=True) if (not self._direct and dev.type == "cuda") else {}
+        self._vert = [torch.empty((M, c1 - c0), dtype=torch.float32, device=dev) for c0, c1 in self.groups]
+        self._scratch = [torch.empty((M, c1 - c0), dtype=torch.float32, device=dev) for c0, c1 in self.groups[:1]]
+        self._scratch += [self._scratch[0] if (c1 - c0) == self._scratch[0].shape[1] else
+                          torch.empty((M, c1 - c0), dtype=torch.float32, device=dev) for c0, c1 in self.groups[1:]]
+        self._sbuf = [torch.empty((band.send_rows(), c1 - c0), dtype=torch.float32, device=dev) for c0, c1 in self.groups]
+        n_shared = sum(band.sides[p]["n_shared"] for p in band.peers)
+        self._rshared = [torch.empty((n_shared, c1 - c0), dtype=torch.float32, device=dev) for c0, c1 in self.groups]
+        if not self._direct:             # host staging (gloo): pinned mirrors of the send buffer and of both receive parts
+            n_ghost = sum(band.sides[p]["n_ghost"] for p in band.peers)
+            self._sbuf_h = [torch.empty(tuple(b.shape), dtype=torch.float32, **pin) for b in self._sbuf]
+            self._rshared_h = [torch.empty(tuple(b.shape), dtype=torch.float32, **pin) for b in self._rshared]
+            self._rghost_h = [torch.empty((n_ghost, c1 - c0), dtype=torch.float32, **pin) for c0, c1 in self.groups]
+        self._ops = []
+        for gi in range(len(self.groups)):
+            ops, go = [], 0
+            for p in band.peers:
+                s = band.sides[p]
+                a, b = band._send_rng[p]
+                sa, sb = band._shared_rng[p]
+                ns_out = s["send_shared"]
+                snd = self._sbuf[gi] if self._direct else self._sbuf_h[gi]
+                rsh = self._rshared[gi] if self._direct else self._rshared_h[gi]
+                rgh = (self._vert[gi][s["ghost_row0"]:s["ghost_row0"] + s["n_ghost"]] if self._direct
+                       else self._rghost_h[gi][go:go + s["n_ghost"]])
+                go += s["n_ghost"]
+                # two messages per direction: the rows the receiver adds to its own, the rows it takes as they are
+                for t, op in ((snd[a:a + ns_out], dist.isend), (snd[a + ns_out:b], dist.isend), (rsh[sa:sb], dist.irecv), (rgh, dist.irecv)):
+                    if t.shape[0]:
+                        ops.append(dist.P2POp(op, t, p))
+            self._ops.append(ops)
+        if self.device.type == "cuda":
+            self._side = torch.cuda.Stream(device=dev)
+            self._ev_edge, self._ev_packed = torch.cuda.Event(), torch.cuda.Event()
 
     def _make_edge_plan(self):
         """Edge-first schedule (one channel group): the chunks that feed this rank's boundary vertices are
         splatted first and those rows completed, so that they travel while the interior chunks are splatted --
-        the exchange hides behind ~3/4 of the splat instead of behind a second channel group (splitting the
+        the exchange hides behind ~2/3 of the splat instead of behind a second channel group (splitting the
         channels costs 10 % of the step in small-launch overhead)."""
         eng, band = self.band.eng, self.band
-        want = os.environ.get("PHL_ROWTILE_EDGE_FIRST", "1") != "0"
-        if not (want and self._fused and len(self.groups) == 1 and band.sides and hasattr(eng, "splat_part")
-                and self.L % 4 == 0 and eng.tile_stats(self.L)["staged_splat"]):
+        if not eng.tile_stats(self.L)["staged_splat"]:
             return
         send = band._send_all
         mask = eng.chunks_touching(send)
         if mask.all() or not mask.any():
             return
         dev = band.device
-        is_send = torch.zeros(band.M, dtype=torch.bool, device=dev)
-        is_send[send] = True
+        order = torch.argsort(send)                       # the rows the edge part completes, ascending ...
+        send_rows = send[order]
+        if band._send_unique:
+            pack_pos = order.to(torch.int32)              # ... and where each goes in the send buffer
+        else:
+            send_rows, pack_pos = torch.unique(send_rows), None        # (a row wanted by both neighbours: packed by a gather)
+        is_other = torch.ones(band.M_own, dtype=torch.bool, device=dev)
+        is_other[send_rows] = False                       # ghost rows belong to neither part: they are received
         self._plan = dict(
             edge=torch.from_numpy(np.nonzero(mask)[0].astype(np.int32)).to(dev),
             interior=torch.from_numpy(np.nonzero(~mask)[0].astype(np.int32)).to(dev),
-            send_rows=torch.nonzero(is_send).flatten().to(torch.int32),
-            other_rows=torch.nonzero(~is_send).flatten().to(torch.int32),
+            send_rows=send_rows.to(torch.int32).contiguous(), pack_pos=pack_pos,
+            other_rows=torch.nonzero(is_other).flatten().to(torch.int32),
+            none=torch.empty(0, dtype=torch.int32, device=dev),
             partial=torch.empty((max(eng.partial_rows, 1), self.L), dtype=torch.float32, device=dev))
         self._edge_first = True
 
@@ -331,6 +459,8 @@ class RowTileFilter:
         dist = self.dist
         if out is None:
             out = torch.empty((self.band.n_local, self.L), dtype=torch.float32, device=self.band.device)
+        if self._edge_first:
+            return self._filter_edge_first(src, out)
         if self._fused:
             return self._filter_fused(src, out)
         pending = []
@@ -350,25 +480,52 @@ class RowTileFilter:
                 req.wait()
             pack = self._rpack[gi] if self._rpack[gi].device == self.band.device else self._rpack[gi].to(self.band.device)
             inbox = {p: pack[slice(*self.band.recv_range(p))] for p in self.band.sides}
-            self.band.finish(vert, inbox, out=out[:, c0:c1], packed=pack)
+            self.band.finish(vert, inbox, out=out[:, c0:c1])
         return out
 
     def _filter_edge_first(self, src, out):
-        dist, band, eng, pl = self.dist, self.band, self.band.eng, self._plan
-        vert, sbuf = self._vert[0], self._sbuf[0]
-        eng.splat_part(src, vert, pl["partial"], pl["edge"], pl["send_rows"])        # boundary rows complete
-        eng.gather_rows(vert, band._send_all, out=sbuf)
-        reqs = dist.batch_isend_irecv(self._ops[0]) if (self._ops[0] and not self._stub_exchange) else []   # ... and on their way
-        eng.splat_part(src, vert, pl["partial"], pl["interior"], pl["other_rows"])   # the rest, under the exchange
+        band, eng, pl, dist = self.band, self.band.eng, self._plan, self.dist
+        vert, sbuf, none = self._vert[0], self._sbuf[0], pl["none"]
+        main, side = torch.cuda.current_stream(self.device), self._side
+        eng.splat_part(src, vert, pl["partial"], pl["edge"], none)            # chunk sums only: edge chunks ...
+        self._ev_edge.record(main)
+        eng.splat_part(src, vert, pl["partial"], pl["interior"], none)        # ... and the interior chunks right behind them
+        reqs = []
+        with torch.cuda.stream(side):
+            side.wait_event(self._ev_edge)
+            # boundary rows complete and packed by one kernel, beside the interior chunks
+            eng.splat_part(src, vert, pl["partial"], none, pl["send_rows"], pack_pos=pl["pack_pos"], pack=sbuf if pl["pack_pos"] is not None else None)
+            if pl["pack_pos"] is None:
+                eng.gather_rows(vert, band._send_all, out=sbuf)
+            if self._direct:
+                if self._ops[0] and not self._stub_exchange:
+                    reqs = dist.batch_isend_irecv(self._ops[0])               # ... and on their way (ordered behind `side`)
+            else:
+                self._sbuf_h[0].copy_(sbuf, non_blocking=True)
+                self._ev_packed.record(side)
+        if not self._direct:
+            self._ev_packed.synchronize()       # the host waits for the boundary rows only; the interior chunks are queued
+            if self._ops[0] and not self._stub_exchange:
+                reqs = dist.batch_isend_irecv(self._ops[0])
+        eng.splat_part(src, vert, pl["partial"], none, pl["other_rows"])      # all other rows of this band, under the exchange
         for req in reqs:
             req.wait()
-        band.finish(vert, self._rbuf[0], out=out, packed=self._rpack[0], scratch=self._scratch[0])
+        main.wait_stream(side)
+        if not self._direct:                    # host-staged payloads: ghost rows to their place, shared rows next to it
+            go = 0
+            for p in band.peers:
+                s = band.sides[p]
+                if s["n_ghost"]:
+                    vert[s["ghost_row0"]:s["ghost_row0"] + s["n_ghost"]].copy_(self._rghost_h[0][go:go + s["n_ghost"]], non_blocking=True)
+                go += s["n_ghost"]
+            self._rshared[0].copy_(self._rshared_h[0], non_blocking=True)
+        if band._shared_all.numel():
+            eng.scatter_add_rows(vert, band._shared_all, self._rshared[0])
+        band.blur_slice(vert, out=out, scratch=self._scratch[0])
         return out
 
     def _filter_fused(self, src, out):
-        """Same schedule on preallocated buffers and persistent op lists (RCCL: payloads stay in HBM)."""
-        if self._edge_first:
-            return self._filter_edge_first(src, out)
+        """Channel groups on preallocated buffers and persistent op lists (device payloads)."""
         dist, band = self.dist, self.band
         reqs = []
         for gi, (c0, c1) in enumerate(self.groups):
@@ -377,7 +534,9 @@ class RowTileFilter:
         for gi, (c0, c1) in enumerate(self.groups):
             for req in reqs[gi]:
                 req.wait()
-            band.finish(self._vert[gi], self._rbuf[gi], out=out[:, c0:c1], packed=self._rpack[gi], scratch=self._scratch[gi])
+            if band.sides and band._shared_all.numel():
+                band.eng.scatter_add_rows(self._vert[gi], band._shared_all, self._rshared[gi])
+            band.blur_slice(self._vert[gi], out=out[:, c0:c1], scratch=self._scratch[gi])
         return out
 
     def exchange_probe(self, src, out, reps=10):
@@ -410,7 +569,7 @@ class RowTileFilter:
 
         def exchange_only():
             for gi in range(len(self.groups)):
-                if self._fused:
+                if self._ops is not None:
                     ops = self._ops[gi]
                 else:
                     ops = []
@@ -437,12 +596,18 @@ class RowTileFilter:
     def describe(self):
         b = self.band
         rows = {str(p): b.recv_rows(p) for p in b.sides}
-        return {"rowtile": {"rows_per_rank": b.own_rows, "strip_rows": b.S, "M_local_plus_ghosts": int(b.M),
+        blur = None
+        if getattr(b, "blur_rows", None) is not None:
+            blur = [int((b.blur_rows[a, :, 1] - b.blur_rows[a, :, 0]).sum()) for a in range(b.d + 1)]
+        return {"rowtile": {"rows_per_rank": b.own_rows, "strip_rows": b.S, "M_local_plus_ghosts": int(b.M), "M_own": int(b.M_own),
                             "boundary_vertices_recv": rows,
+                            "ghost_rows_received_in_place": {str(p): b.sides[p]["n_ghost"] for p in b.sides},
+                            "blur_rows_per_axis": blur,
                             "channel_groups": len(self.groups),
-                            "schedule": ("edge chunks first, exchange under the interior splat" if getattr(self, "_edge_first", False)
-                                         else "channel groups pipelined"),
-                            "edge_chunks": int(self._plan["edge"].numel()) if getattr(self, "_plan", None) else None,
+                            "schedule": (("edge chunks first, exchange under the interior splat"
+                                          + ("" if self._direct else " (payloads staged through pinned host memory)"))
+                                         if self._edge_first else ("channel groups pipelined" if self._fused else "plain")),
+                            "edge_chunks": int(self._plan["edge"].numel()) if self._plan else None,
                             "exchange_bytes_per_step_per_rank": int(sum(rows.values()) * self.L * 4 * 2)}}
 
 
@@ -454,10 +619,11 @@ def simulate(feat, src_full, world, engine_factory, device):
     out = [b.build_outbox() for b in bands]
     for r, b in enumerate(bands):
         b.build_inbox({p: out[p][r] for p in b.sides})
+    order = [b.order_outbox() for b in bands]
+    for r, b in enumerate(bands):
+        b.order_inbox({p: order[p][r] for p in b.sides})
     outs = [b.splat_outbox(src_full[b.row0 * W:b.row1 * W]) for b in bands]
     res = []
     for r, b in enumerate(bands):
-        inbox = {p: outs[p][1][r] for p in b.sides}
-        packed = torch.cat([inbox[p] for p in sorted(inbox)]) if inbox else None
-        res.append(b.finish(outs[r][0], inbox, packed=packed))
+        res.append(b.finish(outs[r][0], {p: outs[p][1][r] for p in b.sides}))
     return torch.cat(res, 0), bands

@@ -210,6 +210,20 @@ int phl_chunks_touching(phl_lattice *lat, const int64_t *rows_dev, int64_t k, in
 int phl_splat_part(phl_lattice *lat, const float *src_dev, int vd, int64_t src_row_stride, float *vert_dev,
                    float *partial_dev, const int32_t *chunks_dev, int64_t nchunks_sel, const int32_t *rows_dev,
                    int64_t nrows, phl_stream stream);
+/* phl_splat_part that also fills the exchange's send buffer: listed row i is written to pack_dev[pack_pos_dev[i]]
+ * (rows of pack_row_stride floats; pack_pos < 0: not packed) by the kernel that completes it, instead of a separate
+ * gather afterwards.  src_dev may be NULL when no chunks are listed.  pack_pos_dev == NULL: plain phl_splat_part. */
+int phl_splat_part_pack(phl_lattice *lat, const float *src_dev, int vd, int64_t src_row_stride, float *vert_dev,
+                        float *partial_dev, const int32_t *chunks_dev, int64_t nchunks_sel, const int32_t *rows_dev,
+                        int64_t nrows, const int32_t *pack_pos_dev, float *pack_dev, int64_t pack_row_stride,
+                        phl_stream stream);
+/* Row-band lattices: per blur axis a, the rows whose OUTPUT of axis a is read by anything later (the next axes' stencils,
+ * finally slice) as three ascending, non-overlapping row ranges ranges[a][k] = {begin, end} (empty ranges allowed).  The
+ * blur of phl_blur / phl_filter then computes only those rows (a pass over the axis pair (2p, 2p+1) computes the rows
+ * named for axis 2p+1); the others keep stale values nobody reads.  A band carries ghost vertices 2-3 lattice steps deep
+ * for the FIRST axes' stencils; later axes need fewer of them and slice none (phl/rowtile.py derives the sets from the
+ * neighbour tables).  ranges == NULL: all rows again.  phl_add_vertices resets it.  No reference counterpart. */
+int phl_set_blur_rows(phl_lattice *lat, const int64_t *ranges /* [d+1][3][2] */, int naxes);
 /* slice(): out[p] = sum_i w_i * vert[v_i] / (1 + 2^-d)                        (:473-483) */
 int phl_slice(phl_lattice *lat, const float *vert_dev, int vd, float *out_dev, int64_t out_row_stride,
               const float *sub_dev /* NULL or src to subtract */, int64_t sub_row_stride, unsigned flags,

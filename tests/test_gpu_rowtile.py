@@ -71,7 +71,7 @@ def test_add_vertices_semantics():
     assert v.shape[0] == M0 + 3 and float(v[M0:].abs().max()) == 0.0               # ghosts receive nothing locally
 
 
-def _gpu_worker(rank, world, port, H, W, L, q):
+def _gpu_worker(rank, world, port, H, W, L, q, groups):
     import os
     import sys
 
@@ -85,20 +85,27 @@ def _gpu_worker(rank, world, port, H, W, L, q):
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
     dev = torch.device("cuda", 0)
     feat, src = make_image(H, W, L, sigma_xy=3.0)
-    job = rowtile.RowTileFilter(feat, L, rank, world, dev, dist, groups=2)   # HIP engine; payloads staged through gloo
+    job = rowtile.RowTileFilter(feat, L, rank, world, dev, dist, groups=groups)   # HIP engine; payloads staged through gloo
     mine = torch.from_numpy(src[job.row0 * W:(job.row0 + job.own_rows) * W]).to(dev)
     out = job.filter(mine)
     out2 = job.filter(mine)
     assert torch.equal(out, out2)
-    q.put((rank, out.cpu().numpy(), job.describe()))
+    probe = job.exchange_probe(mine, torch.empty_like(out), reps=2)
+    assert torch.equal(job.filter(mine), out), "the stubbed-exchange timing pass must leave no trace"
+    info = job.describe()
+    info["probe"] = probe
+    q.put((rank, out.cpu().numpy(), info))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_two_processes_share_the_gpu_over_gloo():
+@pytest.mark.parametrize("groups", [None, 2])
+def test_two_processes_share_the_gpu_over_gloo(groups):
     """The torch.distributed driver (RowTileFilter) with the HIP engine in two real processes.
     One GPU box cannot host two RCCL ranks, so the payloads travel through gloo here; the rank
-    logic, ghost import and index maps are the ones the RCCL run uses."""
+    logic, ghost import and index maps are the ones the RCCL run uses.  groups = None: the DEFAULT schedule -- edge
+    chunks first, boundary rows completed and packed on a side stream, exchange under the interior chunks, ghost rows
+    received in place -- with its payloads staged through pinned host memory; groups = 2: the plain path."""
     import socket
 
     import torch.multiprocessing as mp
@@ -113,7 +120,7 @@ def test_two_processes_share_the_gpu_over_gloo():
     s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_gpu_worker, args=(r, world, port, H, W, L, q)) for r in range(world)]
+    procs = [ctx.Process(target=_gpu_worker, args=(r, world, port, H, W, L, q, groups)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=300) for _ in range(world)], key=lambda t: t[0])
@@ -124,6 +131,12 @@ def test_two_processes_share_the_gpu_over_gloo():
     want = phl.Lattice(torch.from_numpy(feat.reshape(-1, 5)).cuda()).filter(torch.from_numpy(src).cuda()).cpu().numpy()
     got = np.concatenate([r[1] for r in res], 0)
     assert rel(got, want) <= RTOL
+    sched = res[0][2]["rowtile"]["schedule"]
+    if groups is None:
+        assert sched.startswith("edge chunks first") and "pinned host" in sched, sched
+        assert res[0][2]["rowtile"]["blur_rows_per_axis"] is not None
+    else:
+        assert sched == "plain", sched
 
 
 class _LoopbackDist:
@@ -345,3 +358,95 @@ def test_bench_two_ranks_validates_itself(workload):
             assert k in chk
     else:
         assert line["scaling"] == "weak" and chk["repeatable"]
+
+
+def _run_ranks(feat, src, L, world, dev, **kw):
+    """All ranks as threads over _LoopbackDist; returns ({rank: output}, {rank: job})."""
+    import threading
+
+    from phl import rowtile
+
+    W = feat.shape[1]
+    fake = _LoopbackDist(world)
+    outs, jobs, errs = {}, {}, []
+
+    def run(rank):
+        try:
+            fake.local.rank = rank
+            job = rowtile.RowTileFilter(feat, L, rank, world, dev, fake, **kw)
+            mine = src[job.row0 * W:(job.row0 + job.own_rows) * W]
+            outs[rank] = job.filter(mine).clone()
+            jobs[rank] = job
+        except Exception:      # noqa: BLE001
+            import traceback
+
+            errs.append((rank, traceback.format_exc()))
+
+    ts = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=600)
+    assert not errs, errs
+    return outs, jobs
+
+
+@pytest.mark.parametrize("world,H,W,L,sigma", [(2, 256, 96, 64, 3.0), (3, 288, 200, 32, 2.0), (8, 1536, 256, 256, 8.0)])
+def test_band_schedules_agree_bit_for_bit(world, H, W, L, sigma, monkeypatch):
+    """The default band step -- edge chunks first, boundary rows summed AND packed by one kernel on a side stream, ghost
+    rows received in place, every blur axis restricted to the rows something later reads -- against the same band
+    computed the plain way (whole splat, gather, all rows blurred on every axis): the same bits on every own pixel.
+    Restricting the blur is only legal because the rows it skips are never read; this is the test of that claim."""
+    import bench
+
+    feat = bench.synthetic_features(H, W, sigma_xy=sigma)
+    dev = torch.device("cuda")
+    src = bench.synthetic_values(torch, H, W, L, 0, dev)
+    new, jobs = _run_ranks(feat, src, L, world, dev)
+    inner = jobs[min(1, world - 1)]
+    assert inner._edge_first and inner.band.blur_rows is not None
+    rows = inner.describe()["rowtile"]["blur_rows_per_axis"]
+    assert rows[-1] == inner.band.M_own and rows[0] >= rows[-1] and rows[0] <= inner.band.M       # the last axis: own rows only
+    assert rows[0] > rows[-1], rows                                                                  # earlier axes carry ghosts
+    monkeypatch.setenv("PHL_ROWTILE_BLUR_ROWS", "0")
+    monkeypatch.setenv("PHL_ROWTILE_EDGE_FIRST", "0")
+    old, jobs_old = _run_ranks(feat, src, L, world, dev, groups=1)
+    assert not jobs_old[0]._edge_first and jobs_old[0].band.blur_rows is None
+    for r in range(world):
+        assert torch.equal(new[r], old[r]), f"rank {r}: schedules differ"
+    monkeypatch.delenv("PHL_ROWTILE_EDGE_FIRST")
+    mid, _ = _run_ranks(feat, src, L, world, dev)          # edge-first, unrestricted blur
+    for r in range(world):
+        assert torch.equal(new[r], mid[r]), f"rank {r}: restricted blur differs"
+
+
+def test_reduce_and_pack_in_one_kernel():
+    """phl_splat_part_pack: the listed rows are completed and written to their places in a send buffer by one launch
+    (sole-contributor rows are copied, multi-chunk rows summed, long lists reduced by a workgroup) == phl_splat_part
+    followed by a gather."""
+    import bench
+    import phl
+
+    feat = bench.tsukuba_features(288, 384, 0.1, 0.1)       # flat regions: vertices fed by long chunk lists
+    dev = torch.device("cuda")
+    L = 64
+    lat = phl.Lattice(torch.from_numpy(feat.reshape(-1, 5)).to(dev))
+    assert lat.tile_stats(L)["staged_splat"] == 1
+    src = torch.rand((feat.shape[0] * feat.shape[1], L), device=dev)
+    rng = np.random.default_rng(3)
+    pick = np.sort(rng.permutation(lat.M)[:lat.M // 3]).astype(np.int64)
+    rows = torch.from_numpy(pick).to(dev)
+    mask = lat.chunks_touching(rows)
+    ch = torch.from_numpy(np.nonzero(mask)[0].astype(np.int32)).to(dev)
+    partial = torch.empty((max(lat.partial_rows, 1), L), device=dev)
+    a = torch.zeros((lat.M, L), device=dev)
+    lat.splat_part(src, a, partial, ch, rows.to(torch.int32))
+    want = lat.gather_rows(a, rows)
+    perm = torch.from_numpy(rng.permutation(len(pick)).astype(np.int32)).to(dev)
+    pack = torch.full((len(pick) + 3, L), float("nan"), device=dev)
+    b = torch.zeros((lat.M, L), device=dev)
+    none = torch.empty(0, dtype=torch.int32, device=dev)
+    lat.splat_part(src, b, partial, ch, none)                                  # chunk sums only
+    lat.splat_part(src, b, partial, none, rows.to(torch.int32), pack_pos=perm, pack=pack)     # rows + pack
+    assert torch.equal(a[rows], b[rows])
+    assert torch.equal(pack[perm.long()], want) and torch.isnan(pack[len(pick):]).all()
