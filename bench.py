@@ -792,7 +792,26 @@ def self_check(torch, phl, dist, backend, rank, world, device, rowtiled, job, la
         err = rel(out, want[a:a + job.n_local])
         res.update(what="row-band result vs a single-lattice filter of the whole volume on the same GPU", **probe)
         whole.close()
-        del want, full
+        del want
+        # ... and how far the bands (one defect-free lattice per band) are from the REFERENCE's result, whose hash table
+        # files the key in flight at each doubling from a stale slot (permutohedral.h:59-62,101-103): the single lattice
+        # built with the reference's table, same volume, same GPU.  Reported, not part of `ok`: the rows beyond 1e-4 are the
+        # ones the reference's duplicate vertices touch.
+        whole_ref = phl.Lattice(torch.from_numpy(feat.reshape(-1, d)).to(device), reference_table=True)
+        want_ref = whole_ref.filter(full)[a:a + job.n_local]
+        scale = torch.clamp(want_ref.abs(), min=1e-3 * float(want_ref.abs().max()))
+        relr = ((out - want_ref).abs() / scale).max(dim=1).values
+        far = torch.tensor([float((relr > CHECK_TOL).sum()), float(relr.numel()), float(relr.max())], dtype=torch.float64,
+                           device=device if backend == "nccl" else "cpu")
+        if world > 1:
+            mx = far[2:].clone()
+            dist.all_reduce(far[:2], op=dist.ReduceOp.SUM)
+            dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+            far[2] = mx[0]
+        res["vs_reference_table"] = {"rows_beyond_1e-4": float(far[0] / far[1]), "max_rel": float(far[2]), "M_reference": int(whole_ref.M),
+                                     "what": "band rows vs the single lattice built with the reference's table (its duplicate vertices)"}
+        whole_ref.close()
+        del want_ref, full
     else:
         a = lat.filter(src)
         b = lat.filter(src)

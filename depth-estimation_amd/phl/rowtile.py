@@ -398,8 +398,8 @@ class RowTileFilter:
                         ops.append(dist.P2POp(op, t, p))
             self._ops.append(ops)
         if self.device.type == "cuda":
-            self._side = torch.cuda.Stream(device=dev)
-            self._ev_edge, self._ev_packed = torch.cuda.Event(), torch.cuda.Event()
+            self._side = torch.cuda.Stream(device=dev, priority=-1)       # high priority: the boundary goes first
+            self._ev_start, self._ev_edge, self._ev_packed = torch.cuda.Event(), torch.cuda.Event(), torch.cuda.Event()
 
     def _make_edge_plan(self):
         """Edge-first schedule (one channel group): the chunks that feed this rank's boundary vertices are
@@ -487,13 +487,17 @@ class RowTileFilter:
         band, eng, pl, dist = self.band, self.band.eng, self._plan, self.dist
         vert, sbuf, none = self._vert[0], self._sbuf[0], pl["none"]
         main, side = torch.cuda.current_stream(self.device), self._side
-        eng.splat_part(src, vert, pl["partial"], pl["edge"], none)            # chunk sums only: edge chunks ...
-        self._ev_edge.record(main)
-        eng.splat_part(src, vert, pl["partial"], pl["interior"], none)        # ... and the interior chunks right behind them
+        # Two queues.  The HIGH-PRIORITY side stream carries the boundary: edge chunks -> their rows summed and packed by one
+        # kernel -> the exchange.  The caller's stream carries the bulk: interior chunks -> all other rows.  The two chunk
+        # launches are independent (each writes its own partial rows / sole rows), so the interior workgroups fill the
+        # slots the edge workgroups leave -- no kernel boundary between them, the splat costs what one launch over all
+        # chunks costs -- while the edge part, first in line, is done after about a third of it.
+        self._ev_start.record(main)
         reqs = []
         with torch.cuda.stream(side):
-            side.wait_event(self._ev_edge)
-            # boundary rows complete and packed by one kernel, beside the interior chunks
+            side.wait_event(self._ev_start)     # (the previous step's slice has finished with `vert`)
+            eng.splat_part(src, vert, pl["partial"], pl["edge"], none)
+            self._ev_edge.record(side)
             eng.splat_part(src, vert, pl["partial"], none, pl["send_rows"], pack_pos=pl["pack_pos"], pack=sbuf if pl["pack_pos"] is not None else None)
             if pl["pack_pos"] is None:
                 eng.gather_rows(vert, band._send_all, out=sbuf)
@@ -503,11 +507,13 @@ class RowTileFilter:
             else:
                 self._sbuf_h[0].copy_(sbuf, non_blocking=True)
                 self._ev_packed.record(side)
+        eng.splat_part(src, vert, pl["partial"], pl["interior"], none)        # interior chunks, beside the edge part
+        main.wait_event(self._ev_edge)          # rows shared between an edge and an interior chunk need both
+        eng.splat_part(src, vert, pl["partial"], none, pl["other_rows"])      # all other rows of this band, under the exchange
         if not self._direct:
-            self._ev_packed.synchronize()       # the host waits for the boundary rows only; the interior chunks are queued
+            self._ev_packed.synchronize()       # the host waits for the boundary rows only; everything else is queued
             if self._ops[0] and not self._stub_exchange:
                 reqs = dist.batch_isend_irecv(self._ops[0])
-        eng.splat_part(src, vert, pl["partial"], none, pl["other_rows"])      # all other rows of this band, under the exchange
         for req in reqs:
             req.wait()
         main.wait_stream(side)

