@@ -922,6 +922,17 @@ int phl_get_vertex_order(phl_lattice *lat, int32_t *row_of_vertex)
     return PHL_OK;
 }
 
+int phl_get_pixel_order(phl_lattice *lat, int32_t *pix_order)
+{
+    if (!lat || !pix_order) { phl_set_error("phl_get_pixel_order: bad arguments"); return PHL_ERR_INVALID; }
+    if (lat->n == 0) return PHL_OK;
+    if (!lat->pix_order) { phl_set_error("phl_get_pixel_order: the lattice has no chunks"); return PHL_ERR_UNSUPPORTED; }
+    device_guard g(lat->device);
+    PHL_HIP(hipDeviceSynchronize());
+    PHL_HIP(hipMemcpy(pix_order, lat->pix_order, sizeof(int32_t) * (size_t)lat->n, hipMemcpyDeviceToHost));
+    return PHL_OK;
+}
+
 int phl_get_keys(phl_lattice *lat, int16_t *keys)
 {
     if (!lat || !keys) { phl_set_error("phl_get_keys: bad arguments"); return PHL_ERR_INVALID; }

@@ -433,6 +433,14 @@ class Lattice:
         return out
 
     # ---- introspection (host copies) --------------------------------------------------------
+    def pixel_order(self):
+        """int32 [n]: pixels in chunk order (chunk c = pixel_order()[c*P:(c+1)*P], P = tile_stats()['pixels_per_chunk'])."""
+        out = np.empty(self.n, np.int32)
+        lib = load_library()
+        lib.phl_get_pixel_order.argtypes = [C.c_void_p, C.c_void_p]
+        _check(lib.phl_get_pixel_order(self._h, out.ctypes.data_as(C.c_void_p)))
+        return out
+
     def keys(self):
         out = np.empty((self.M, self.d), np.int16)
         _check(load_library().phl_get_keys(self._h, out.ctypes.data_as(C.c_void_p)))

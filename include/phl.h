@@ -294,6 +294,8 @@ int phl_tile_stats(const phl_lattice *lat, int vd, int64_t out[7]);
  * (locality) order instead: row_of_vertex[v] = row that holds first-touch vertex v; phl_add_vertices returns rows.
  * Ghost vertices come last in both numberings. */
 int phl_get_vertex_order(phl_lattice *lat, int32_t *row_of_vertex_host /* [M] */);
+/* Pixels in chunk order: chunk c of the LDS-staged kernels holds pixels pix_order[c*P ... (c+1)*P), P = phl_tile_stats()[0]. */
+int phl_get_pixel_order(phl_lattice *lat, int32_t *pix_order_host /* [n] */);
 int phl_get_keys(phl_lattice *lat, int16_t *keys_host /* [M][d] */);
 int phl_get_replay(phl_lattice *lat, int32_t *vid_host /* [n][d+1] */, float *w_host /* [n][d+1] */);
 int phl_get_neighbors(phl_lattice *lat, int32_t *nbr_host /* [d+1][M][2], -1 = absent */);
