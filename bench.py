@@ -728,8 +728,9 @@ def main():
                        # "reference": vertices, duplicates included, are the reference's (its hash table files the key in
                        # flight at every doubling from a stale slot, permutohedral.h:59-62,101-103) -- with --exact the
                        # output is bit-identical to the reference engine at this size (cpu_baseline.gpu_bit_equal_to_reference
-                       # checks it in this run); "clean": one vertex per key.  Row bands build per-band lattices: always clean.
-                       "table": "clean" if (rowtiled or args.clean_table) else "reference"},
+                       # checks it in this run); "clean": one vertex per key.  Row bands are cut out of the whole image's
+                       # reference-table lattice (phl_sub_lattice): "reference" too, checked by `check` in the same run.
+                       "table": (job.band.table if rowtiled else ("clean" if args.clean_table else "reference"))},
             "ranks": world, "backend": backend, "devices_visible": ndev,
             "launched_by": "bench.py launcher" if os.environ.get("PHL_BENCH_LAUNCHED") else ("torchrun" if "TORCHELASTIC_RUN_ID" in os.environ else "direct"),
             "lattice_build_ms": round(build_ms, 2),
@@ -786,11 +787,13 @@ def self_check(torch, phl, dist, backend, rank, world, device, rowtiled, job, la
         else:
             bands = [mine]
         full = torch.cat([synthetic_values(torch, int(r), W, L, int(r0), device) for r0, r in bands])
-        whole = phl.Lattice(torch.from_numpy(feat.reshape(-1, d)).to(device))
+        ref_bands = job.band.table == "reference"
+        whole = phl.Lattice(torch.from_numpy(feat.reshape(-1, d)).to(device), reference_table=ref_bands)
         want = whole.filter(full)
         a = job.row0 * W
         err = rel(out, want[a:a + job.n_local])
-        res.update(what="row-band result vs a single-lattice filter of the whole volume on the same GPU", **probe)
+        res.update(what="row-band result vs a single-lattice filter of the whole volume on the same GPU ("
+                        + ("reference table: the bands are cut out of it" if ref_bands else "defect-free table, like the bands") + ")", **probe)
         whole.close()
         del want
         # ... and how far the bands (one defect-free lattice per band) are from the REFERENCE's result, whose hash table

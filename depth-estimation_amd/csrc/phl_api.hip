@@ -384,6 +384,20 @@ int phl_hip_fail(hipError_t e, const char *what, const char *file, int line)
     return e == hipErrorNoDevice || e == hipErrorInvalidDevice ? PHL_ERR_NO_DEVICE : PHL_ERR_HIP;
 }
 
+// an empty handle (phl_sub_lattice fills it): same initial state phl_build_ex gives one
+int phl_lattice_blank(phl_lattice **out, int device, int d, int64_t n)
+{
+    phl_lattice *lat = new phl_lattice();
+    memset(lat, 0, sizeof(*lat));
+    lat->device = device;
+    lat->d = d;
+    lat->n = n;
+    lat->nbr00_override = -2;
+    lat->shared = new phl_shared();
+    *out = lat;
+    return PHL_OK;
+}
+
 extern "C" {
 
 int phl_version(void) { return PHL_VERSION; }

@@ -207,6 +207,8 @@ hipError_t phl_dev_free(void *p);
 bool phl_scratch_acquire(void **base, size_t *cap);
 void phl_scratch_release(size_t wanted_bytes);
 
+int phl_lattice_blank(phl_lattice **out, int device, int d, int64_t n);      // phl_api.hip (extern "C" there)
+
 // ---- launchers implemented in phl_build.hip ----
 int phl_build_device(phl_lattice *lat, const float *ref, int64_t rs, int64_t cs, hipStream_t st);
 int phl_ensure_csr(phl_lattice *lat, hipStream_t st);  // pixel-sorted lists, built on first use

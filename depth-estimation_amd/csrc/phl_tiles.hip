@@ -134,6 +134,12 @@ __global__ __launch_bounds__(256) void k_strip_key(const int *__restrict__ vhome
     key[v] = ((ca / stripw) * ncb + cb) * stripw + ca % stripw;
 }
 
+__global__ __launch_bounds__(256) void k_iota_tail(int *__restrict__ p, int first, int end)
+{
+    const int i = first + blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < end) p[i] = i;
+}
+
 __global__ __launch_bounds__(256) void k_invert_perm(const int *__restrict__ perm, int M, int *__restrict__ inv)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -2069,7 +2075,10 @@ int phl_tiles_build(phl_lattice *lat, const float *ref, int64_t rs, int64_t cs, 
     // 2b. internal vertex numbering (see k_vertex_home), then the key -> vertex table and the blur neighbours
     {
         static const bool renumber = !(getenv("PHL_RENUMBER") && atoi(getenv("PHL_RENUMBER")) == 0);
-        const int M = (int)lat->M;
+        const int M_all = (int)lat->M;
+        // a band cut out of the whole image's lattice (phl_sub_lattice) comes with ghost vertices behind its own ones:
+        // only the own vertices are renumbered, the ghosts keep their rows (and the caller's order)
+        const int M = (lat->M_local > 0 && lat->M_local < lat->M) ? (int)lat->M_local : M_all;
         // fresh build (phl_build_device's tables are there): the candidates' vertex ids are written once, below,
         // through the locality numbering -- unless the vertices' homes have to be read off replay[] first
         bool from_tables = lat->bt_slot_of != nullptr;
@@ -2093,15 +2102,17 @@ int phl_tiles_build(phl_lattice *lat, const float *ref, int64_t rs, int64_t cs, 
             const int stripw = (nca + nstrips - 1) / nstrips;
             hipLaunchKernelGGL(k_strip_key, dim3((M + 255) / 256), dim3(256), 0, st, vhome, M, nca, ncb, stripw, vkey);
             PHL_HIP(hipGetLastError());
-            PHL_HIP(phl_dev_malloc((void **)&lat->ft_of_int, sizeof(int) * (size_t)M));
-            PHL_HIP(phl_dev_malloc((void **)&lat->int_of_ft, sizeof(int) * (size_t)M));
+            PHL_HIP(phl_dev_malloc((void **)&lat->ft_of_int, sizeof(int) * (size_t)M_all));
+            PHL_HIP(phl_dev_malloc((void **)&lat->int_of_ft, sizeof(int) * (size_t)M_all));
             rc = stable_sort_perm(vkey, M, (int64_t)(nstrips + 1) * ncb * stripw, lat->ft_of_int, tmp, st);
             if (rc) return rc;
-            hipLaunchKernelGGL(k_invert_perm, dim3((M + 255) / 256), dim3(256), 0, st, lat->ft_of_int, M, lat->int_of_ft);
+            if (M_all > M)        // ghosts: identity
+                hipLaunchKernelGGL(k_iota_tail, dim3((M_all - M + 255) / 256), dim3(256), 0, st, lat->ft_of_int, M, M_all);
+            hipLaunchKernelGGL(k_invert_perm, dim3((M_all + 255) / 256), dim3(256), 0, st, lat->ft_of_int, M_all, lat->int_of_ft);
             int16_t *vkeys_new;
-            PHL_HIP(phl_dev_malloc((void **)&vkeys_new, sizeof(int16_t) * (size_t)M * d));
-            hipLaunchKernelGGL(k_permute_keys, dim3((unsigned)(((int64_t)M * d + 255) / 256)), dim3(256), 0, st, lat->vkeys,
-                               lat->ft_of_int, M, d, vkeys_new);
+            PHL_HIP(phl_dev_malloc((void **)&vkeys_new, sizeof(int16_t) * (size_t)M_all * d));
+            hipLaunchKernelGGL(k_permute_keys, dim3((unsigned)(((int64_t)M_all * d + 255) / 256)), dim3(256), 0, st, lat->vkeys,
+                               lat->ft_of_int, M_all, d, vkeys_new);
             if (from_tables) {
                 rc = phl_write_final_vids(lat, st);
                 if (rc) return rc;

@@ -199,6 +199,42 @@ class Lattice:
         self._h = handle
         self.M = int(lib.phl_num_vertices(handle))
 
+    # ---- a band cut out of the whole image's lattice (row-band multi-GPU, phl/rowtile.py) ---------------------
+    @classmethod
+    def whole_image(cls, ref, device=None):
+        """The lattice row bands are cut from: the whole image's, with the reference's table behaviour."""
+        return cls(ref, device=device, reference_table=True)
+
+    def vertices_of_pixels(self, p0, p1):
+        """bool numpy [M]: first-touch vertices touched by pixels [p0, p1)."""
+        lib = load_library()
+        lib.phl_vertices_of_pixels.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]
+        mask = np.zeros(self.M, np.uint8)
+        with torch.cuda.device(self.device):
+            _check(lib.phl_vertices_of_pixels(self._h, int(p0), int(p1), mask.ctypes.data_as(C.c_void_p), _stream(self.device)))
+        return mask.astype(bool)
+
+    def sub_lattice(self, p0, p1, sel, n_own, ref_band):
+        """Lattice of pixels [p0, p1) on the selected vertices ``sel`` (first-touch ids; the first n_own = every vertex those
+        pixels touch, then ghosts in the caller's order): phl_sub_lattice in include/phl.h.  The new lattice numbers its
+        vertices by position in ``sel``; rows of ghost vertices are M_own + position among the ghosts."""
+        lib = load_library()
+        lib.phl_sub_lattice.argtypes = [C.POINTER(C.c_void_p), C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int64,
+                                        C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]
+        sel = np.ascontiguousarray(sel, np.int32)
+        ref_d = _as_device(ref_band.detach(), self.device)
+        assert ref_d.shape == (p1 - p0, self.d)
+        handle = C.c_void_p()
+        with torch.cuda.device(self.device):
+            _check(lib.phl_sub_lattice(C.byref(handle), self._h, int(p0), int(p1), sel.ctypes.data_as(C.c_void_p), len(sel), int(n_own),
+                                       C.c_void_p(ref_d.data_ptr()), ref_d.stride(0), ref_d.stride(1), _stream(self.device)))
+        sub = Lattice.__new__(Lattice)
+        sub.device, sub.n, sub.d = self.device, int(p1 - p0), self.d
+        sub.reference_table = self.reference_table
+        sub._h = handle
+        sub.M = int(lib.phl_num_vertices(handle))
+        return sub
+
     def close(self):
         h, self._h = getattr(self, "_h", None), None
         if h and _lib is not None:          # at interpreter shutdown the module globals may be gone

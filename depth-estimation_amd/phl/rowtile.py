@@ -119,9 +119,17 @@ class RowBand:
     """One rank's share.  Build phases: build_outbox -> build_inbox -> order_outbox -> order_inbox; then per call
     splat_outbox -> finish.  Tensors live on the engine's device."""
 
-    def __init__(self, feat, rank, world, engine_factory, device):
+    def __init__(self, feat, rank, world, engine_factory, device, table=None):
+        """table: "reference" -- the band is CUT OUT OF the whole image's reference-table lattice (engines that offer
+        ``whole_image`` / ``sub_lattice``: every rank builds the whole lattice once, keeps its band and the ghosts, and
+        needs no build-time exchange at all: vertex ids of the whole lattice are common knowledge) -- or "clean": one
+        defect-free lattice per band from its own pixels, ghosts exchanged by key.  Default: "reference" where the engine
+        can (PHL_ROWTILE_TABLE=clean overrides)."""
         H, W, d = feat.shape
         self.rank, self.world, self.W, self.d = rank, world, W, d
+        if table is None:
+            table = "reference" if (hasattr(engine_factory, "whole_image") and os.environ.get("PHL_ROWTILE_TABLE", "reference") != "clean") else "clean"
+        self.table = table
         cuts = band_rows(H, world)
         self.row0, self.row1 = cuts[rank], cuts[rank + 1]
         self.own_rows = self.row1 - self.row0
@@ -139,13 +147,16 @@ class RowBand:
         self.device = device
         own = np.ascontiguousarray(feat[self.row0:self.row1].reshape(-1, d), dtype=np.float32)
         t0 = time.time()
+        self.sides, self._send_keys, self._ready = {}, {}, False
+        reach = (a_k + b_k) * _REACH_SCALE + 1e-3 * (1.0 + max(abs(span[0][0]), abs(span[-1][1])))   # + fp32 elevate slack
+        if table == "reference":
+            self._cut_from_whole(feat, cuts, span, sign, k, reach, engine_factory, own)
+            self._t_build = time.time() - t0
+            return
         self.eng = engine_factory(torch.from_numpy(own).to(device))
         self.M_own = int(self.eng.M)          # before any ghost is filed
-        self.sides = {}   # peer -> dict(send_idx, ...)
         keys = self.eng.keys()
         ypos = sign * vertex_coordinate(keys, d, k)
-        reach = (a_k + b_k) * _REACH_SCALE + 1e-3 * (1.0 + max(abs(span[0][0]), abs(span[-1][1])))   # + fp32 elevate slack
-        self._send_keys = {}
         for peer in (rank - 1, rank + 1):
             if 0 <= peer < world:
                 v = np.nonzero((ypos >= span[peer][0] - reach) & (ypos <= span[peer][1] + reach))[0]
@@ -155,7 +166,64 @@ class RowBand:
                 self._send_keys[peer] = torch.from_numpy(np.ascontiguousarray(keys[v]))
         self._t_build = time.time() - t0
         self.peers = sorted(self.sides)
-        self._ready = False
+
+    @property
+    def needs_exchange(self):
+        """False once everything the filter phases need is in place (a band cut from the whole lattice never exchanges
+        anything at build time)."""
+        return not self._ready
+
+    def _cut_from_whole(self, feat, cuts, span, sign, k, reach, factory, own_feat):
+        """table = "reference": see __init__.  Both sides of a cut derive the same lists from the whole lattice:
+        what rank s sends rank t = s's vertices within a_k + b_k of t's span, first those t has itself (ascending vertex
+        id), then t's ghosts, nearest to t's band first (ties by vertex id) -- the order of t's ghost rows."""
+        H, W, d = feat.shape
+        rank, world, dev = self.rank, self.world, self.device
+        whole = factory.whole_image(torch.from_numpy(np.ascontiguousarray(feat.reshape(-1, d), dtype=np.float32)).to(dev))
+        keys = whole.keys()
+        y = sign * vertex_coordinate(keys, d, k)
+        near = {r: (y >= span[r][0] - reach) & (y <= span[r][1] + reach) for r in (rank - 1, rank, rank + 1) if 0 <= r < world}
+        dist = {r: np.maximum(0.0, np.maximum(span[r][0] - y, y - span[r][1])) for r in near}
+        has = {r: whole.vertices_of_pixels(cuts[r] * W, cuts[r + 1] * W) for r in near}
+        own = np.nonzero(has[rank])[0]
+        peers = [p for p in (rank - 1, rank + 1) if 0 <= p < world]
+
+        def wanted_by(t, s):
+            """ids rank s sends rank t, in t's order; number of shared ones"""
+            cand = has[s] & near[t]
+            shared = np.nonzero(cand & has[t])[0]
+            ghosts = np.nonzero(cand & ~has[t])[0]
+            ghosts = ghosts[np.lexsort((ghosts, dist[t][ghosts]))]
+            return shared, ghosts
+
+        sel, plan = [own], {}
+        for p in peers:
+            shared_in, ghosts_in = wanted_by(rank, p)
+            shared_out, ghosts_out = wanted_by(p, rank)
+            plan[p] = (shared_in, ghosts_in, shared_out, ghosts_out)
+            sel.append(ghosts_in)
+        sel = np.concatenate(sel).astype(np.int32)
+        self.eng = whole.sub_lattice(cuts[rank] * W, cuts[rank + 1] * W, sel, len(own), torch.from_numpy(own_feat).to(dev))
+        self.M_whole = int(whole.M)
+        if hasattr(whole, "close"):
+            whole.close()
+        self.M_own = len(own)
+        pos = np.full(len(keys), -1, np.int64)
+        pos[sel] = np.arange(len(sel))                          # whole-lattice vertex -> the band's first-touch id
+        rows = self.eng.vertex_rows().cpu().numpy().astype(np.int64) if hasattr(self.eng, "vertex_rows") else np.arange(len(sel))
+        g0 = len(own)
+        for p in peers:
+            shared_in, ghosts_in, shared_out, ghosts_out = plan[p]
+            ghost_rows = rows[pos[ghosts_in]]
+            assert np.array_equal(ghost_rows, g0 + np.arange(len(ghosts_in))), "ghost rows must follow the own rows in the given order"
+            t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.int64)).to(dev)
+            self.sides[p] = dict(send_idx=t(rows[pos[np.concatenate([shared_out, ghosts_out])]]), send_shared=len(shared_out),
+                                 n_shared=len(shared_in), n_ghost=len(ghosts_in), ghost_row0=g0, shared_map=t(rows[pos[shared_in]]),
+                                 map_idx=t(np.concatenate([rows[pos[shared_in]], ghost_rows])))
+            g0 += len(ghosts_in)
+        self.peers = sorted(self.sides)
+        self._send_keys = None
+        self._finalize()
 
     # -- build phases ---------------------------------------------------------------------------
     def build_outbox(self):
@@ -199,6 +267,10 @@ class RowBand:
             s = self.sides[peer]
             s["send_shared"] = int(msg[0])
             s["send_idx"] = s["send_idx"][torch.from_numpy(msg[1:]).to(self.device)]
+        self._finalize()
+        self._t_build += time.time() - t0
+
+    def _finalize(self):
         # packed forms for the engine's fused row kernels: one gather for all peers' send rows, one scatter-add for
         # all received rows of shared vertices (only if no vertex receives from both sides: no atomics)
         if self.peers:
@@ -215,7 +287,6 @@ class RowBand:
                 self._shared_rng[p] = (sh, sh + s["n_shared"])
                 so, ro, sh = so + ks, ro + kr, sh + s["n_shared"]
         self._plan_blur_rows()
-        self._t_build += time.time() - t0
         self._ready = True
 
     def _plan_blur_rows(self):
@@ -319,7 +390,7 @@ class RowTileFilter:
       * channel groups pipelined (device payloads): the boundary rows of group g travel while group g+1 is splatted.
       * plain: any engine, any backend."""
 
-    def __init__(self, feat, L, rank, world, device, dist, engine_factory=None, groups=None):
+    def __init__(self, feat, L, rank, world, device, dist, engine_factory=None, groups=None, table=None):
         if engine_factory is None:
             import phl
             engine_factory = phl.Lattice
@@ -327,13 +398,14 @@ class RowTileFilter:
         # P2P payloads must live where the backend can reach them
         self.comm_device = device if dist.get_backend() == "nccl" else torch.device("cpu")
         t0 = time.time()
-        self.band = band = RowBand(feat, rank, world, engine_factory, device)
-        out = band.build_outbox()
-        counts = self._exchange({p: torch.tensor([k.shape[0]], dtype=torch.int64) for p, k in out.items()},
-                                {p: ((1,), torch.int64) for p in out})
-        inbox = self._exchange(out, {p: ((int(c.item()), band.d), torch.int16) for p, c in counts.items()})
-        band.build_inbox(inbox)
-        band.order_inbox(self._exchange(band.order_outbox(), {p: ((1 + int(k.shape[0]),), torch.int32) for p, k in out.items()}))
+        self.band = band = RowBand(feat, rank, world, engine_factory, device, table=table)
+        if band.needs_exchange:              # bands built from their own pixels: ghosts by key, then the order of their rows
+            out = band.build_outbox()
+            counts = self._exchange({p: torch.tensor([k.shape[0]], dtype=torch.int64) for p, k in out.items()},
+                                    {p: ((1,), torch.int64) for p in out})
+            inbox = self._exchange(out, {p: ((int(c.item()), band.d), torch.int16) for p, c in counts.items()})
+            band.build_inbox(inbox)
+            band.order_inbox(self._exchange(band.order_outbox(), {p: ((1 + int(k.shape[0]),), torch.int32) for p, k in out.items()}))
         if device.type == "cuda":
             torch.cuda.synchronize(device)
         self.build_ms = (time.time() - t0) * 1e3
@@ -605,7 +677,7 @@ class RowTileFilter:
         blur = None
         if getattr(b, "blur_rows", None) is not None:
             blur = [int((b.blur_rows[a, :, 1] - b.blur_rows[a, :, 0]).sum()) for a in range(b.d + 1)]
-        return {"rowtile": {"rows_per_rank": b.own_rows, "strip_rows": b.S, "M_local_plus_ghosts": int(b.M), "M_own": int(b.M_own),
+        return {"rowtile": {"table": b.table, "rows_per_rank": b.own_rows, "strip_rows": b.S, "M_local_plus_ghosts": int(b.M), "M_own": int(b.M_own),
                             "boundary_vertices_recv": rows,
                             "ghost_rows_received_in_place": {str(p): b.sides[p]["n_ghost"] for p in b.sides},
                             "blur_rows_per_axis": blur,
@@ -617,17 +689,18 @@ class RowTileFilter:
                             "exchange_bytes_per_step_per_rank": int(sum(rows.values()) * self.L * 4 * 2)}}
 
 
-def simulate(feat, src_full, world, engine_factory, device):
+def simulate(feat, src_full, world, engine_factory, device, table=None):
     """Play all `world` ranks in this process (loopback exchange).  Returns the filtered image
     [H*W, L] assembled from the bands.  For tests on a single GPU / CPU."""
     H, W, d = feat.shape
-    bands = [RowBand(feat, r, world, engine_factory, device) for r in range(world)]
-    out = [b.build_outbox() for b in bands]
-    for r, b in enumerate(bands):
-        b.build_inbox({p: out[p][r] for p in b.sides})
-    order = [b.order_outbox() for b in bands]
-    for r, b in enumerate(bands):
-        b.order_inbox({p: order[p][r] for p in b.sides})
+    bands = [RowBand(feat, r, world, engine_factory, device, table=table) for r in range(world)]
+    if any(b.needs_exchange for b in bands):
+        out = [b.build_outbox() for b in bands]
+        for r, b in enumerate(bands):
+            b.build_inbox({p: out[p][r] for p in b.sides})
+        order = [b.order_outbox() for b in bands]
+        for r, b in enumerate(bands):
+            b.order_inbox({p: order[p][r] for p in b.sides})
     outs = [b.splat_outbox(src_full[b.row0 * W:b.row1 * W]) for b in bands]
     res = []
     for r, b in enumerate(bands):

@@ -129,6 +129,18 @@ int phl_trim_scratch(void);
 int phl_add_vertices(phl_lattice *lat, const int16_t *keys_host, int64_t count, int32_t *vid_host,
                      phl_stream stream);   /* vid_host: ROW of each key in the [M][vd] vertex buffers */
 int64_t phl_num_local_vertices(const phl_lattice *lat); /* vertices created by this lattice's own pixels */
+/* A band's lattice CUT OUT OF the whole image's lattice `whole` (built with PHL_BUILD_REFERENCE_TABLE, so that the band
+ * inherits the reference's vertices -- the duplicates its hash table creates at its doublings, permutohedral.h:59-62,101-103,
+ * and which of them every lookup resolved to -- instead of re-deriving a defect-free lattice from its own pixels).
+ * Pixels [p0, p1) of `whole` become pixels 0 .. p1-p0-1; sel_host lists the n_sel vertices of `whole` to keep (first-touch
+ * ids, distinct): the first n_own must cover every vertex those pixels touch, the rest are ghosts (vertices of the
+ * neighbouring bands within blur's reach), kept in the caller's order behind the own vertices.  The new lattice's
+ * first-touch numbering is the position in sel_host.  ref_dev: the band's own features [p1-p0][d] (chunk grid).
+ * phl_vertices_of_pixels: mask_host[v] = 1 iff a pixel of [p0, p1) touches first-touch vertex v (else 0), [phl_num_vertices].
+ * No reference counterpart (the reference is single-process). */
+int phl_vertices_of_pixels(phl_lattice *lat, int64_t p0, int64_t p1, unsigned char *mask_host, phl_stream stream);
+int phl_sub_lattice(phl_lattice **out, phl_lattice *whole, int64_t p0, int64_t p1, const int32_t *sel_host, int64_t n_sel,
+                    int64_t n_own, const float *ref_dev, int64_t ref_row_stride, int64_t ref_col_stride, phl_stream stream);
 
 /* Pre-size everything phl_filter(vd) needs (the [M][vd] ping-pong buffers, the partial-row buffer
  * of the chunk splat or the contribution lists of the gather splat) so that the NEXT call, on any stream,

@@ -21,7 +21,7 @@ def test_bands_match_single_lattice_on_gpu(world, H, W, L):
     feat, src = make_image(H, W, L, sigma_xy=3.0)
     dev = torch.device("cuda")
     s = torch.from_numpy(src).to(dev)
-    want = phl.Lattice(torch.from_numpy(feat.reshape(-1, 5)).to(dev)).filter(s).cpu().numpy()
+    want = phl.Lattice(torch.from_numpy(feat.reshape(-1, 5)).to(dev), reference_table=True).filter(s).cpu().numpy()
     got, bands = rowtile.simulate(feat, s, world, phl.Lattice, dev)
     assert rel(got.cpu().numpy(), want) <= RTOL
     for b in bands:
@@ -128,7 +128,7 @@ def test_two_processes_share_the_gpu_over_gloo(groups):
         p.join(timeout=120)
         assert p.exitcode == 0
     feat, src = make_image(H, W, L, sigma_xy=3.0)
-    want = phl.Lattice(torch.from_numpy(feat.reshape(-1, 5)).cuda()).filter(torch.from_numpy(src).cuda()).cpu().numpy()
+    want = phl.Lattice(torch.from_numpy(feat.reshape(-1, 5)).cuda(), reference_table=True).filter(torch.from_numpy(src).cuda()).cpu().numpy()
     got = np.concatenate([r[1] for r in res], 0)
     assert rel(got, want) <= RTOL
     sched = res[0][2]["rowtile"]["schedule"]
@@ -220,7 +220,7 @@ def test_preallocated_rccl_shaped_path_in_process(world, groups):
     for t in ts:
         t.join(timeout=300)
     assert not errs, errs
-    want = phl.Lattice(torch.from_numpy(feat.reshape(-1, 5)).to(dev)).filter(torch.from_numpy(src).to(dev)).cpu().numpy()
+    want = phl.Lattice(torch.from_numpy(feat.reshape(-1, 5)).to(dev), reference_table=True).filter(torch.from_numpy(src).to(dev)).cpu().numpy()
     got = np.concatenate([outs[r] for r in range(world)], 0)
     assert rel(got, want) <= RTOL
 
@@ -242,8 +242,11 @@ def test_full_size_c3_in_row_bands(world):
     feat = bench.synthetic_features(H, W)
     dev = torch.device("cuda")
     src = bench.synthetic_values(torch, H, W, L, 0, dev)
-    want = phl.Lattice(torch.from_numpy(feat.reshape(-1, 5)).to(dev)).filter(src)
+    # bands are cut out of the whole image's REFERENCE-TABLE lattice (rowtile.RowBand, table = "reference"): the result is
+    # the reference's, duplicates of its hash table included -- not the defect-free lattice's
+    want = phl.Lattice(torch.from_numpy(feat.reshape(-1, 5)).to(dev), reference_table=True).filter(src)
     got, bands = rowtile.simulate(feat, src, world, phl.Lattice, dev)
+    assert all(b.table == "reference" for b in bands)
     err = float(((got - want).abs() / want.abs().clamp_min(1e-3 * float(want.abs().max()))).max())
     rows = [b.recv_rows(p) for b in bands for p in b.sides]
     print(f"[measured] c3 in {world} bands: max rel err vs single lattice {err:.2e}; boundary rows per side "
@@ -325,7 +328,7 @@ def test_rccl_shaped_path_random_shapes():
         for t in ts:
             t.join(timeout=300)
         assert not errs, (trial, world, H, W, L, groups, errs)
-        want = phl.Lattice(torch.from_numpy(feat.reshape(-1, 5)).to(dev)).filter(torch.from_numpy(src).to(dev)).cpu().numpy()
+        want = phl.Lattice(torch.from_numpy(feat.reshape(-1, 5)).to(dev), reference_table=True).filter(torch.from_numpy(src).to(dev)).cpu().numpy()
         got = np.concatenate([outs[r][0] for r in range(world)], 0)
         assert rel(got, want) <= RTOL, (trial, world, H, W, L, groups)
         seen.add(any(outs[r][1] for r in range(world)))
@@ -353,7 +356,8 @@ def test_bench_two_ranks_validates_itself(workload):
     chk = line["check"]
     assert chk["ok"] and chk["check_max_rel"] <= 1e-4
     if workload == "band8":
-        assert line["scaling"] == "strong" and line["config"]["table"] == "clean"
+        assert line["scaling"] == "strong" and line["config"]["table"] == "reference"
+        assert chk["vs_reference_table"]["rows_beyond_1e-4"] == 0.0
         for k in ("exchange_ms", "step_ms", "step_no_exchange_ms", "overlap_hidden_frac"):
             assert k in chk
     else:
@@ -450,3 +454,83 @@ def test_reduce_and_pack_in_one_kernel():
     lat.splat_part(src, b, partial, none, rows.to(torch.int32), pack_pos=perm, pack=pack)     # rows + pack
     assert torch.equal(a[rows], b[rows])
     assert torch.equal(pack[perm.long()], want) and torch.isnan(pack[len(pick):]).all()
+
+
+def test_band_cut_from_the_whole_lattice_is_its_restriction():
+    """phl_sub_lattice: a band's lattice taken out of the whole image's reference-table lattice -- keys, the vertex every
+    (pixel, remainder) resolves to, weights, and the blur neighbours (wherever the neighbour was selected too) are the whole
+    lattice's, duplicates of the reference's hash table and their visibility included."""
+    import bench
+    import phl
+    from phl import rowtile
+
+    H, W = 256, 384
+    feat = bench.synthetic_features(H, W, sigma_xy=3.0)
+    dev = torch.device("cuda")
+    whole = phl.Lattice(torch.from_numpy(feat.reshape(-1, 5)).to(dev), reference_table=True)
+    clean = phl.Lattice(torch.from_numpy(feat.reshape(-1, 5)).to(dev))
+    assert whole.M > clean.M > 16383, "this image should grow the reference's table and leave duplicate vertices"
+    wk, (wvid, ww), wnb = whole.keys(), whole.replay(), whole.neighbors()
+    r0, r1 = 96, 160
+    p0, p1 = r0 * W, r1 * W
+    own_mask = whole.vertices_of_pixels(p0, p1)
+    assert np.array_equal(np.nonzero(own_mask)[0], np.unique(wvid[p0:p1]))
+    own = np.nonzero(own_mask)[0]
+    y = rowtile.vertex_coordinate(wk, 5, 1)
+    lo, hi = feat[r0, 0, 1], feat[r1 - 1, 0, 1]
+    ghosts = np.nonzero(~own_mask & (y >= lo - 3.01) & (y <= hi + 3.01))[0]
+    ghosts = ghosts[np.argsort(np.maximum(lo - y[ghosts], y[ghosts] - hi), kind="stable")]
+    sel = np.concatenate([own, ghosts]).astype(np.int32)
+    sub = whole.sub_lattice(p0, p1, sel, len(own), torch.from_numpy(feat[r0:r1].reshape(-1, 5)).to(dev))
+    assert sub.M == len(sel) and sub.M_local == len(own) and sub.n == p1 - p0
+    assert np.array_equal(sub.keys(), wk[sel])
+    svid, sw = sub.replay()
+    assert np.array_equal(sel[svid], wvid[p0:p1]) and np.array_equal(sw, ww[p0:p1])
+    rows = sub.vertex_rows().cpu().numpy()
+    assert np.array_equal(rows[len(own):], np.arange(len(own), len(sel))), "ghost rows keep the caller's order behind the own rows"
+    pos = np.full(whole.M, -1, np.int64)
+    pos[sel] = np.arange(len(sel))
+    snb = sub.neighbors()
+    want = np.where(wnb[:, sel, :] >= 0, pos[np.clip(wnb[:, sel, :], 0, None)], -1)     # absent, or not selected: -1
+    assert np.array_equal(snb, want)
+    # ... and it filters: the band's own pixels, with the ghost rows fed from the whole lattice's splat, give the whole
+    # lattice's output on those pixels
+    L = 32
+    src = torch.rand((H * W, L), device=dev)
+    vw = whole.to_first_touch(whole.splat(src))[torch.from_numpy(sel.astype(np.int64)).to(dev)]       # selected vertices, first-touch order
+    out = sub.slice(sub.blur(sub.from_first_touch(vw.contiguous())))
+    ref = whole.filter(src)[p0:p1]
+    # interior rows of the band (more than the blur's reach from vertices that were not selected) agree
+    err = ((out - ref).abs() / ref.abs().clamp_min(1e-3 * float(ref.abs().max()))).max(dim=1).values.reshape(r1 - r0, W)
+    assert float(err.max()) <= 1e-5, float(err.max())
+
+
+def test_reference_table_bands_give_the_reference_result(monkeypatch):
+    """Row bands cut from the whole reference-table lattice return the single reference-table lattice's result; bands
+    built the old way (one defect-free lattice per band) differ from it on the rows the reference's duplicates touch."""
+    import bench
+    import phl
+
+    H, W, L, world = 512, 384, 16, 4
+    feat = bench.synthetic_features(H, W, sigma_xy=3.0)
+    dev = torch.device("cuda")
+    src = bench.synthetic_values(torch, H, W, L, 0, dev)
+    whole = phl.Lattice(torch.from_numpy(feat.reshape(-1, 5)).to(dev), reference_table=True)
+    want = whole.filter(src)
+
+    def far_rows(got):
+        rel_ = ((got - want).abs() / want.abs().clamp_min(1e-3 * float(want.abs().max()))).max(dim=1).values
+        return float((rel_ > 1e-4).float().mean()), float(rel_.max())
+
+    outs, jobs = _run_ranks(feat, src, L, world, dev)
+    assert all(j.band.table == "reference" for j in jobs.values())
+    got = torch.cat([outs[r] for r in range(world)], 0)
+    frac, mx = far_rows(got)
+    print(f"[measured] reference-table bands vs the single reference-table lattice: max rel {mx:.2e}")
+    assert frac == 0.0 and mx <= 1e-5
+    monkeypatch.setenv("PHL_ROWTILE_TABLE", "clean")
+    outs_c, jobs_c = _run_ranks(feat, src, L, world, dev)
+    assert all(j.band.table == "clean" for j in jobs_c.values())
+    frac_c, mx_c = far_rows(torch.cat([outs_c[r] for r in range(world)], 0))
+    print(f"[measured] defect-free bands vs the reference-table lattice: {frac_c:.5f} of the rows beyond 1e-4 (max rel {mx_c:.2e})")
+    assert frac_c > 0.0

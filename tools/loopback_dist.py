@@ -53,6 +53,18 @@ def build_jobs(feat, L, world, device, want_ranks=None, backend="nccl", **kw):
 
     fake = LoopbackDist(world, backend)
     jobs, errs = {}, []
+    import os
+
+    import phl
+
+    if (want_ranks is not None and kw.get("table", None) != "clean" and os.environ.get("PHL_ROWTILE_TABLE", "reference") != "clean"
+            and hasattr(phl.Lattice, "whole_image")):
+        # bands cut out of the whole image's lattice need no build-time exchange: build only the ranks asked for, one after
+        # the other (as separate processes would: one whole-image build each)
+        for r in want_ranks:
+            fake.local.rank = r
+            jobs[r] = rowtile.RowTileFilter(feat, L, r, world, device, fake, **kw)
+        return jobs, fake
 
     def run(r):
         try:
