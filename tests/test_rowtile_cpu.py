@@ -230,3 +230,79 @@ def test_two_ranks_over_gloo():
     pr = res[0][3]["probe"]
     assert set(pr) == {"exchange_ms", "step_ms", "step_no_exchange_ms", "overlap_hidden_frac"}
     assert pr["exchange_ms"] > 0 and pr["step_ms"] > 0 and 0.0 <= pr["overlap_hidden_frac"] <= 1.0
+
+
+def _growing_image(H, W, L, seed=11):
+    """An image whose lattice grows the reference's hash table (M >= 16383): duplicate vertices exist."""
+    feat, src = make_image(H, W, L, sigma_xy=2.0, seed=seed, iid_colour=True)
+    return feat, src
+
+
+def test_reference_table_bands_on_the_cpu():
+    """Bands cut out of the whole image's reference-table lattice (RowBand table="reference", here with the faithful CPU
+    oracle as the whole lattice and numpy bands) return the reference's result -- duplicates of its hash table included --
+    while bands built from their own pixels (defect-free lattices) differ on the rows those duplicates touch."""
+    from oracle import phl_oracle as po
+    from phl import rowtile
+    from _engines import OracleEngine, OracleEngineRef
+
+    H, W, L, world = 90, 100, 3, 3
+    feat, src = _growing_image(H, W, L)
+    ref = feat.reshape(-1, 5)
+    faithful = po.Oracle(ref, faithful_table=True)
+    clean = po.Oracle(ref)
+    assert faithful.M > clean.M >= 16383, (faithful.M, clean.M)
+    want = faithful.filter(src)
+    got, bands = rowtile.simulate(feat, torch.from_numpy(src), world, OracleEngineRef, torch.device("cpu"))
+    assert all(b.table == "reference" and not b.needs_exchange for b in bands)
+    assert rel(got.numpy(), want) <= 1e-5
+    got_c, bands_c = rowtile.simulate(feat, torch.from_numpy(src), world, OracleEngine, torch.device("cpu"))
+    assert all(b.table == "clean" for b in bands_c)
+    assert rel(got_c.numpy(), clean.filter(src)) <= RTOL
+    far = (np.abs(got_c.numpy() - want) / np.maximum(np.abs(want), 1e-3 * np.abs(want).max())).max(axis=1) > 1e-4
+    assert far.any(), "the defect-free bands should differ from the reference where its duplicate vertices act"
+
+
+def _worker_ref(rank, world, port, H, W, L, q):
+    sys.path.insert(0, os.path.join(ROOT, "depth-estimation_amd"))
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as dist
+    from phl import rowtile
+    from _engines import OracleEngineRef
+
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    feat, src = _growing_image(H, W, L)
+    job = rowtile.RowTileFilter(feat, L, rank, world, torch.device("cpu"), dist, engine_factory=OracleEngineRef)
+    mine = torch.from_numpy(src[job.row0 * W:(job.row0 + job.own_rows) * W])
+    out1 = job.filter(mine)
+    assert torch.equal(out1, job.filter(mine))
+    q.put((rank, out1.numpy(), job.describe()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_reference_table_bands_two_ranks_over_gloo():
+    from oracle import phl_oracle as po
+
+    H, W, L, world = 64, 140, 2, 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_ref, args=(r, world, port, H, W, L, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=180) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    feat, src = _growing_image(H, W, L)
+    faithful = po.Oracle(feat.reshape(-1, 5), faithful_table=True)
+    assert faithful.M >= 16383
+    want = faithful.filter(src)
+    got = np.concatenate([r[1] for r in res], 0)
+    assert rel(got, want) <= 1e-5
+    assert res[0][2]["rowtile"]["table"] == "reference"
