@@ -123,8 +123,8 @@ def _mean_field_infer_staged(E_0, W, Mu, niters):
     trip inside every ``W @ Q`` with the compatibility product and the softmax on the host."""
     import phl
 
-    dev = torch.device("cuda", torch.cuda.current_device())
-    lat = phl.lattice_for(W.ref.detach())                 # CPU ref: built on the current device
+    dev = W.ref.device if W.ref.is_cuda else torch.device("cuda", torch.cuda.current_device())
+    lat = phl.lattice_for(W.ref.detach())                 # CPU ref: built on the current device; GPU ref: where it lives
     E0d = phl.to_device(E_0.detach().contiguous(), dev)
     Q = phl.softmax_neg_add(E0d)
     X = torch.empty_like(Q) if niters > 0 else None

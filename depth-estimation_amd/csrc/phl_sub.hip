@@ -105,6 +105,17 @@ int phl_sub_lattice(phl_lattice **out, phl_lattice *g, int64_t p0, int64_t p1, c
         phl_set_error("phl_sub_lattice: the whole image's table doubles inside blur() (M = 2^k - 1 exactly): not carried over to bands");
         return PHL_ERR_UNSUPPORTED;
     }
+    {   // the selection must name distinct vertices of the whole lattice (a repeated id would silently drop a row)
+        std::vector<unsigned char> seen((size_t)g->M, 0);
+        for (int64_t i = 0; i < n_sel; i++) {
+            const int32_t v = sel_host[i];
+            if (v < 0 || v >= g->M || seen[(size_t)v]) {
+                phl_set_error("phl_sub_lattice: selection entry %lld = %d is out of range or repeated", (long long)i, (int)v);
+                return PHL_ERR_INVALID;
+            }
+            seen[(size_t)v] = 1;
+        }
+    }
     device_sel guard(g->device);
     hipStream_t st = (hipStream_t)stream;
     const int d = g->d, dp1 = d + 1;

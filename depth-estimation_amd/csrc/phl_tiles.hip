@@ -1843,6 +1843,87 @@ int phl_tiles_ensure_vorder(phl_lattice *lat, hipStream_t st)
     return PHL_OK;
 }
 
+// ---- side streams for launches that are independent of their neighbours in a call ---------------------------------------
+// A chunk class of a few heavy chunks (textured 16x16 tiles of a natural image: 35 us for 0.6 MB at C3) used to run as its
+// own launch BEHIND the main grid, the whole chip waiting for a handful of workgroups.  It now runs BESIDE the main grid, on
+// a high-priority side stream forked from the caller's (event fork / join: legal inside a stream capture too).  Slots are
+// pooled per device; a slot is taken for the duration of the host call only -- later users of the same stream are ordered
+// behind the earlier work, and an event wait refers to the record that preceded it, so re-recording an event is safe.
+namespace {
+struct fork_slot {
+    hipStream_t s = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;
+    bool busy = false;
+};
+std::mutex g_fork_mu;
+std::map<int, std::vector<fork_slot *>> g_fork_pool;        // (never destroyed: the runtime may be gone at exit)
+
+fork_slot *fork_acquire()
+{
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    std::lock_guard<std::mutex> lk(g_fork_mu);
+    for (fork_slot *f : g_fork_pool[dev])
+        if (!f->busy) { f->busy = true; return f; }
+    if (g_fork_pool[dev].size() >= 16) return nullptr;
+    fork_slot *f = new fork_slot();
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);        // hi = the numerically lowest value = the highest priority
+    if (hipStreamCreateWithPriority(&f->s, hipStreamNonBlocking, hi) != hipSuccess ||
+        hipEventCreateWithFlags(&f->fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&f->join, hipEventDisableTiming) != hipSuccess) {
+        (void)hipGetLastError();
+        if (f->s) (void)hipStreamDestroy(f->s);
+        if (f->fork) (void)hipEventDestroy(f->fork);
+        if (f->join) (void)hipEventDestroy(f->join);
+        delete f;
+        return nullptr;
+    }
+    f->busy = true;
+    g_fork_pool[dev].push_back(f);
+    return f;
+}
+void fork_release(fork_slot *f)
+{
+    if (!f) return;
+    std::lock_guard<std::mutex> lk(g_fork_mu);
+    f->busy = false;
+}
+// fork from `st` (work enqueued on the slot's stream starts behind everything enqueued on st so far)
+fork_slot *fork_from(hipStream_t st)
+{
+    fork_slot *f = fork_acquire();
+    if (f && (hipEventRecord(f->fork, st) != hipSuccess || hipStreamWaitEvent(f->s, f->fork, 0) != hipSuccess)) {
+        (void)hipGetLastError();
+        fork_release(f);
+        f = nullptr;
+    }
+    return f;
+}
+// A forked chain inside a host function with temporaries: on any exit the side stream is drained before they are released.
+struct fork_guard {
+    fork_slot *f = nullptr;
+    ~fork_guard()
+    {
+        if (!f) return;
+        (void)hipStreamSynchronize(f->s);
+        fork_release(f);
+    }
+    // make `st` wait for the chain, give the slot back
+    hipError_t join(hipStream_t st)
+    {
+        if (!f) return hipSuccess;
+        hipError_t e = hipEventRecord(f->join, f->s);
+        if (e == hipSuccess) e = hipStreamWaitEvent(st, f->join, 0);
+        if (e == hipSuccess) {
+            fork_release(f);
+            f = nullptr;
+        }
+        return e;
+    }
+};
+}  // namespace
+
 int phl_tiles_link_vertices(phl_lattice *lat, hipStream_t st)
 {
     const int M = (int)lat->M, S = (int)lat->S;
@@ -2037,6 +2118,7 @@ int phl_tiles_build(phl_lattice *lat, const float *ref, int64_t rs, int64_t cs, 
         void *p[3] = {nullptr, nullptr, nullptr};
         ~deferred_t() { for (void *q : p) if (q) (void)phl_dev_free(q); }
     } deferred;
+    fork_guard nbr_chain;                            // (declared behind `deferred`: drained before those blocks are released)
     {   // temporaries of the chunk build go back to the scratch cache before the vertex lists are linked
     temp_pool tmp;
     // 1.-2. the pixel order (pixel_order above), unless it has been made under the table replay already
@@ -2131,7 +2213,11 @@ int phl_tiles_build(phl_lattice *lat, const float *ref, int64_t rs, int64_t cs, 
         }
         deferred.p[1] = lat->vfirst;                 // build-time only
         lat->vfirst = nullptr;
-        rc = phl_rebuild_table_and_neighbors(lat, st, &deferred.p[2]);
+        // key -> vertex table, packed keys, blur neighbours, composed pairs: ~100 us of small dependent launches that
+        // nothing in the chunk build below depends on -- on a forked stream beside it, joined before this phase ends
+        static const bool side_nbr = !(getenv("PHL_SIDE_NEIGHBORS") && atoi(getenv("PHL_SIDE_NEIGHBORS")) == 0);
+        if (side_nbr) nbr_chain.f = fork_from(st);
+        rc = phl_rebuild_table_and_neighbors(lat, nbr_chain.f ? nbr_chain.f->s : st, &deferred.p[2]);
         if (rc) return rc;
     }
 
@@ -2234,6 +2320,7 @@ int phl_tiles_build(phl_lattice *lat, const float *ref, int64_t rs, int64_t cs, 
 #undef PHL_CHUNK_MASKS
 #undef PHL_CHUNK_MASKS_X
     PHL_HIP(hipGetLastError());
+    PHL_HIP(nbr_chain.join(st));
     PHL_HIP(hipStreamSynchronize(st));
     }
     phl_release_build_tables(lat);                 // (read by k_final_vid: behind the synchronisation)
@@ -2293,54 +2380,6 @@ int phl_tiles_chunks_touching(phl_lattice *lat, const int64_t *rows_dev, int64_t
     return PHL_OK;
 }
 
-// ---- side streams for launches that are independent of their neighbours in a call ---------------------------------------
-// A chunk class of a few heavy chunks (textured 16x16 tiles of a natural image: 35 us for 0.6 MB at C3) used to run as its
-// own launch BEHIND the main grid, the whole chip waiting for a handful of workgroups.  It now runs BESIDE the main grid, on
-// a high-priority side stream forked from the caller's (event fork / join: legal inside a stream capture too).  Slots are
-// pooled per device; a slot is taken for the duration of the host call only -- later users of the same stream are ordered
-// behind the earlier work, and an event wait refers to the record that preceded it, so re-recording an event is safe.
-namespace {
-struct fork_slot {
-    hipStream_t s = nullptr;
-    hipEvent_t fork = nullptr, join = nullptr;
-    bool busy = false;
-};
-std::mutex g_fork_mu;
-std::map<int, std::vector<fork_slot *>> g_fork_pool;        // (never destroyed: the runtime may be gone at exit)
-
-fork_slot *fork_acquire()
-{
-    int dev = -1;
-    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-    std::lock_guard<std::mutex> lk(g_fork_mu);
-    for (fork_slot *f : g_fork_pool[dev])
-        if (!f->busy) { f->busy = true; return f; }
-    if (g_fork_pool[dev].size() >= 16) return nullptr;
-    fork_slot *f = new fork_slot();
-    int lo = 0, hi = 0;
-    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);        // hi = the numerically lowest value = the highest priority
-    if (hipStreamCreateWithPriority(&f->s, hipStreamNonBlocking, hi) != hipSuccess ||
-        hipEventCreateWithFlags(&f->fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&f->join, hipEventDisableTiming) != hipSuccess) {
-        (void)hipGetLastError();
-        if (f->s) (void)hipStreamDestroy(f->s);
-        if (f->fork) (void)hipEventDestroy(f->fork);
-        if (f->join) (void)hipEventDestroy(f->join);
-        delete f;
-        return nullptr;
-    }
-    f->busy = true;
-    g_fork_pool[dev].push_back(f);
-    return f;
-}
-void fork_release(fork_slot *f)
-{
-    if (!f) return;
-    std::lock_guard<std::mutex> lk(g_fork_mu);
-    f->busy = false;
-}
-}  // namespace
-
 int phl_launch_splat_tiled(phl_lattice *lat, const float *src, int64_t src_rs, int vd, float *vert, float *partial,
                            hipStream_t st, bool subset, const int *chunk_list, int nlist, const int *vlist, int64_t nvl,
                            const phl_splat_wide *wide, const int *pack_pos, float *pack, int64_t pack_rs)
@@ -2363,12 +2402,7 @@ int phl_launch_splat_tiled(phl_lattice *lat, const float *src, int64_t src_rs, i
     size_t tl_n = 0;
     // the small classes go first, on a forked high-priority stream, and run beside the main grid (see fork_slot)
     static const bool side_classes = !(getenv("PHL_SIDE_CLASSES") && atoi(getenv("PHL_SIDE_CLASSES")) == 0);
-    fork_slot *fk = (plan.n > 1 && !subset && !tl_path && side_classes) ? fork_acquire() : nullptr;
-    if (fk && (hipEventRecord(fk->fork, st) != hipSuccess || hipStreamWaitEvent(fk->s, fk->fork, 0) != hipSuccess)) {
-        (void)hipGetLastError();
-        fork_release(fk);
-        fk = nullptr;
-    }
+    fork_slot *fk = (plan.n > 1 && !subset && !tl_path && side_classes) ? fork_from(st) : nullptr;
     hipStream_t const st_main = st;
     int order[12];
     int no = 0;

@@ -234,7 +234,8 @@ int phl_splat_part_pack(phl_lattice *lat, const float *src_dev, int vd, int64_t 
  * blur of phl_blur / phl_filter then computes only those rows (a pass over the axis pair (2p, 2p+1) computes the rows
  * named for axis 2p+1); the others keep stale values nobody reads.  A band carries ghost vertices 2-3 lattice steps deep
  * for the FIRST axes' stencils; later axes need fewer of them and slice none (phl/rowtile.py derives the sets from the
- * neighbour tables).  ranges == NULL: all rows again.  phl_add_vertices resets it.  No reference counterpart. */
+ * neighbour tables).  ranges == NULL: all rows again.  phl_add_vertices resets it.  Like phl_add_vertices it belongs to
+ * the assembly of a band's lattice: not concurrent with filter calls on the handle.  No reference counterpart. */
 int phl_set_blur_rows(phl_lattice *lat, const int64_t *ranges /* [d+1][3][2] */, int naxes);
 /* slice(): out[p] = sum_i w_i * vert[v_i] / (1 + 2^-d)                        (:473-483) */
 int phl_slice(phl_lattice *lat, const float *vert_dev, int vd, float *out_dev, int64_t out_row_stride,

@@ -534,3 +534,37 @@ def test_reference_table_bands_give_the_reference_result(monkeypatch):
     frac_c, mx_c = far_rows(torch.cat([outs_c[r] for r in range(world)], 0))
     print(f"[measured] defect-free bands vs the reference-table lattice: {frac_c:.5f} of the rows beyond 1e-4 (max rel {mx_c:.2e})")
     assert frac_c > 0.0
+
+
+def test_sub_lattice_edge_cases():
+    """phl_sub_lattice argument handling: a selection that misses a vertex the band's pixels touch is refused (never a
+    silent wrong lattice), a selection without ghosts is a lattice of the band alone, ghost-only tails keep their order."""
+    import phl
+    from test_rowtile_cpu import make_image
+
+    feat, src = make_image(64, 48, 8, sigma_xy=3.0)
+    dev = torch.device("cuda")
+    W = 48
+    whole = phl.Lattice.whole_image(torch.from_numpy(feat.reshape(-1, 5)).to(dev))
+    p0, p1 = 16 * W, 40 * W
+    own = np.nonzero(whole.vertices_of_pixels(p0, p1))[0].astype(np.int32)
+    band_feat = torch.from_numpy(feat[16:40].reshape(-1, 5)).to(dev)
+    with pytest.raises(phl.PhlError) as ei:
+        whole.sub_lattice(p0, p1, own[:-1], len(own) - 1, band_feat)          # one own vertex short
+    assert ei.value.status == 1
+    with pytest.raises(phl.PhlError):
+        whole.sub_lattice(p0, p1, own, len(own) + 1, band_feat)               # n_own > n_sel
+    with pytest.raises(phl.PhlError):
+        whole.sub_lattice(p0, p1, np.concatenate([own, own[:1]]), len(own), band_feat)    # a repeated vertex
+    alone = whole.sub_lattice(p0, p1, own, len(own), band_feat)
+    assert alone.M == alone.M_local == len(own)
+    s = torch.from_numpy(src[p0:p1]).to(dev)
+    # a band without ghosts filters like a lattice built from the band's own pixels (same vertices: M below the first doubling)
+    ref = phl.Lattice(band_feat).filter(s)
+    got = alone.filter(s)
+    assert whole.M < 16383 and float((got - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
+    rest = np.setdiff1d(np.arange(whole.M, dtype=np.int32), own)[::-1].copy()   # every other vertex as a ghost, descending ids
+    sub = whole.sub_lattice(p0, p1, np.concatenate([own, rest]), len(own), band_feat)
+    assert sub.M == whole.M and np.array_equal(sub.keys()[len(own):], whole.keys()[rest])
+    rows = sub.vertex_rows().cpu().numpy()
+    assert np.array_equal(rows[len(own):], np.arange(len(own), whole.M))
