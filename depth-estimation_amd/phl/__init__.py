@@ -122,7 +122,8 @@ def _stream(device):
     return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
-_STAGE_BYTES = 8 << 20       # pinned staging piece of the host <-> device copies below
+_STAGE_BYTES = 2 << 20       # pinned staging piece of the host <-> device copies below (small enough that a Tsukuba-sized
+                             # E_0 of 7 MB already overlaps its host memcpy with the DMA of the piece before)
 
 
 def to_device(t, device):
