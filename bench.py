@@ -687,6 +687,35 @@ def main():
     mean_field = None
     if args.mean_field and rank == 0 and not rowtiled:
         mean_field = mean_field_iteration(torch, phl, lat, src, L, device)
+    if args.mean_field and rowtiled and L % 4 == 0:
+        # the whole mean-field iteration on row bands: only W @ Q exchanges anything, the compatibility product and the
+        # softmax are per pixel -- every rank on its own rows (collective: every rank runs it)
+        from crf.crf_module import charbonneir, compatibility_matrix, mean_field_step
+
+        labels = torch.arange(L, dtype=torch.float32, device=device)
+        Mu_b = compatibility_matrix(lambda a, b: charbonneir(a, b, 3.0), labels)
+        gen = torch.Generator(device=device)
+        gen.manual_seed(99 + rank)
+        E0_b = torch.rand(src.shape, generator=gen, device=device) * 10.0
+        Qn = torch.empty_like(src)
+        Wb = lambda U: job.filter(U, subtract_input=True)
+        for _ in range(4):
+            mean_field_step(E0_b, Wb, Mu_b, src, out=Qn)
+        sync_all()
+        t0 = time.perf_counter()
+        reps = 10
+        for _ in range(reps):
+            mean_field_step(E0_b, Wb, Mu_b, src, out=Qn)
+        sync_all()
+        dtm = time.perf_counter() - t0
+        if dist is not None:
+            tm = torch.tensor([dtm], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
+            dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+            dtm = float(tm.item())
+        if rank == 0:
+            mean_field = {"ms": round(dtm / reps * 1e3, 3), "Mpixel_labels_per_s": round(n_total * L / (dtm / reps) / 1e6, 1),
+                          "what": "row bands: filter - Q with the boundary exchange, then (.)@Mu + E0 + softmax(-.) on each rank's own rows; max over ranks"}
+        del E0_b, Qn
 
     backward = None
     if args.mean_field and rank == 0 and not rowtiled and not (args.exact or args.no_tiles):

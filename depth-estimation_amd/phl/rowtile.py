@@ -360,14 +360,23 @@ class RowBand:
                     vert.index_add_(0, s["shared_map"], rows[:ns].to(vert.device))
         return vert
 
-    def finish(self, vert, inbox, out=None, scratch=None):
+    def finish(self, vert, inbox, out=None, scratch=None, sub=None):
         """inbox: {peer: rows in the order asked for}; scratch: optional second [M, C] buffer for the blur."""
         self.place(vert, inbox)
-        return self.blur_slice(vert, out=out, scratch=scratch)
+        return self.blur_slice(vert, out=out, scratch=scratch, sub=sub)
 
-    def blur_slice(self, vert, out=None, scratch=None):
+    def blur_slice(self, vert, out=None, scratch=None, sub=None):
+        """sub: subtract these rows from the result inside the slice (the ``- U`` of LatticeGaussian, gaussian_matrix.py:303)."""
         vert = self.eng.blur(vert) if scratch is None else self.eng.blur(vert, scratch)
-        return self.eng.slice(vert) if out is None else self.eng.slice(vert, out=out)
+        if sub is None:
+            return self.eng.slice(vert) if out is None else self.eng.slice(vert, out=out)
+        if hasattr(self.eng, "gather_rows"):           # engines with the phl.Lattice stage surface fuse it
+            return self.eng.slice(vert, sub=sub, out=out)
+        res = self.eng.slice(vert) - sub
+        if out is not None:
+            out.copy_(res)
+            return out
+        return res
 
     @property
     def M(self):
@@ -526,11 +535,13 @@ class RowTileFilter:
                 req.wait()
         return recv
 
-    def filter(self, src, out=None):
-        """src: this rank's rows, [own_rows*W, L] on the engine device -> same shape (written to ``out`` if given)."""
+    def filter(self, src, out=None, subtract_input=False):
+        """src: this rank's rows, [own_rows*W, L] on the engine device -> same shape (written to ``out`` if given).
+        subtract_input: ``filter(src) - src`` with the subtraction fused into the slice (LatticeGaussian's product)."""
         dist = self.dist
         if out is None:
             out = torch.empty((self.band.n_local, self.L), dtype=torch.float32, device=self.band.device)
+        self._sub = src if subtract_input else None
         if self._edge_first:
             return self._filter_edge_first(src, out)
         if self._fused:
@@ -552,7 +563,7 @@ class RowTileFilter:
                 req.wait()
             pack = self._rpack[gi] if self._rpack[gi].device == self.band.device else self._rpack[gi].to(self.band.device)
             inbox = {p: pack[slice(*self.band.recv_range(p))] for p in self.band.sides}
-            self.band.finish(vert, inbox, out=out[:, c0:c1])
+            self.band.finish(vert, inbox, out=out[:, c0:c1], sub=None if self._sub is None else self._sub[:, c0:c1])
         return out
 
     def _filter_edge_first(self, src, out):
@@ -599,7 +610,7 @@ class RowTileFilter:
             self._rshared[0].copy_(self._rshared_h[0], non_blocking=True)
         if band._shared_all.numel():
             eng.scatter_add_rows(vert, band._shared_all, self._rshared[0])
-        band.blur_slice(vert, out=out, scratch=self._scratch[0])
+        band.blur_slice(vert, out=out, scratch=self._scratch[0], sub=self._sub)
         return out
 
     def _filter_fused(self, src, out):
@@ -614,7 +625,7 @@ class RowTileFilter:
                 req.wait()
             if band.sides and band._shared_all.numel():
                 band.eng.scatter_add_rows(self._vert[gi], band._shared_all, self._rshared[gi])
-            band.blur_slice(self._vert[gi], out=out[:, c0:c1], scratch=self._scratch[gi])
+            band.blur_slice(self._vert[gi], out=out[:, c0:c1], scratch=self._scratch[gi], sub=None if self._sub is None else self._sub[:, c0:c1])
         return out
 
     def exchange_probe(self, src, out, reps=10):
@@ -687,6 +698,28 @@ class RowTileFilter:
                                          if self._edge_first else ("channel groups pipelined" if self._fused else "plain")),
                             "edge_chunks": int(self._plan["edge"].numel()) if self._plan else None,
                             "exchange_bytes_per_step_per_rank": int(sum(rows.values()) * self.L * 4 * 2)}}
+
+
+class RowBandGaussian:
+    """The W of ``mean_field_infer(E_0, W, Mu)`` (crf/crf_module.py:41-53) for ONE RANK of a row-band run: ``W @ U`` is
+    LatticeGaussian's product ``filter(U, ref) - U`` (crf/gaussian_matrix.py:292-303) on this rank's rows of the image, the
+    boundary vertices exchanged with the neighbouring ranks inside.  Everything else of a mean-field iteration -- the
+    compatibility product, the softmax -- is per pixel, so every rank runs ``mean_field_infer`` on its own rows of E_0 with
+    this operator and the ranks' results stacked are the whole image's.  Collective: all ranks must call ``@`` the same
+    number of times."""
+
+    def __init__(self, feat, L, rank, world, device, dist, **kw):
+        self.job = RowTileFilter(feat, L, rank, world, device, dist, **kw)
+        self.row0, self.own_rows, self.n_local = self.job.row0, self.job.own_rows, self.job.n_local
+
+    def __matmul__(self, U):
+        assert U.shape == (self.n_local, self.job.L), "Incompatible shapes {}, and {}".format(tuple(U.shape), (self.n_local, self.job.L))
+        return self.job.filter(U, subtract_input=True)
+
+    def rows(self, full):
+        """this rank's rows of a whole-image [H*W, .] tensor"""
+        W = self.job.band.W
+        return full[self.row0 * W:(self.row0 + self.own_rows) * W]
 
 
 def simulate(feat, src_full, world, engine_factory, device, table=None):

@@ -568,3 +568,47 @@ def test_sub_lattice_edge_cases():
     assert sub.M == whole.M and np.array_equal(sub.keys()[len(own):], whole.keys()[rest])
     rows = sub.vertex_rows().cpu().numpy()
     assert np.array_equal(rows[len(own):], np.arange(len(own), whole.M))
+
+
+def test_mean_field_inference_on_row_bands():
+    """mean_field_infer (crf/crf_module.py:41-53) with the row-band operator as its W: every rank iterates on its own rows of
+    E_0 (compatibility product and softmax are per pixel, only W @ Q exchanges boundary vertices); the ranks' results stacked
+    are the single-GPU result of the mirrored API on the whole image."""
+    import threading
+
+    import bench
+    import crf.crf_module as cm
+    from crf.gaussian_matrix import LatticeGaussian
+    from phl import rowtile
+
+    H, W, L, world, niters = 384, 128, 32, 3, 3
+    feat = bench.synthetic_features(H, W, sigma_xy=4.0)
+    dev = torch.device("cuda")
+    E0 = torch.rand((H * W, L), device=dev, generator=torch.Generator(device=dev).manual_seed(5)) * 10.0
+    labels = torch.arange(L, dtype=torch.float32, device=dev)
+    Mu = cm.compatibility_matrix(lambda a, b: cm.charbonneir(a, b, 3.0), labels)
+    want = cm.mean_field_infer(E0, LatticeGaussian(torch.from_numpy(feat.reshape(-1, 5)).to(dev)), Mu, niters)
+    fake = _LoopbackDist(world)
+    outs, errs = {}, []
+
+    def run(rank):
+        try:
+            fake.local.rank = rank
+            Wb = rowtile.RowBandGaussian(feat, L, rank, world, dev, fake)
+            outs[rank] = cm.mean_field_infer(Wb.rows(E0).contiguous(), Wb, Mu, niters).clone()
+        except Exception:      # noqa: BLE001
+            import traceback
+
+            errs.append((rank, traceback.format_exc()))
+
+    ts = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=600)
+    assert not errs, errs
+    got = torch.cat([outs[r] for r in range(world)], 0)
+    err = float(((got - want).abs() / want.abs().clamp_min(1e-3 * float(want.abs().max()))).max())
+    disp = float(((got @ labels - want @ labels).abs() / (want @ labels).abs().clamp_min(1e-2)).max())
+    print(f"[measured] mean field on {world} row bands vs one GPU, {niters} iterations: Q rel {err:.2e}, disparity rel {disp:.2e}")
+    assert err <= 1e-4 and disp <= 1e-5
