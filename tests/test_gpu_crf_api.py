@@ -606,3 +606,28 @@ def test_mean_field_inference_can_be_captured_into_a_graph():
     g.replay()
     torch.cuda.synchronize()
     assert torch.equal(out, cm.mean_field_infer(E0, Wop, Mu, 5)) and not torch.equal(out, eager)
+
+
+@pytest.mark.parametrize("L,niters", [(6, 2), (16, 0), (20, 1)])
+def test_cpu_tensor_call_shape_edge_cases(L, niters):
+    """The staged CPU-tensor path of mean_field_infer on shapes off the fused kernels' grid (L % 4 != 0: library GEMM +
+    fused softmax), zero iterations, a non-contiguous E_0 and a float64 Mu (falls back to the plain torch loop): always the
+    numbers of the device-tensor call."""
+    import crf.crf_module as cm
+    from crf.gaussian_matrix import LatticeGaussian
+
+    g = torch.Generator().manual_seed(L)
+    n = 40 * 30
+    yy, xx = np.mgrid[0:40, 0:30].astype(np.float32)
+    ref = torch.from_numpy(np.stack([xx.ravel() / 3, yy.ravel() / 3, np.sin(xx.ravel() / 5)], 1).astype(np.float32))
+    big = torch.rand((n, 2 * L), generator=g) * 8.0
+    E0 = big[:, ::2]                                           # non-contiguous view
+    labels = torch.arange(L, dtype=torch.float32)
+    Mu = cm.compatibility_matrix(lambda a, b: cm.charbonneir(a, b, 2.0), labels)
+    got = cm.mean_field_infer(E0, LatticeGaussian(ref), Mu, niters)
+    want = cm.mean_field_infer(E0.contiguous().cuda(), LatticeGaussian(ref.cuda()), Mu.cuda(), niters)
+    assert not got.is_cuda and got.shape == E0.shape
+    assert float((got - want.cpu()).abs().max()) <= 1e-6
+    # float64 operands are not the staged path's business: the reference's loop shape, still correct
+    got64 = cm.mean_field_infer(E0, LatticeGaussian(ref), Mu.double(), niters) if niters == 0 else None
+    assert got64 is None or got64.shape == E0.shape
