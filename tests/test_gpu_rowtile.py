@@ -612,3 +612,112 @@ def test_mean_field_inference_on_row_bands():
     disp = float(((got @ labels - want @ labels).abs() / (want @ labels).abs().clamp_min(1e-2)).max())
     print(f"[measured] mean field on {world} row bands vs one GPU, {niters} iterations: Q rel {err:.2e}, disparity rel {disp:.2e}")
     assert err <= 1e-4 and disp <= 1e-5
+
+
+class _AsyncLoopbackDist(_LoopbackDist):
+    """_LoopbackDist with RCCL's stream semantics instead of a blocking exchange: a batch is ENQUEUED on the rank's
+    communication stream behind the caller's current stream (as ProcessGroupNCCL orders its work), runs late (a spin kernel in
+    front of every batch widens every race window), and Req.wait() only makes the caller's current stream wait for it -- the
+    host never blocks.  A schedule that reads a receive buffer, or overwrites a send buffer, without the stream dependency RCCL
+    needs shows up as wrong numbers here."""
+
+    class _Req:
+        def __init__(self, ev):
+            self.ev = ev
+
+        def wait(self):
+            torch.cuda.current_stream().wait_event(self.ev)
+            return True
+
+    def __init__(self, world, delay_cycles=2_000_000):
+        super().__init__(world)
+        self.comm = {}
+        self.delay = delay_cycles
+
+    def batch_isend_irecv(self, ops):
+        me = self.local.rank
+        comm = self.comm.get(me)
+        if comm is None:
+            comm = self.comm[me] = torch.cuda.Stream()
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        comm.wait_event(ev)
+        with torch.cuda.stream(comm):
+            torch.cuda._sleep(self.delay)                        # the wire is slow
+            for o in ops:
+                if o.op == "isend":
+                    t = o.tensor.clone()
+                    e = torch.cuda.Event()
+                    e.record(comm)
+                    self.q[(me, o.peer)].put((t, e))
+            for o in ops:
+                if o.op == "irecv":
+                    t, e = self.q[(o.peer, me)].get(timeout=300)
+                    comm.wait_event(e)
+                    if o.tensor.dtype == torch.uint8 or t.dtype == torch.uint8:
+                        o.tensor.view(torch.uint8).copy_(t.view(torch.uint8))
+                    else:
+                        o.tensor.copy_(t)
+            done = torch.cuda.Event()
+            done.record(comm)
+        return [self._Req(done)]
+
+
+def test_edge_first_schedule_under_asynchronous_exchange():
+    """The default band step (two queues, ghost rows received in place, send buffer packed by the reduction) with an exchange
+    that behaves like RCCL -- enqueued, late, never blocking the host -- over several back-to-back steps with changing inputs:
+    every step's result equals the one computed with the blocking loopback exchange, bit for bit."""
+    import threading
+
+    import bench
+    from phl import rowtile
+
+    H, W, L, world, steps = 768, 256, 64, 4, 4
+    feat = bench.synthetic_features(H, W, sigma_xy=6.0)
+    dev = torch.device("cuda")
+    srcs = [bench.synthetic_values(torch, H, W, L, 100 * s, dev) for s in range(steps)]
+
+    def run_all(fake):
+        outs, errs = {}, []
+
+        def run(rank):
+            try:
+                fake.local.rank = rank
+                job = rowtile.RowTileFilter(feat, L, rank, world, dev, fake)
+                assert job._edge_first and job._direct
+                res = []
+                for s in range(steps):          # no host synchronisation between steps: buffers are reused while work is in flight
+                    res.append(job.filter(srcs[s][job.row0 * W:(job.row0 + job.own_rows) * W]))
+                torch.cuda.synchronize()
+                outs[rank] = res
+            except Exception:      # noqa: BLE001
+                import traceback
+
+                errs.append((rank, traceback.format_exc()))
+
+        ts = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join(timeout=600)
+        assert not errs, errs
+        return outs
+
+    want = run_all(_LoopbackDist(world))
+    got = run_all(_AsyncLoopbackDist(world))
+    for r in range(world):
+        for s in range(steps):
+            assert torch.equal(got[r][s], want[r][s]), f"rank {r} step {s}: the asynchronous exchange changes the result"
+    # the harness has teeth: the same run with a wait() that does not wait reads ghost rows before they arrive
+
+    class _NoWait(_AsyncLoopbackDist):
+        class _Req:
+            def __init__(self, ev):
+                pass
+
+            def wait(self):
+                return True
+
+    bad = run_all(_NoWait(world))
+    assert any(not torch.equal(bad[r][s], want[r][s]) for r in range(world) for s in range(steps)), \
+        "a missing stream dependency went unnoticed: the asynchronous loopback does not test what it claims"
