@@ -663,7 +663,8 @@ class _AsyncLoopbackDist(_LoopbackDist):
         return [self._Req(done)]
 
 
-def test_edge_first_schedule_under_asynchronous_exchange():
+@pytest.mark.parametrize("groups", [None, 2])
+def test_edge_first_schedule_under_asynchronous_exchange(groups):
     """The default band step (two queues, ghost rows received in place, send buffer packed by the reduction) with an exchange
     that behaves like RCCL -- enqueued, late, never blocking the host -- over several back-to-back steps with changing inputs:
     every step's result equals the one computed with the blocking loopback exchange, bit for bit."""
@@ -683,8 +684,8 @@ def test_edge_first_schedule_under_asynchronous_exchange():
         def run(rank):
             try:
                 fake.local.rank = rank
-                job = rowtile.RowTileFilter(feat, L, rank, world, dev, fake)
-                assert job._edge_first and job._direct
+                job = rowtile.RowTileFilter(feat, L, rank, world, dev, fake, groups=groups)
+                assert job._direct and (job._edge_first if groups is None else (job._fused and not job._edge_first))
                 res = []
                 for s in range(steps):          # no host synchronisation between steps: buffers are reused while work is in flight
                     res.append(job.filter(srcs[s][job.row0 * W:(job.row0 + job.own_rows) * W]))
