@@ -551,6 +551,10 @@ def main():
         out_rt = torch.empty_like(src)
         step = lambda: job.filter(src, out=out_rt)
         build_ms, M, n_local = job.build_ms, job.M, job.n_local
+        # which of the step's (bit-identical) schedules hides most of the REAL exchange is measured, not assumed
+        # (RowTileFilter.autotune; collective); PHL_ROWTILE_MODE pins one instead
+        if world > 1 and not os.environ.get("PHL_ROWTILE_MODE"):
+            job.autotune(src, out_rt)
         extra = job.describe()
     else:
         ref = torch.from_numpy(feat.reshape(-1, d)).to(device)

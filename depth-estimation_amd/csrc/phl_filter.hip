@@ -577,6 +577,24 @@ int phl_launch_slice(const phl_lattice *lat, const float *vert, int vd, float *o
     return PHL_OK;
 }
 
+// Test hook (phl_debug_slow_copy): a copy by a FEW workgroups -- long-running, next to no HBM bandwidth, a handful of wave
+// slots -- the footprint of a point-to-point transfer kernel, for rehearsing how much of an exchange a schedule hides.
+__global__ __launch_bounds__(256) void k_slow_copy(const float4 *__restrict__ src, float4 *__restrict__ dst, int64_t n4, int repeat)
+{
+    for (int r = 0; r < repeat; r++)
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+
+extern "C" int phl_debug_slow_copy(const float *src, float *dst, int64_t n_floats, int workgroups, int repeat, phl_stream stream)
+{
+    if (!src || !dst || n_floats < 0 || n_floats % 4 || workgroups < 1 || repeat < 1) { phl_set_error("phl_debug_slow_copy: bad arguments"); return PHL_ERR_INVALID; }
+    if (n_floats == 0) return PHL_OK;
+    hipLaunchKernelGGL(k_slow_copy, dim3((unsigned)workgroups), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const float4 *>(src),
+                       reinterpret_cast<float4 *>(dst), n_floats / 4, repeat);
+    PHL_HIP(hipGetLastError());
+    return PHL_OK;
+}
+
 int phl_launch_copy2d(const float *src, int64_t srs, int64_t scs, float *dst, int64_t drs, int64_t dcs, int64_t rows,
                       int cols, hipStream_t st)
 {

@@ -430,6 +430,7 @@ class RowTileFilter:
         self.groups = [(g * L // groups, (g + 1) * L // groups) for g in range(groups)]
         self._fused = self._rows_engine and self._direct and (not band.sides or band._map_disjoint) and all((c1 - c0) % 4 == 0 for c0, c1 in self.groups)
         self._plan, self._edge_first = None, False
+        self._mode, self._tuned = os.environ.get("PHL_ROWTILE_MODE", "edge, two queues"), None
         self._stub_exchange = False      # timing probes only: run the step without its point-to-point exchange
         self._vert = self._scratch = self._sbuf = self._ops = self._rshared = None
         if hasattr(band.eng, "reserve"):
@@ -542,8 +543,8 @@ class RowTileFilter:
         if out is None:
             out = torch.empty((self.band.n_local, self.L), dtype=torch.float32, device=self.band.device)
         self._sub = src if subtract_input else None
-        if self._edge_first:
-            return self._filter_edge_first(src, out)
+        if self._edge_first and self._mode != "whole":
+            return self._filter_edge_serial(src, out) if self._mode == "edge, one queue" else self._filter_edge_first(src, out)
         if self._fused:
             return self._filter_fused(src, out)
         pending = []
@@ -565,6 +566,49 @@ class RowTileFilter:
             inbox = {p: pack[slice(*self.band.recv_range(p))] for p in self.band.sides}
             self.band.finish(vert, inbox, out=out[:, c0:c1], sub=None if self._sub is None else self._sub[:, c0:c1])
         return out
+
+    def _filter_edge_serial(self, src, out):
+        """Edge first on ONE queue (round 3's schedule): edge chunks, their rows summed and packed, the exchange handed over,
+        then the interior chunks behind them on the same stream.  The two chunk launches meet at a kernel boundary (one
+        interior band of 8: +30 us against the two-queue form with nothing on the wire), but the boundary rows are certainly
+        ready after the first third of the splat, whatever the hardware's arbitration between two running kernels does."""
+        band, eng, pl, dist = self.band, self.band.eng, self._plan, self.dist
+        vert, sbuf, none = self._vert[0], self._sbuf[0], pl["none"]
+        main = torch.cuda.current_stream(self.device)
+        eng.splat_part(src, vert, pl["partial"], pl["edge"], pl["send_rows"], pack_pos=pl["pack_pos"], pack=sbuf if pl["pack_pos"] is not None else None)
+        if pl["pack_pos"] is None:
+            eng.gather_rows(vert, band._send_all, out=sbuf)
+        reqs = []
+        if self._direct:
+            if self._ops[0] and not self._stub_exchange:
+                reqs = dist.batch_isend_irecv(self._ops[0])
+        else:
+            self._sbuf_h[0].copy_(sbuf, non_blocking=True)
+            self._ev_packed.record(main)
+        eng.splat_part(src, vert, pl["partial"], pl["interior"], pl["other_rows"])
+        if not self._direct:
+            self._ev_packed.synchronize()
+            if self._ops[0] and not self._stub_exchange:
+                reqs = dist.batch_isend_irecv(self._ops[0])
+        for req in reqs:
+            req.wait()
+        self._receive_staged(vert)
+        if band._shared_all.numel():
+            eng.scatter_add_rows(vert, band._shared_all, self._rshared[0])
+        band.blur_slice(vert, out=out, scratch=self._scratch[0], sub=self._sub)
+        return out
+
+    def _receive_staged(self, vert):
+        """host-staged payloads: ghost rows to their place, shared rows next to it (nothing to do with device payloads)"""
+        if self._direct:
+            return
+        band, go = self.band, 0
+        for p in band.peers:
+            s = band.sides[p]
+            if s["n_ghost"]:
+                vert[s["ghost_row0"]:s["ghost_row0"] + s["n_ghost"]].copy_(self._rghost_h[0][go:go + s["n_ghost"]], non_blocking=True)
+            go += s["n_ghost"]
+        self._rshared[0].copy_(self._rshared_h[0], non_blocking=True)
 
     def _filter_edge_first(self, src, out):
         band, eng, pl, dist = self.band, self.band.eng, self._plan, self.dist
@@ -600,14 +644,7 @@ class RowTileFilter:
         for req in reqs:
             req.wait()
         main.wait_stream(side)
-        if not self._direct:                    # host-staged payloads: ghost rows to their place, shared rows next to it
-            go = 0
-            for p in band.peers:
-                s = band.sides[p]
-                if s["n_ghost"]:
-                    vert[s["ghost_row0"]:s["ghost_row0"] + s["n_ghost"]].copy_(self._rghost_h[0][go:go + s["n_ghost"]], non_blocking=True)
-                go += s["n_ghost"]
-            self._rshared[0].copy_(self._rshared_h[0], non_blocking=True)
+        self._receive_staged(vert)
         if band._shared_all.numel():
             eng.scatter_add_rows(vert, band._shared_all, self._rshared[0])
         band.blur_slice(vert, out=out, scratch=self._scratch[0], sub=self._sub)
@@ -627,6 +664,44 @@ class RowTileFilter:
                 band.eng.scatter_add_rows(self._vert[gi], band._shared_all, self._rshared[gi])
             band.blur_slice(self._vert[gi], out=out[:, c0:c1], scratch=self._scratch[gi], sub=None if self._sub is None else self._sub[:, c0:c1])
         return out
+
+    MODES = ("edge, two queues", "edge, one queue", "whole")
+
+    def autotune(self, src, out, reps=6):
+        """Pick the step's schedule by MEASUREMENT, with the real exchange (collective: every rank must call it).  How much
+        of the exchange a schedule hides depends on things this code cannot know in advance -- how the hardware arbitrates
+        two concurrently running kernels, which hardware queue the communication library's stream shares, how long the wire
+        takes -- so the three forms that give bit-identical results are each timed over `reps` steps (barrier, MAX over the
+        ranks) and the fastest is kept:
+          "edge, two queues"   edge chunks on a high-priority side stream beside the interior chunks (fastest with nothing on
+                               the wire: no kernel boundary inside the splat);
+          "edge, one queue"    edge chunks, then the interior chunks behind them (boundary rows certainly ready after a third
+                               of the splat);
+          "whole"              the whole splat, then the exchange (nothing hidden, no split at all).
+        Returns {mode: ms}; the choice is in describe()."""
+        if not self._edge_first:
+            return None
+        dist, dev = self.dist, self.band.device
+        modes = [m for m in self.MODES if m != "whole" or self._fused]
+        res = {}
+        for m in modes:
+            self._mode = m
+            for _ in range(2):
+                self.filter(src, out=out)
+            if dev.type == "cuda":
+                torch.cuda.synchronize(dev)
+            dist.barrier()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                self.filter(src, out=out)
+            if dev.type == "cuda":
+                torch.cuda.synchronize(dev)
+            dt = torch.tensor([(time.perf_counter() - t0) / reps * 1e3], dtype=torch.float64, device=dev if self._direct else "cpu")
+            dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+            res[m] = round(float(dt.item()), 4)
+        self._mode = min(res, key=res.get)          # (the same on every rank: the times were reduced over the ranks)
+        self._tuned = res
+        return res
 
     def exchange_probe(self, src, out, reps=10):
         """Where the exchange stands in a step, measured on this rank (wall clock around synchronised loops, so it
@@ -693,9 +768,10 @@ class RowTileFilter:
                             "ghost_rows_received_in_place": {str(p): b.sides[p]["n_ghost"] for p in b.sides},
                             "blur_rows_per_axis": blur,
                             "channel_groups": len(self.groups),
-                            "schedule": (("edge chunks first, exchange under the interior splat"
+                            "schedule": ((("edge chunks first, exchange under the interior splat" if self._mode != "whole" else "whole splat, then the exchange")
                                           + ("" if self._direct else " (payloads staged through pinned host memory)"))
                                          if self._edge_first else ("channel groups pipelined" if self._fused else "plain")),
+                            "mode": self._mode if self._edge_first else None, "autotune_ms": self._tuned,
                             "edge_chunks": int(self._plan["edge"].numel()) if self._plan else None,
                             "exchange_bytes_per_step_per_rank": int(sum(rows.values()) * self.L * 4 * 2)}}
 

@@ -334,6 +334,10 @@ int phl_debug_probe_paths(const int16_t *keys_clean, int64_t n_clean, int d, con
                           const int32_t *stale_clean, int n_stale, uint64_t cap, const int32_t *check, int n_check,
                           int on_device, int *result_out);
 
+/* Test hook: dst <- src (n_floats % 4 == 0, 16-byte aligned) copied `repeat` times by `workgroups` workgroups of 256 threads:
+ * a long-running kernel with the footprint of a point-to-point transfer (a few wave slots, next to no HBM bandwidth), for
+ * rehearsing on one GPU how much of an exchange of a given duration a schedule hides (tools/band_time.py wire variants). */
+int phl_debug_slow_copy(const float *src_dev, float *dst_dev, int64_t n_floats, int workgroups, int repeat, phl_stream stream);
 /* Test hook: side streams the calling thread holds for the reference-table build (one per device the thread has
  * built such a lattice on; building on devices A, B, A, B ... must not create more than two). */
 int phl_debug_side_streams(void);

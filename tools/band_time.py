@@ -50,16 +50,27 @@ for v in variants:
     env = {"noblurrows": {"PHL_ROWTILE_BLUR_ROWS": "0"}, "groups1": {"PHL_ROWTILE_EDGE_FIRST": "0"}, "groups2": {"PHL_ROWTILE_EDGE_FIRST": "0"}}.get(v, {})
     os.environ.update(env)
     kw = {"groups": 2} if v == "groups2" else ({"groups": 1} if v == "groups1" else {})
-    jobs, fake = build_jobs(feat, L, world, dev, want_ranks=[rank], backend="gloo" if v == "staged" else "nccl", **kw)
+    if v.startswith("wire"):             # the default schedule with an exchange that takes <n> microseconds on the wire
+        from loopback_dist import WireDist
+        from phl import rowtile
+
+        wg, rep = (int(x) for x in v[4:].split("x"))
+        fake = WireDist(world, wg, rep)
+        fake.local.rank = rank
+        jobs = {rank: rowtile.RowTileFilter(feat, L, rank, world, dev, fake)}
+    else:
+        jobs, fake = build_jobs(feat, L, world, dev, want_ranks=[rank], backend="gloo" if v == "staged" else "nccl", **kw)
     for k in env:
         del os.environ[k]
     job = jobs[rank]
     b = job.band
     src = bench.synthetic_values(torch, b.own_rows, W, L, b.row0, dev)
     out = torch.empty_like(src)
-    job._stub_exchange = True
+    job._stub_exchange = not v.startswith("wire")
     g, h = gpu_ms(lambda: job.filter(src, out=out))
     d = job.describe()["rowtile"]
+    if v.startswith("wire"):
+        print(f"{v:11s}: the exchange alone ({wg} workgroups x {rep} passes over the receive buffers): {fake.wire_ms * 1e3:.0f} us", flush=True)
     print(f"{v:11s}: gpu {g:.4f} ms/step, host issue {h:.3f} ms; schedule '{d['schedule']}', M {d['M_local_plus_ghosts']} "
           f"(own {d['M_own']}), blur rows per axis {d['blur_rows_per_axis']}, edge chunks {d['edge_chunks']}", flush=True)
     results[v] = g
