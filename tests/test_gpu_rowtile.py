@@ -427,7 +427,7 @@ def test_band_schedules_agree_bit_for_bit(world, H, W, L, sigma, monkeypatch):
     for r in range(world):
         assert torch.equal(new[r], mid[r]), f"rank {r}: restricted blur differs"
     monkeypatch.delenv("PHL_ROWTILE_BLUR_ROWS")
-    for mode in ("edge, one queue", "whole"):              # the other two forms RowTileFilter.autotune chooses between
+    for mode in ("edge, two queues", "whole"):             # the other two forms RowTileFilter.autotune chooses between
         monkeypatch.setenv("PHL_ROWTILE_MODE", mode)
         alt, jobs_alt = _run_ranks(feat, src, L, world, dev)
         assert jobs_alt[0]._mode == mode
