@@ -552,6 +552,9 @@ __global__ __launch_bounds__(512) void k_compat_softmax(const float *__restrict_
             }
         }
         if (kc == NT - 1) softmax_in_place();
+        // the DMAs this wave issued in the last slot of its epilogue half are what slot 1 of this half reads: they had this
+        // whole slot to land, now make it certain (nothing else of this wave is in flight; in later slots: nothing at all)
+        dma_drain();                             // (in every slot: a branch here upsets the compiler's own wait placement)
         CS_ARRIVE(kc);
         asm volatile("" ::: "memory");           // LDS reads of this slot stay on this side of the barrier
         __builtin_amdgcn_s_barrier();
@@ -639,6 +642,404 @@ __global__ __launch_bounds__(512) void k_compat_softmax(const float *__restrict_
 }
 #undef PHL_E0_LOAD_UNIT
 #undef PHL_WAIT_BUT
+
+// ------------------------------------------------------------------------------------------------------------
+// k_compat_split: the same fused step for L in (224, 256] on the bf16 matrix cores (v_mfma_f32_16x16x32_bf16, sixteen
+// times the f32 rate), with BOTH operands split into three bf16 addends -- x = h + m + l, eight significant bits each,
+// by truncation: the split is exact, h + m + l == x bit for bit -- and the six products that matter:
+//     x mu  =  hH + hM + mH + hL + lH + mM   ( + mL + lM + lL  <=  2^-23 |x mu|, dropped )
+// Every partial product of two bf16 numbers is exact in f32 and the matrix core accumulates in f32, so the result
+// carries the error of an f32 dot product (measured against float64 next to the f32-MFMA kernel: tests and
+// tools/compat_time.py), at 6/16 x 1/2 = 3/8 of its matrix time: the kernel becomes what the step is by its bytes,
+// a streaming pass over E0, X and Q.
+//
+// Same skeleton as k_compat_softmax (two wave groups in anti-phase, the group in its epilogue half feeds the one on the
+// matrix cores through LDS rings, every slot ends in the workgroup barrier; transposed product, 16x16 tiles, softmax on
+// the accumulators) with these differences:
+//  * the compatibility matrix arrives PREPARED (k_compat_planes): three bf16 planes in exactly the order the matrix
+//    cores read them.  A slot is (K chunk of 32, label half): its piece of the planes is 128 labels x 32 k x 3 planes
+//    = 24 KiB, [label tile][plane][lane] x 16 B -- a DMA piece is 64 consecutive 16-byte units, an operand read is
+//    lane-linear (no swizzle, no bank conflict).  16 slots per half; pieces are requested THREE slots ahead into a ring
+//    of four (96 KiB), X chunks (f32, 16 KiB, as before) four slots = two chunks ahead into a ring of three: the slots are
+//    a fifth as long as the f32 kernel's, the latency to cover is the same.
+//  * the waves on the matrix cores split their X operands themselves (8 values a lane and pixel group per chunk:
+//    and / sub / and / sub + three byte permutes per pair), once per chunk, kept across the chunk's two slots.
+//  * row traffic (Q stores, next E0 loads) runs in the first EPI_D slots of the epilogue half, so that the E0 values
+//    have the remaining slots to land before the matrix cores take them as C input.
+//  * a wave that goes from its epilogue half to the matrix cores still has the DMAs of its last two slots in flight
+//    (they feed slots 1 and 2 of the half it enters): counted waits at the end of its first two slots there.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// two f32 -> the packed bf16 pairs of their three addends (truncation: top 8 significant bits, the next 8, the last 8)
+__device__ __forceinline__ void split3(float x0, float x1, unsigned &h, unsigned &m, unsigned &l)
+{
+    const unsigned b0 = __float_as_uint(x0), b1 = __float_as_uint(x1);
+    const float r0 = x0 - __uint_as_float(b0 & 0xFFFF0000u), r1 = x1 - __uint_as_float(b1 & 0xFFFF0000u);
+    const unsigned c0 = __float_as_uint(r0), c1 = __float_as_uint(r1);
+    const float s0 = r0 - __uint_as_float(c0 & 0xFFFF0000u), s1 = r1 - __uint_as_float(c1 & 0xFFFF0000u);
+    h = __builtin_amdgcn_perm(b1, b0, 0x07060302u);        // {hi16(x1), hi16(x0)}
+    m = __builtin_amdgcn_perm(c1, c0, 0x07060302u);
+    l = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302u);
+}
+
+constexpr int CSP_PIECE = 24576;                 // bytes of one slot's piece of the planes
+constexpr int CSP_PLANES_BYTES = 16 * CSP_PIECE; // 16 pieces: (K chunk 0..7) x (label half 0..1)
+
+// MuT [256][256] f32 (zero beyond the real label count) -> planes: piece (kc, hf), label tile Tl of the half, plane P,
+// lane (i, g): eight bf16 = plane P of MuT[16 (8 hf + Tl) + i][32 kc + 8 g .. + 7]
+__global__ __launch_bounds__(256) void k_compat_planes(const float *__restrict__ MuT, u32x4 *__restrict__ planes)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x;           // one thread per (piece, Tl, lane): 16 * 8 * 64
+    if (t >= 16 * 8 * 64) return;
+    const int lane = t & 63, Tl = (t >> 6) & 7, piece = t >> 9, kc = piece >> 1, hf = piece & 1;
+    const float *src = MuT + (size_t)(16 * (8 * hf + Tl) + (lane & 15)) * 256 + 32 * kc + 8 * (lane >> 4);
+    u32x4 h, m, l;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        unsigned a, b, c;
+        split3(src[2 * j], src[2 * j + 1], a, b, c);
+        h[j] = a; m[j] = b; l[j] = c;
+    }
+    u32x4 *dst = planes + (size_t)piece * (CSP_PIECE / 16) + (size_t)Tl * 3 * 64 + lane;
+    dst[0] = h;
+    dst[64] = m;
+    dst[128] = l;
+}
+
+template <bool LOGITS, bool PAD>
+__global__ __launch_bounds__(512) void k_compat_split(const float *__restrict__ E0, int64_t e_rs,
+                                                      const float *__restrict__ X, int64_t x_rs,
+                                                      const unsigned char *__restrict__ planes, float *__restrict__ out,
+                                                      int64_t o_rs, int64_t n, int Lr)
+{
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    constexpr int NT = 8, NL = 16, NS = 16;        // K chunks, label tiles of 16, slots per half
+    constexpr int X_FLOATS = 4 * 1024;            // one chunk of the tile's X: 4 waves x [32 pixels][32 k]
+    constexpr int X_BASE = 4 * CSP_PIECE;         // bytes: the X ring [3][X_FLOATS] sits behind the ring of four pieces
+    constexpr int EPI_D = 10;                     // epilogue slots that move rows
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int grp = wave >> 2, w4 = wave & 3;
+    const int i = lane & 15, g4 = lane >> 4;
+    const int64_t ntiles = n / 128;
+    const int64_t G2 = 2 * (int64_t)gridDim.x;
+    const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float *)lds;
+    const char *ldsb = reinterpret_cast<const char *>(lds);
+
+    // X feed: as in k_compat_softmax (rows of 128 B, 16-byte slots XOR-swizzled by (row >> 1) & 7)
+    const int part0 = (lane & 7) ^ (lane >> 4), part1 = (lane & 7) ^ (4 + (lane >> 4));
+    const unsigned xvoff0 = (unsigned)((lane >> 3) * x_rs + 4 * part0) * 4u, xvoff1 = (unsigned)((lane >> 3) * x_rs + 4 * part1) * 4u;
+    const unsigned mvoff = (unsigned)lane * 16u;
+    const int64_t b2 = 2 * (int64_t)blockIdx.x;
+    // feed(s, ph, xb): the requests of slot S = 16 ph + s (s >= -4 before the first slot): the piece of the planes for
+    // slot S + 3 and, in even slots, the X chunk of slots S + 4 and S + 5 into X buffer xb = ((S + 4) >> 1) % 3.
+    // Returns whether X pieces were issued (the consuming group may have run out of tiles).
+    auto feed = [&](auto sc, int ph, int xb) -> bool {
+        constexpr int s = decltype(sc)::value;
+        if constexpr (s + 3 >= 0) {
+            constexpr int t = s + 3;
+            const unsigned char *src = planes + (size_t)(t & 15) * CSP_PIECE + (size_t)w4 * 6 * 1024;
+            const unsigned dst = lds_base + (t & 3) * CSP_PIECE + w4 * 6 * 1024;
+#pragma unroll
+            for (int r = 0; r < 6; r++) glds16(reinterpret_cast<const float *>(src + r * 1024), mvoff, dst + r * 1024);
+        }
+        bool ok = false;
+        if constexpr (s + 4 >= 0 && (s & 1) == 0) {
+            constexpr int t = s + 4;
+            const int php = ph + (t >= NS ? 1 : 0);
+            constexpr int kc = (t & 15) >> 1;
+            const int64_t tile = (php & 1) ? b2 + 1 + (int64_t)((php - 1) >> 1) * G2 : b2 + (int64_t)(php >> 1) * G2;
+            ok = tile < ntiles;
+            if (ok) {
+                const float *xw = X + (tile * 128 + w4 * 32) * x_rs;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    unsigned vo = (j & 1) ? xvoff1 : xvoff0;
+                    if (PAD && kc == NT - 1)
+                        vo = (unsigned)((lane >> 3) * x_rs + min(4 * ((j & 1) ? part1 : part0), Lr - 4 - 32 * kc)) * 4u;
+                    glds16(xw + (int64_t)8 * j * x_rs + 32 * kc, vo, lds_base + X_BASE + (xb * X_FLOATS + w4 * 1024 + j * 256) * 4);
+                }
+            }
+        }
+        asm volatile("" ::: "memory");
+        return ok;
+    };
+#define PHL_VMCNT(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((N) < 63 ? (N) : 63) : "memory")
+
+    const unsigned lo_e = (unsigned)(i * e_rs + 4 * g4) * 4u, lo_o = (unsigned)(i * o_rs + 4 * g4) * 4u;
+#define PHL_E0_LOAD_UNIT(pg, T, wave_rows)                                                                                \
+    do {                                                                                                                  \
+        const char *p_ = reinterpret_cast<const char *>((wave_rows) + (pg) * 16 * e_rs + 16 * (T));                       \
+        unsigned lo_ = lo_e;                                                                                              \
+        if (PAD && (T) >= NL - 2) {                                                                                       \
+            p_ = reinterpret_cast<const char *>((wave_rows) + (pg) * 16 * e_rs);                                          \
+            lo_ = (unsigned)(i * e_rs + min(16 * (T) + 4 * g4, Lr - 4)) * 4u;                                             \
+        }                                                                                                                 \
+        const float4 v_ = *reinterpret_cast<const float4 *>(p_ + lo_);                                                    \
+        acc[pg][T] = f32x4{v_.x, v_.y, v_.z, v_.w};                                                                       \
+    } while (0)
+
+    // The same load, invisible to the compiler's wait counting (inline assembly): the loads of the NEXT tile's E0 go
+    // straight into the accumulators in the first EPI_D slots of an epilogue half, and a compiler-made wait for them
+    // would also drain the DMA pieces issued behind them (it cannot count those) -- a stalled slot per half.  The wait is
+    // ours: a counted one at the start of the matrix-core half.
+#define PHL_E0_LOAD_HIDDEN(pg, T, wave_rows)                                                                              \
+    do {                                                                                                                  \
+        const float *p_ = (wave_rows) + (pg) * 16 * e_rs + 16 * (T);                                                      \
+        unsigned lo_ = lo_e;                                                                                              \
+        if (PAD && (T) >= NL - 2) {                                                                                       \
+            p_ = (wave_rows) + (pg) * 16 * e_rs;                                                                          \
+            lo_ = (unsigned)(i * e_rs + min(16 * (T) + 4 * g4, Lr - 4)) * 4u;                                             \
+        }                                                                                                                 \
+        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(acc[pg][T]) : "v"(lo_), "s"(p_) : "memory");                 \
+    } while (0)
+
+    const int64_t iters = (ntiles - 2 * (int64_t)blockIdx.x + G2 - 1) / G2;
+    int64_t tile = 2 * (int64_t)blockIdx.x + grp;
+    bool valid = tile < ntiles;
+    f32x4 acc[2][NL];
+    auto pad_e0 = [&]() {
+        if (PAD) {
+#pragma unroll
+            for (int T = NL - 2; T < NL; T++)
+                if (16 * T + 4 * g4 >= Lr) {
+                    acc[0][T] = f32x4{INFINITY, INFINITY, INFINITY, INFINITY};
+                    acc[1][T] = acc[0][T];
+                }
+        }
+    };
+    if (valid) {
+#pragma unroll
+        for (int pg = 0; pg < 2; pg++)
+#pragma unroll
+            for (int T = 0; T < NL; T++) PHL_E0_LOAD_UNIT(pg, T, E0 + (tile * 128 + w4 * 32) * e_rs);
+    }
+#ifdef __HIP_DEVICE_COMPILE__
+    asm volatile("" ::"v"(acc[1][NL - 1]));
+#endif
+    int ph = 0, x3 = 0;                            // half index of the current slot, (slot >> 1) % 3
+    auto next_chunk = [&]() { x3 = x3 == 2 ? 0 : x3 + 1; };
+    if (grp == 1) {
+        // group 0's first half is fed by group 1: first what its slots 0..3 need, then slot by slot
+        feed(std::integral_constant<int, -4>(), 0, 0);
+        feed(std::integral_constant<int, -3>(), 0, 0);
+        feed(std::integral_constant<int, -2>(), 0, 1);
+        feed(std::integral_constant<int, -1>(), 0, 0);
+        dma_drain();
+        __builtin_amdgcn_s_barrier();
+        bool xe = false;
+        static_for<NS>([&](auto sc) {
+            constexpr int s = decltype(sc)::value;
+            const bool xp = feed(sc, 0, x3 == 0 ? 2 : x3 - 1);
+            if ((s & 1) == 0) xe = xp;
+            // what slot s + 1 reads was requested in slot s - 2: the requests of slots s - 1 and s may stay in flight
+            if (xe) PHL_VMCNT((s >= 1 ? 6 : 0) + 6 + 4);
+            else PHL_VMCNT((s >= 1 ? 6 : 0) + 6);
+            __builtin_amdgcn_s_barrier();
+            if (s & 1) next_chunk();
+        });
+        ph = 1;
+    } else {
+        __builtin_amdgcn_s_barrier();
+    }
+
+    auto softmax_in_place = [&]() {
+    if (valid && !LOGITS) {
+#pragma unroll
+        for (int pg = 0; pg < 2; pg++) {
+            float m = acc[pg][0][0];
+            m = vmin3(m, acc[pg][0][1], acc[pg][0][2]);
+#pragma unroll
+            for (int T = 1; T < NL; T++) {
+                m = vmin3(m, acc[pg][T][0], acc[pg][T][1]);
+                m = vmin3(m, acc[pg][T][2], acc[pg][T][3]);
+            }
+            m = vmin3(m, acc[pg][0][3], acc[pg][0][3]);
+            {
+                float ma = m, mb = m;
+                PHL_ROW_SWAP(ma, mb);
+                m = vmin3(ma, mb, mb);
+                ma = m; mb = m;
+                PHL_HALF_SWAP(ma, mb);
+                m = vmin3(ma, mb, mb) * 1.4426950408889634f;
+            }
+            f32x4 vs = 0.f;
+#pragma unroll
+            for (int T = 0; T < NL; T++) {
+                acc[pg][T] = __builtin_elementwise_fma(acc[pg][T], (f32x4)(-1.4426950408889634f), (f32x4)m);
+#pragma unroll
+                for (int r = 0; r < 4; r++) acc[pg][T][r] = __builtin_amdgcn_exp2f(acc[pg][T][r]);
+                vs += acc[pg][T];
+            }
+            float sum = (vs[0] + vs[1]) + (vs[2] + vs[3]);
+            {
+                float sa = sum, sb = sum;
+                PHL_ROW_SWAP(sa, sb);
+                sum = sa + sb;
+                sa = sum; sb = sum;
+                PHL_HALF_SWAP(sa, sb);
+                sum = sa + sb;
+            }
+            const float inv = __builtin_amdgcn_rcpf(sum);
+#pragma unroll
+            for (int T = 0; T < NL; T++) acc[pg][T] *= inv;
+        }
+    } else if (valid) {
+#pragma unroll
+        for (int pg = 0; pg < 2; pg++)
+#pragma unroll
+            for (int T = 0; T < NL; T++) acc[pg][T] = -acc[pg][T];
+    }
+    };
+
+    // operand addresses: the planes of label tile Tl of the slot's piece at (3 Tl + P) KiB + lane * 16; the lane's X values
+    // are k-parts 2 g4 and 2 g4 + 1 of row 16 pg + i
+    const int sw = (i >> 1) & 7;
+    const char *a_lane = ldsb + lane * 16;
+    const float *x_lane0 = lds + X_BASE / 4 + w4 * 1024 + i * 32 + ((2 * g4) ^ sw) * 4;
+    const float *x_lane1 = lds + X_BASE / 4 + w4 * 1024 + i * 32 + ((2 * g4 + 1) ^ sw) * 4;
+    u32x4 xh[2], xm[2], xl[2];                     // the chunk's X operands: [pixel group], split
+    bool x_late = true;                            // the X feeds behind the last E0 load of an epilogue half were all issued
+
+    for (int64_t it = 0; it < iters; it++) {
+        // =========== matrix-core half ===========================================================================
+        // the tile's E0 (hidden loads of the epilogue's first EPI_D slots) has landed when at most the DMAs of the slots
+        // behind them are in flight: six pieces of the planes a slot, four X pieces in the even ones if they were issued
+        {
+            constexpr int LATE = NS - EPI_D, LATE_EVEN = NS / 2 - (EPI_D + 1) / 2;     // slots EPI_D .. NS-1, the even ones among them
+            if (it > 0) {
+                if (x_late) PHL_VMCNT(6 * LATE + 4 * LATE_EVEN);
+                else PHL_VMCNT(6 * LATE);
+            }
+        }
+#ifdef __HIP_DEVICE_COMPILE__
+#pragma unroll
+        for (int T = 0; T < NL; T++) asm volatile("" : "+v"(acc[0][T]), "+v"(acc[1][T]));
+#endif
+        pad_e0();
+        static_for<NS>([&](auto sc) {
+            constexpr int s = decltype(sc)::value, kc = s >> 1, hf = s & 1;
+            if (valid) {
+                const char *ab = a_lane + (s & 3) * CSP_PIECE;
+                constexpr int TB = 2, STEPS = 8 / TB;
+                u32x4 pa[2][TB][3];
+                auto read_a = [&](int st, u32x4 (&dst)[TB][3]) {
+#pragma unroll
+                    for (int j = 0; j < TB; j++)
+#pragma unroll
+                        for (int P = 0; P < 3; P++)
+                            dst[j][P] = *reinterpret_cast<const u32x4 *>(ab + ((st * TB + j) * 3 + P) * 1024);
+                };
+                read_a(0, pa[0]);
+                if (hf == 0) {
+#pragma unroll
+                    for (int pg = 0; pg < 2; pg++) {
+                        float4 v0 = *reinterpret_cast<const float4 *>(x_lane0 + x3 * X_FLOATS + pg * 16 * 32);
+                        float4 v1 = *reinterpret_cast<const float4 *>(x_lane1 + x3 * X_FLOATS + pg * 16 * 32);
+                        if (PAD && kc == NT - 1) {
+                            if (32 * kc + 8 * g4 >= Lr) v0 = make_float4(0.f, 0.f, 0.f, 0.f);
+                            if (32 * kc + 8 * g4 + 4 >= Lr) v1 = make_float4(0.f, 0.f, 0.f, 0.f);
+                        }
+                        unsigned h_[4], m_[4], l_[4];
+                        split3(v0.x, v0.y, h_[0], m_[0], l_[0]);
+                        split3(v0.z, v0.w, h_[1], m_[1], l_[1]);
+                        split3(v1.x, v1.y, h_[2], m_[2], l_[2]);
+                        split3(v1.z, v1.w, h_[3], m_[3], l_[3]);
+                        xh[pg] = u32x4{h_[0], h_[1], h_[2], h_[3]};
+                        xm[pg] = u32x4{m_[0], m_[1], m_[2], m_[3]};
+                        xl[pg] = u32x4{l_[0], l_[1], l_[2], l_[3]};
+                    }
+                }
+#pragma unroll
+                for (int st = 0; st < STEPS; st++) {
+                    if (st + 1 < STEPS) read_a(st + 1, pa[(st + 1) & 1]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    u32x4(&pc)[TB][3] = pa[st & 1];
+#define PHL_MFB(P, xop)                                                                                                   \
+    _Pragma("unroll") for (int j = 0; j < TB; j++) {                                                                      \
+        acc[0][8 * hf + st * TB + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                                           \
+            __builtin_bit_cast(bf16x8, pc[j][P]), __builtin_bit_cast(bf16x8, xop[0]), acc[0][8 * hf + st * TB + j], 0, 0, 0); \
+        acc[1][8 * hf + st * TB + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                                           \
+            __builtin_bit_cast(bf16x8, pc[j][P]), __builtin_bit_cast(bf16x8, xop[1]), acc[1][8 * hf + st * TB + j], 0, 0, 0); \
+    }
+                    // smallest terms first: L h, M m, H l, M h, H m, H h
+                    PHL_MFB(2, xh) PHL_MFB(1, xm) PHL_MFB(0, xl) PHL_MFB(1, xh) PHL_MFB(0, xm) PHL_MFB(0, xh)
+#undef PHL_MFB
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            if (s == NS - 1) softmax_in_place();
+            // this wave's requests from the last two slots of its epilogue half feed slots 1 and 2 of this half
+            if (s == 0) PHL_VMCNT(6);
+            if (s == 1) PHL_VMCNT(0);
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (s & 1) next_chunk();
+        });
+        ph++;
+        // =========== epilogue half: stores of `tile`, E0 of the next tile, loader duty =============================
+        {
+            const int64_t nxt = tile + G2;
+            const bool has_next = nxt < ntiles;
+            float *orows = out + (tile * 128 + w4 * 32) * o_rs;
+            const float *erows = E0 + ((has_next ? nxt : tile) * 128 + w4 * 32) * e_rs;
+            bool xe = false;
+            x_late = true;
+            static_for<NS>([&](auto sc) {
+                constexpr int s = decltype(sc)::value;
+                __builtin_amdgcn_s_sleep(2);
+                const bool xp = feed(sc, ph, x3 == 0 ? 2 : x3 - 1);
+                if ((s & 1) == 0) xe = xp;
+                if (s >= EPI_D && (s & 1) == 0) x_late = x_late && xp;
+                constexpr int U = 4 * NT, D = EPI_D;
+                constexpr int u_lo = s < D ? (U * s + D - 1) / D : U, u_hi = s + 1 < D ? (U * (s + 1) + D - 1) / D : U;
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    if (u < u_lo || u >= u_hi) continue;
+                    const int pg = u / NL, T = u % NL;
+                    if (valid && (!PAD || T < NL - 2 || 16 * T + 4 * g4 < Lr))
+                        *reinterpret_cast<float4 *>(reinterpret_cast<char *>(orows + pg * 16 * o_rs + 16 * T) + lo_o) =
+                            make_float4(acc[pg][T][0], acc[pg][T][1], acc[pg][T][2], acc[pg][T][3]);
+                    if (has_next) PHL_E0_LOAD_HIDDEN(pg, T, erows);
+                }
+                // What slot s + 1 reads was requested in slot s - 2 or earlier.  vmcnt counts in issue order, so what this
+                // wave issued behind the DMAs of slot s - 2 may stay in flight: the units of slot s - 2, the DMAs and units
+                // of slots s - 1 and s.  (Under PAD a store may be skipped: none is counted -- waiting for fewer is safe.)
+                constexpr int un0 = s < D ? u_hi - u_lo : 0;
+                constexpr int un1 = (s >= 1 && s - 1 < D) ? ((s < D ? (U * s + D - 1) / D : U) - (U * (s - 1) + D - 1) / D) : 0;
+                constexpr int un2 = (s >= 2 && s - 2 < D) ? ((s - 1 < D ? (U * (s - 1) + D - 1) / D : U) - (U * (s - 2) + D - 1) / D) : 0;
+                constexpr int UN = un0 + un1 + un2;
+                constexpr int DM = 6 + (s >= 1 ? 6 : 0);
+                constexpr int ST = PAD ? 0 : UN;
+                if (xe) {
+                    if (valid && has_next) PHL_VMCNT(DM + 4 + UN + ST);
+                    else if (has_next) PHL_VMCNT(DM + 4 + UN);
+                    else if (valid) PHL_VMCNT(DM + 4 + ST);
+                    else PHL_VMCNT(DM + 4);
+                } else {
+                    if (valid && has_next) PHL_VMCNT(DM + UN + ST);
+                    else if (has_next) PHL_VMCNT(DM + UN);
+                    else if (valid) PHL_VMCNT(DM + ST);
+                    else PHL_VMCNT(DM);
+                }
+                __builtin_amdgcn_s_barrier();
+                if (s & 1) next_chunk();
+            });
+            ph++;
+            tile = nxt;
+            valid = has_next;
+        }
+    }
+    if (grp == 0) {
+        for (int s = 0; s < NS; s++) __builtin_amdgcn_s_barrier();
+    }
+    dma_drain();
+}
+#undef PHL_E0_LOAD_UNIT
+#undef PHL_E0_LOAD_HIDDEN
+#undef PHL_VMCNT
 #undef PHL_ROW_SWAP
 
 // The last n % 128 pixels of phl_compat_softmax (the tile kernel takes whole tiles only): one workgroup per pixel,
@@ -803,6 +1204,65 @@ int phl_compat_softmax(const float *E0, int64_t e_rs, const float *X, int64_t x_
     }
 #undef PHL_CS
 #undef PHL_CS_LAUNCH
+    PHL_HIP(hipGetLastError());
+    return PHL_OK;
+}
+
+size_t phl_compat_planes_bytes(int L)
+{
+    return (L > 224 && L <= 256 && L % 4 == 0) ? (size_t)CSP_PLANES_BYTES : 0;
+}
+
+int phl_compat_prepare(const float *MuT, int L, void *planes, phl_stream stream)
+{
+    if (!phl_compat_planes_bytes(L)) { phl_set_error("phl_compat_prepare: the split kernel takes 224 < L <= 256, L %% 4 == 0 (L=%d)", L); return PHL_ERR_UNSUPPORTED; }
+    if (!MuT || !planes || ((reinterpret_cast<uintptr_t>(MuT) | reinterpret_cast<uintptr_t>(planes)) & 15)) { phl_set_error("phl_compat_prepare: bad arguments"); return PHL_ERR_INVALID; }
+    k_compat_planes<<<dim3(16 * 8 * 64 / 256), dim3(256), 0, (hipStream_t)stream>>>(MuT, reinterpret_cast<u32x4 *>(planes));
+    PHL_HIP(hipGetLastError());
+    return PHL_OK;
+}
+
+int phl_compat_softmax_split(const float *E0, int64_t e_rs, const float *X, int64_t x_rs, const float *MuT, const void *planes,
+                             float *out, int64_t o_rs, int64_t n, int L, unsigned flags, phl_stream stream)
+{
+    if (n < 0 || L < 1 || (n > 0 && (!E0 || !X || !MuT || !planes || !out))) { phl_set_error("phl_compat_softmax_split: bad arguments"); return PHL_ERR_INVALID; }
+    if (n == 0) return PHL_OK;
+    if (!phl_compat_planes_bytes(L) || x_rs % 4 || e_rs % 4 || o_rs % 4 || x_rs >= (1 << 24) || e_rs >= (1 << 24) || o_rs >= (1 << 24) ||
+        ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(MuT) | reinterpret_cast<uintptr_t>(planes) | reinterpret_cast<uintptr_t>(E0) |
+          reinterpret_cast<uintptr_t>(out)) & 15)) {
+        phl_set_error("phl_compat_softmax_split: needs 224 < L <= 256, L %% 4 == 0 and 16-byte aligned E0 / X / out rows (L=%d)", L);
+        return PHL_ERR_UNSUPPORTED;
+    }
+    const bool pad = L != 256;
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t n_main = n / 128 * 128, npairs = (n / 128 + 1) / 2;
+    const unsigned grid = (unsigned)(npairs < 256 ? npairs : 256);
+    const size_t lds = (size_t)4 * CSP_PIECE + 3 * 4 * 1024 * sizeof(float);     // ring of four pieces + X ring: 144 KiB
+    const bool logits = (flags & PHL_COMPAT_LOGITS) != 0;
+    int dev = 0;
+    PHL_HIP(hipGetDevice(&dev));
+#define PHL_CSP_LAUNCH(LG_, PD_)                                                                                          \
+    do {                                                                                                                  \
+        static std::atomic<unsigned long long> ready{0};                                                                  \
+        const unsigned long long bit = 1ull << (dev & 63);                                                                \
+        if (!(ready.load(std::memory_order_acquire) & bit)) {                                                             \
+            PHL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_compat_split<LG_, PD_>),                        \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                           \
+            ready.fetch_or(bit, std::memory_order_release);                                                               \
+        }                                                                                                                 \
+        k_compat_split<LG_, PD_><<<dim3(grid), dim3(512), lds, st>>>(E0, e_rs, X, x_rs, reinterpret_cast<const unsigned char *>(planes), out, o_rs, n, L); \
+    } while (0)
+    if (n_main > 0) {
+        if (logits && pad) PHL_CSP_LAUNCH(true, true);
+        else if (logits) PHL_CSP_LAUNCH(true, false);
+        else if (pad) PHL_CSP_LAUNCH(false, true);
+        else PHL_CSP_LAUNCH(false, false);
+    }
+#undef PHL_CSP_LAUNCH
+    if (n > n_main) {        // the last n % 128 pixels: the f32 chain of the other kernel's tail (at most 127 rows)
+        if (logits) k_compat_tail<true><<<dim3((unsigned)(n - n_main)), dim3(256), 0, st>>>(E0, e_rs, X, x_rs, MuT, 256, out, o_rs, n_main, L);
+        else k_compat_tail<false><<<dim3((unsigned)(n - n_main)), dim3(256), 0, st>>>(E0, e_rs, X, x_rs, MuT, 256, out, o_rs, n_main, L);
+    }
     PHL_HIP(hipGetLastError());
     return PHL_OK;
 }

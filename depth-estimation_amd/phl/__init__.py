@@ -96,6 +96,11 @@ def load_library():
         lib.phl_expected_value.argtypes = [vp, i64, vp, vp, i64, i32, vp]
         lib.phl_compat_softmax.argtypes = [vp, i64, vp, i64, vp, vp, i64, i64, i32, u32, vp]
         lib.phl_uniform_compat_softmax.argtypes = [vp, i64, vp, i64, C.c_float, C.c_float, vp, i64, i64, i32, u32, vp]
+        if hasattr(lib, "phl_compat_softmax_split"):
+            lib.phl_compat_planes_bytes.argtypes = [i32]
+            lib.phl_compat_planes_bytes.restype = C.c_size_t
+            lib.phl_compat_prepare.argtypes = [vp, i32, vp, vp]
+            lib.phl_compat_softmax_split.argtypes = [vp, i64, vp, i64, vp, vp, vp, i64, i64, i32, u32, vp]
         lib.phl_stream_copy.argtypes = [vp, vp, i64, vp]
         lib.phl_copy2d.argtypes = [vp, i64, i64, vp, i64, i64, i64, i32, vp]
         lib.phl_cost_volume.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, vp, i64, vp]
@@ -542,6 +547,24 @@ def _mu_transposed(Mu, device):
     return hit[0]
 
 
+_mu_planes_cache = {}
+
+
+def _mu_planes(Mu, mu_t, device):
+    """The compatibility matrix as the split kernel reads it (phl_compat_prepare), cached like Mu^T."""
+    key = (Mu.data_ptr(), Mu._version, tuple(Mu.shape), tuple(Mu.stride()), str(device))
+    hit = _mu_planes_cache.get(key)
+    if hit is None:
+        if len(_mu_planes_cache) > 8:
+            _mu_planes_cache.clear()
+        lib = load_library()
+        planes = torch.empty((lib.phl_compat_planes_bytes(Mu.shape[0]),), dtype=torch.uint8, device=device)
+        with torch.cuda.device(device):
+            _check(lib.phl_compat_prepare(C.c_void_p(mu_t.data_ptr()), Mu.shape[0], C.c_void_p(planes.data_ptr()), _stream(device)))
+        hit = _mu_planes_cache[key] = (planes, Mu, mu_t)
+    return hit[0]
+
+
 _mu_uniform_cache = {}
 
 
@@ -565,13 +588,20 @@ def _mu_uniform(Mu):
     return res
 
 
-def compat_softmax(E0, X, Mu, out=None, logits=False, structure=True):
+def compat_softmax(E0, X, Mu, out=None, logits=False, structure=True, arith=None):
     """softmax(-(E0 + X @ Mu), dim=1): the whole non-lattice half of a mean-field iteration
     (crf/crf_module.py:51-52) for fp32 CUDA E0, X [n, L] and Mu [L, L], in one fused MFMA kernel
     (phl_compat_softmax) when L % 4 == 0 and L <= 256 (label counts that are not a multiple of 32 run on a padded
     tile); other label counts take a library GEMM followed by the fused add + softmax pass.  A Mu of the Potts family
     (alpha * ones + beta * eye, detected once per Mu; ``structure=False`` switches that off) needs no product at all:
-    phl_uniform_compat_softmax streams E0, X and Q once.  logits=True returns -(E0 + X @ Mu) instead (CRFasRNN's output)."""
+    phl_uniform_compat_softmax streams E0, X and Q once.  logits=True returns -(E0 + X @ Mu) instead (CRFasRNN's output).
+    arith: "f32" = the f32-input matrix cores (bitwise an fma chain in k order), "split" = bf16 matrix cores on operands
+    split three ways, six partial products, f32 accumulation (phl_compat_softmax_split: 224 < L <= 256 only; the same
+    accuracy against float64, 3/8 of the matrix time); default: "split" where it applies unless PHL_COMPAT_ARITH=f32."""
+    if arith is None:
+        arith = os.environ.get("PHL_COMPAT_ARITH", "split")
+    if arith not in ("f32", "split"):
+        raise ValueError(f"compat_softmax: arith must be 'f32' or 'split', got {arith!r}")
     if not (_rowmajor(E0) and _rowmajor(X) and X.shape == E0.shape and Mu.shape == (E0.shape[1], E0.shape[1])):
         raise TypeError("compat_softmax: expects fp32 CUDA E0, X [n, L] with unit channel stride and Mu [L, L]")
     n, L = E0.shape
@@ -587,6 +617,14 @@ def compat_softmax(E0, X, Mu, out=None, logits=False, structure=True):
         return out
     if aligned and L <= 256:
         mu_t = _mu_transposed(Mu, E0.device)
+        if arith == "split" and hasattr(load_library(), "phl_compat_softmax_split") and load_library().phl_compat_planes_bytes(L):
+            planes = _mu_planes(Mu, mu_t, E0.device)
+            with torch.cuda.device(E0.device):
+                _check(load_library().phl_compat_softmax_split(
+                    C.c_void_p(E0.data_ptr()), E0.stride(0), C.c_void_p(X.data_ptr()), X.stride(0), C.c_void_p(mu_t.data_ptr()),
+                    C.c_void_p(planes.data_ptr()), C.c_void_p(out.data_ptr()), out.stride(0), n, L, 1 if logits else 0,
+                    _stream(E0.device)))
+            return out
         with torch.cuda.device(E0.device):
             _check(load_library().phl_compat_softmax(
                 C.c_void_p(E0.data_ptr()), E0.stride(0), C.c_void_p(X.data_ptr()), X.stride(0), C.c_void_p(mu_t.data_ptr()),

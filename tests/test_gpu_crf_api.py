@@ -300,16 +300,21 @@ def test_fused_compat_softmax_kernel(n, L):
     assert not torch.allclose(Mu, Mu.t())
     G64 = X.double() @ Mu.double()
     want = torch.softmax(-(E0.double() + G64), dim=1)
-    got = phl.compat_softmax(E0, X, Mu)
     ref32 = torch.softmax(-(E0 + X @ Mu), dim=1)
-    e_fused = float((got.double() - want).abs().max())
     e_torch = float((ref32.double() - want).abs().max())
-    print(f"[measured] compat_softmax n={n} L={L}: max abs err vs fp64 {e_fused:.2e} (torch fp32 GEMM+softmax: {e_torch:.2e})")
-    assert e_fused <= max(2e-6, 2 * e_torch)                 # exact-f32 MFMA: no worse than the fp32 library path
-    assert float((got.sum(1) - 1).abs().max()) <= 1e-5
-    # logits mode: -(E0 + X @ Mu)
-    lg = phl.compat_softmax(E0, X, Mu, logits=True)
-    assert float((lg.double() + (E0.double() + G64)).abs().max()) <= 1e-4 * float((E0.double() + G64).abs().max())
+    e_by = {}
+    for arith in (("f32", "split") if 224 < L <= 256 else ("f32",)):
+        got = phl.compat_softmax(E0, X, Mu, arith=arith)
+        e_by[arith] = e_fused = float((got.double() - want).abs().max())
+        print(f"[measured] compat_softmax n={n} L={L} {arith}: max abs err vs fp64 {e_fused:.2e} (torch fp32 GEMM+softmax: {e_torch:.2e})")
+        assert e_fused <= max(2e-6, 2 * e_torch)             # f32 chain / six exact bf16 partial products: no worse than the fp32 library path
+        assert float((got.sum(1) - 1).abs().max()) <= 1e-5
+        # logits mode: -(E0 + X @ Mu)
+        lg = phl.compat_softmax(E0, X, Mu, logits=True, arith=arith)
+        assert float((lg.double() + (E0.double() + G64)).abs().max()) <= 1e-4 * float((E0.double() + G64).abs().max())
+    if "split" in e_by:                                      # the split form carries the error of an f32 dot product
+        assert e_by["split"] <= 2 * e_by["f32"] + 1e-7
+    got = phl.compat_softmax(E0, X, Mu)
     # in place over a buffer that is not X
     out = torch.empty_like(E0)
     assert phl.compat_softmax(E0, X, Mu, out=out) is out and torch.equal(out, got)
@@ -323,17 +328,20 @@ def test_compat_softmax_many_tiles_both_groups_and_tails():
     import phl
 
     g = torch.Generator(device="cuda").manual_seed(11)
-    for n, L in ((128, 256), (3 * 128, 256), (128 * 1031 + 77, 64), (128 * 2 * 256 * 3 + 128 + 5, 32), (128 * 700, 128), (127, 256)):
+    for n, L in ((128, 256), (3 * 128, 256), (128 * 1031 + 77, 64), (128 * 2 * 256 * 3 + 128 + 5, 32), (128 * 700, 128), (127, 256),
+                 (128 * 2 * 256 * 2 + 128 + 9, 256), (128 * 515 + 1, 236)):
         E0 = torch.rand((n, L), device="cuda", generator=g) * 30 - 5
         X = torch.rand((n, L), device="cuda", generator=g)
         Mu = torch.rand((L, L), device="cuda", generator=g) * 3
-        got = phl.compat_softmax(E0, X, Mu)
-        want = torch.softmax(-(E0 + X @ Mu), dim=1)
-        err = float((got - want).abs().max())
-        print(f"[measured] compat_softmax n={n} L={L}: max abs diff to torch fp32 {err:.2e}")
-        assert err <= 2e-5 and bool(torch.isfinite(got).all())
-        for _ in range(3):
-            assert torch.equal(phl.compat_softmax(E0, X, Mu), got)
+        want = torch.softmax(-(E0.double() + X.double() @ Mu.double()), dim=1)
+        e_torch = float((torch.softmax(-(E0 + X @ Mu), dim=1).double() - want).abs().max())
+        for arith in (("f32", "split") if 224 < L <= 256 else ("f32",)):
+            got = phl.compat_softmax(E0, X, Mu, arith=arith)
+            err = float((got.double() - want).abs().max())
+            print(f"[measured] compat_softmax n={n} L={L} {arith}: max abs err vs fp64 {err:.2e} (torch fp32: {e_torch:.2e})")
+            assert err <= max(2e-6, 2 * e_torch) and bool(torch.isfinite(got).all())
+            for _ in range(3):
+                assert torch.equal(phl.compat_softmax(E0, X, Mu, arith=arith), got)
 
 
 def test_compat_softmax_random_shapes():
@@ -545,17 +553,17 @@ def test_mean_field_gradient_through_the_lattice_operator():
     assert not Qc.requires_grad and float((Qc - Qb).abs().max()) <= 1e-5
 
 
-def test_compat_softmax_repeatable_under_background_traffic():
-    """Race hunt for k_compat_softmax's LDS rings and counted vmcnt waits (tools/compat_stress.py as a test): 30
-    launches of one C2-sized shape beside memory traffic on a second stream, every result bit-equal to the first."""
+@pytest.mark.parametrize("n,L,arith", [(128 * 4001 + 3, 224, "f32"), (128 * 4001 + 3, 256, "split"), (128 * 3001 + 77, 244, "split")])
+def test_compat_softmax_repeatable_under_background_traffic(n, L, arith):
+    """Race hunt for the LDS rings and counted vmcnt waits of k_compat_softmax / k_compat_split (tools/compat_stress.py as
+    a test): 30 launches of one C2-sized shape beside memory traffic on a second stream, every result bit-equal to the first."""
     import phl
 
     g = torch.Generator(device="cuda").manual_seed(1)
-    n, L = 128 * 4001 + 3, 224
     E0 = torch.rand((n, L), device="cuda", generator=g) * 20
     X = torch.rand((n, L), device="cuda", generator=g)
     Mu = torch.rand((L, L), device="cuda", generator=g) * 2
-    first = phl.compat_softmax(E0, X, Mu).clone()
+    first = phl.compat_softmax(E0, X, Mu, arith=arith).clone()
     want = torch.softmax(-(E0.double() + X.double() @ Mu.double()), dim=1)
     assert float((first.double() - want).abs().max()) <= 2e-4
     out = torch.empty_like(first)
@@ -565,7 +573,7 @@ def test_compat_softmax_repeatable_under_background_traffic():
         if it % 3 == 0:
             with torch.cuda.stream(side):
                 junk.add_(1)
-        phl.compat_softmax(E0, X, Mu, out=out)
+        phl.compat_softmax(E0, X, Mu, out=out, arith=arith)
         assert torch.equal(out, first), f"launch {it} differs from the first"
     torch.cuda.synchronize()
 
