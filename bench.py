@@ -1026,26 +1026,45 @@ def mean_field_iteration(torch, phl, lat, Q, L, device):
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
-    # the fused compatibility product + softmax (phl_compat_softmax: hand-written f32 MFMA 16x16x4 tiles with the
-    # softmax as epilogue) alone, steady state: HIP events around `reps` back-to-back launches after the warm-up above
+    # the fused compatibility product + softmax alone, steady state (HIP events around `reps` back-to-back launches after
+    # the warm-up above), in both arithmetic forms: "split" (the default for 224 < L <= 256: bf16 matrix cores on operands
+    # split three ways, six exact partial products, f32 accumulation -- a streaming pass by its bytes) and "f32" (the
+    # f32-input matrix cores, an fma chain in k order -- MFMA-bound); errors of both against float64 on a row sample
     X = W(Q)
-    for _ in range(4):
-        phl.compat_softmax(E0, X, Mu, out=Qn)
-    e2, e3 = ev(), ev()
-    e2.record()
-    for _ in range(reps):
-        phl.compat_softmax(E0, X, Mu, out=Qn)
-    e3.record()
-    torch.cuda.synchronize()
-    cms = e2.elapsed_time(e3) / reps
     n = Q.shape[0]
-    tflops = 2.0 * n * L * L / (cms * 1e-3) / 1e12
+    split_ok = 224 < L <= 256 and L % 4 == 0
+    times = {}
+    for arith in (("split", "f32") if split_ok else ("f32",)):
+        for _ in range(4):
+            phl.compat_softmax(E0, X, Mu, out=Qn, arith=arith)
+        e2, e3 = ev(), ev()
+        e2.record()
+        for _ in range(reps):
+            phl.compat_softmax(E0, X, Mu, out=Qn, arith=arith)
+        e3.record()
+        torch.cuda.synchronize()
+        times[arith] = e2.elapsed_time(e3) / reps
+    rows = torch.cat([torch.arange(0, 2048, device=device), torch.arange(n // 2, n // 2 + 2048, device=device), torch.arange(n - 2048, n, device=device)])
+    want = -(E0[rows].double() + X[rows].double() @ Mu.double())          # the energies (logits epilogue): what the product's rounding shows in
+    errs = {}
+    for arith in times:
+        got = phl.compat_softmax(E0, X, Mu, out=Qn, arith=arith, logits=True)
+        errs[arith] = float((got[rows].double() - want).abs().max()) / float(want.abs().max())
+    used = "split" if split_ok and os.environ.get("PHL_COMPAT_ARITH", "split") == "split" else "f32"
+    cms = times[used]
     F32_MFMA_PEAK = 157.3      # MI355X_MICROARCH.md: dense fp32 matrix peak, TFLOP/s
+    f32_tflops = 2.0 * n * L * L / (times["f32"] * 1e-3) / 1e12
+    compat = {"kernel": "k_compat_split" if used == "split" else "k_compat_softmax", "arith": used, "ms": round(cms, 4),
+              "hbm_bytes_algorithmic": int(3 * 4 * n * L), "algorithmic_GBps": round(3 * 4 * n * L / (cms * 1e-3) / 1e9, 1),
+              "frac_of_8TBps": round(3 * 4 * n * L / (cms * 1e-3) / 8e12, 3),
+              "f32_matrix_cores": {"kernel": "k_compat_softmax", "ms": round(times["f32"], 4), "tflops": round(f32_tflops, 1),
+                                   "frac_of_157.3": round(f32_tflops / F32_MFMA_PEAK, 3)},
+              "energy_err_vs_float64_over_max_energy_on_6144_rows": {k: float(f"{v:.3e}") for k, v in errs.items()},
+              "what": "softmax(-(E0 + X@Mu)) in one kernel: reads E0 and X, writes Q; G and E never exist in HBM"}
+    if used == "split":
+        compat["bf16_tflops_six_products"] = round(6 * 2.0 * n * L * L / (cms * 1e-3) / 1e12, 1)
     return {"ms": round(ms, 3), "Mpixel_labels_per_s": round(n * L / (ms * 1e-3) / 1e6, 1),
-            "what": "filter - Q (fused), (.)@Mu + E0 + softmax(-.)",
-            "compat": {"kernel": "k_compat_softmax", "ms": round(cms, 4), "tflops": round(tflops, 1),
-                       "frac_of_157.3": round(tflops / F32_MFMA_PEAK, 3), "hbm_bytes_algorithmic": int(3 * 4 * n * L),
-                       "what": "softmax(-(E0 + X@Mu)) in one kernel: reads E0 and X, writes Q; G and E never exist in HBM"}}
+            "what": "filter - Q (fused), (.)@Mu + E0 + softmax(-.)", "compat": compat}
 
 
 if __name__ == "__main__":

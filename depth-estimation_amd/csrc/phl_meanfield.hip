@@ -684,6 +684,13 @@ __device__ __forceinline__ void split3(float x0, float x1, unsigned &h, unsigned
 }
 
 constexpr int CSP_PIECE = 24576;                 // bytes of one slot's piece of the planes
+#ifndef PHL_CSP_XR
+#define PHL_CSP_XR 3
+#endif
+#ifndef PHL_CSP_TB
+#define PHL_CSP_TB 2
+#endif
+constexpr int CSP_XR = PHL_CSP_XR, CSP_TB = PHL_CSP_TB;
 constexpr int CSP_PLANES_BYTES = 16 * CSP_PIECE; // 16 pieces: (K chunk 0..7) x (label half 0..1)
 
 // MuT [256][256] f32 (zero beyond the real label count) -> planes: piece (kc, hf), label tile Tl of the half, plane P,
@@ -716,8 +723,15 @@ __global__ __launch_bounds__(512) void k_compat_split(const float *__restrict__ 
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     constexpr int NT = 8, NL = 16, NS = 16;        // K chunks, label tiles of 16, slots per half
     constexpr int X_FLOATS = 4 * 1024;            // one chunk of the tile's X: 4 waves x [32 pixels][32 k]
-    constexpr int X_BASE = 4 * CSP_PIECE;         // bytes: the X ring [3][X_FLOATS] sits behind the ring of four pieces
-    constexpr int EPI_D = 10;                     // epilogue slots that move rows
+    constexpr int X_BASE = 4 * CSP_PIECE;         // bytes: the X ring [XR][X_FLOATS] sits behind the ring of four pieces
+    constexpr int XR = CSP_XR, XA = 2 * (XR - 1); // X ring depth; an X chunk is requested XA slots = XR - 1 chunks ahead
+#ifndef PHL_CSP_EPI_D
+#define PHL_CSP_EPI_D 14
+#endif
+#ifndef PHL_CSP_SLEEP
+#define PHL_CSP_SLEEP 2
+#endif
+    constexpr int EPI_D = PHL_CSP_EPI_D;          // epilogue slots that move rows
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -734,7 +748,7 @@ __global__ __launch_bounds__(512) void k_compat_split(const float *__restrict__ 
     const unsigned mvoff = (unsigned)lane * 16u;
     const int64_t b2 = 2 * (int64_t)blockIdx.x;
     // feed(s, ph, xb): the requests of slot S = 16 ph + s (s >= -4 before the first slot): the piece of the planes for
-    // slot S + 3 and, in even slots, the X chunk of slots S + 4 and S + 5 into X buffer xb = ((S + 4) >> 1) % 3.
+    // slot S + 3 and, in even slots, the X chunk of slots S + XA and S + XA + 1 into X buffer xb = ((S + XA) >> 1) % XR.
     // Returns whether X pieces were issued (the consuming group may have run out of tiles).
     auto feed = [&](auto sc, int ph, int xb) -> bool {
         constexpr int s = decltype(sc)::value;
@@ -746,8 +760,8 @@ __global__ __launch_bounds__(512) void k_compat_split(const float *__restrict__ 
             for (int r = 0; r < 6; r++) glds16(reinterpret_cast<const float *>(src + r * 1024), mvoff, dst + r * 1024);
         }
         bool ok = false;
-        if constexpr (s + 4 >= 0 && (s & 1) == 0) {
-            constexpr int t = s + 4;
+        if constexpr (s + XA >= 0 && (s & 1) == 0) {
+            constexpr int t = s + XA;
             const int php = ph + (t >= NS ? 1 : 0);
             constexpr int kc = (t & 15) >> 1;
             const int64_t tile = (php & 1) ? b2 + 1 + (int64_t)((php - 1) >> 1) * G2 : b2 + (int64_t)(php >> 1) * G2;
@@ -819,20 +833,20 @@ __global__ __launch_bounds__(512) void k_compat_split(const float *__restrict__ 
 #ifdef __HIP_DEVICE_COMPILE__
     asm volatile("" ::"v"(acc[1][NL - 1]));
 #endif
-    int ph = 0, x3 = 0;                            // half index of the current slot, (slot >> 1) % 3
-    auto next_chunk = [&]() { x3 = x3 == 2 ? 0 : x3 + 1; };
+    int ph = 0, x3 = 0;                            // half index of the current slot, (slot >> 1) % XR
+    auto next_chunk = [&]() { x3 = x3 == XR - 1 ? 0 : x3 + 1; };
     if (grp == 1) {
         // group 0's first half is fed by group 1: first what its slots 0..3 need, then slot by slot
-        feed(std::integral_constant<int, -4>(), 0, 0);
-        feed(std::integral_constant<int, -3>(), 0, 0);
-        feed(std::integral_constant<int, -2>(), 0, 1);
-        feed(std::integral_constant<int, -1>(), 0, 0);
+        static_for<XA>([&](auto ic) {
+            constexpr int s = decltype(ic)::value - XA;          // slots -XA .. -1
+            feed(std::integral_constant<int, s>(), 0, ((s + XA) >> 1) % XR);
+        });
         dma_drain();
         __builtin_amdgcn_s_barrier();
         bool xe = false;
         static_for<NS>([&](auto sc) {
             constexpr int s = decltype(sc)::value;
-            const bool xp = feed(sc, 0, x3 == 0 ? 2 : x3 - 1);
+            const bool xp = feed(sc, 0, x3 == 0 ? XR - 1 : x3 - 1);
             if ((s & 1) == 0) xe = xp;
             // what slot s + 1 reads was requested in slot s - 2: the requests of slots s - 1 and s may stay in flight
             if (xe) PHL_VMCNT((s >= 1 ? 6 : 0) + 6 + 4);
@@ -923,7 +937,7 @@ __global__ __launch_bounds__(512) void k_compat_split(const float *__restrict__ 
             constexpr int s = decltype(sc)::value, kc = s >> 1, hf = s & 1;
             if (valid) {
                 const char *ab = a_lane + (s & 3) * CSP_PIECE;
-                constexpr int TB = 2, STEPS = 8 / TB;
+                constexpr int TB = CSP_TB, STEPS = 8 / TB;
                 u32x4 pa[2][TB][3];
                 auto read_a = [&](int st, u32x4 (&dst)[TB][3]) {
 #pragma unroll
@@ -989,8 +1003,8 @@ __global__ __launch_bounds__(512) void k_compat_split(const float *__restrict__ 
             x_late = true;
             static_for<NS>([&](auto sc) {
                 constexpr int s = decltype(sc)::value;
-                __builtin_amdgcn_s_sleep(2);
-                const bool xp = feed(sc, ph, x3 == 0 ? 2 : x3 - 1);
+                __builtin_amdgcn_s_sleep(PHL_CSP_SLEEP);
+                const bool xp = feed(sc, ph, x3 == 0 ? XR - 1 : x3 - 1);
                 if ((s & 1) == 0) xe = xp;
                 if (s >= EPI_D && (s & 1) == 0) x_late = x_late && xp;
                 constexpr int U = 4 * NT, D = EPI_D;
@@ -1237,7 +1251,7 @@ int phl_compat_softmax_split(const float *E0, int64_t e_rs, const float *X, int6
     hipStream_t st = (hipStream_t)stream;
     const int64_t n_main = n / 128 * 128, npairs = (n / 128 + 1) / 2;
     const unsigned grid = (unsigned)(npairs < 256 ? npairs : 256);
-    const size_t lds = (size_t)4 * CSP_PIECE + 3 * 4 * 1024 * sizeof(float);     // ring of four pieces + X ring: 144 KiB
+    const size_t lds = (size_t)4 * CSP_PIECE + CSP_XR * 4 * 1024 * sizeof(float);     // ring of four pieces + X ring: 144 KiB
     const bool logits = (flags & PHL_COMPAT_LOGITS) != 0;
     int dev = 0;
     PHL_HIP(hipGetDevice(&dev));
