@@ -420,7 +420,50 @@ def growth_cases(report):
         lattice_case(*args, report=report, store=False)
 
 
+def round4b_cases(report):
+    """Round 4, second half: the flat mean field at L = 256 (the label count of BASELINE's C2 / C3 configurations, where the
+    compatibility product runs on the bf16 matrix cores with split operands) on a 16 x 24 Tsukuba crop = three 128-pixel
+    tiles, 1 and 5 iterations of the reference (crf_module.py:41-53 over the reference engine).  E_0 is rounded to float16
+    first and stored as float16, so the stored input is exact."""
+    import torch
+
+    torch.manual_seed(3)
+    torch.set_num_threads(1)
+    crf_module, gm = import_reference_python()
+    imL = read_image(os.path.join(REFERENCE, "Experiments", "imL.png"))
+    imR = read_image(os.path.join(REFERENCE, "Experiments", "imR.png"))
+    H, W_ = imL.shape[:2]
+    position = np.mgrid[:H, :W_].transpose((1, 2, 0)) / np.sqrt(H ** 2 + W_ ** 2)
+    L, sigma_c, sigma_p, gamma = 256, 0.1, 0.1, 3
+    r0, c0, h, w = 150, 300, 16, 24
+    full = disparity_badness(imL, imR, L)
+    E0_np = full[r0:r0 + h, c0:c0 + w].reshape(-1, L).astype(np.float16).astype(np.float32)
+    E0 = torch.from_numpy(E0_np)
+    refimg = np.zeros((h, w, 5))
+    refimg[..., :3] = imL[r0:r0 + h, c0:c0 + w] / sigma_c
+    refimg[..., 3:] = position[r0:r0 + h, c0:c0 + w] / sigma_p
+    flat_ref = torch.from_numpy(refimg.reshape(h * w, -1).astype(np.float32))
+    labels = torch.arange(L).float()
+    Mu = crf_module.compatibility_matrix(lambda a, b: crf_module.charbonneir(a, b, gamma), labels)
+    Wop = gm.LatticeGaussian(flat_ref)
+    with torch.no_grad():
+        Q1 = crf_module.mean_field_infer(E0, Wop, Mu, 1)
+        Q5 = crf_module.mean_field_infer(E0, Wop, Mu, 5)
+    np.savez_compressed(os.path.join(HERE, "meanfield_tsukuba_L256.npz"), E0_f16=E0_np.astype(np.float16), ref=flat_ref.numpy(),
+                        labels=labels.numpy(), gamma=np.float32(gamma), Q1=Q1.numpy(), Q5=Q5.numpy(),
+                        disp1=(Q1 @ labels).numpy(), disp5=(Q5 @ labels).numpy(), h=np.int64(h), w=np.int64(w))
+    report.append(dict(case="meanfield_tsukuba_L256", n=h * w, L=L, d=5))
+
+
 def main():
+    if sys.argv[1:] == ["round4b"]:
+        assert po.build_reference(), "reference engine not built"
+        report = json.load(open(os.path.join(HERE, "PIN_REPORT.json")))
+        report = [r for r in report if r.get("case") not in ("meanfield_tsukuba_L256",)]
+        round4b_cases(report)
+        with open(os.path.join(HERE, "PIN_REPORT.json"), "w") as f:
+            json.dump(report, f, indent=1)
+        return
     if sys.argv[1:] == ["costvol"]:          # add the cost-volume vectors without regenerating the rest
         report = json.load(open(os.path.join(HERE, "PIN_REPORT.json")))
         report = [r for r in report if not str(r.get("case", "")).startswith("costvol_")]
@@ -467,6 +510,7 @@ def main():
     python_layer_cases(report)
     mean_field_wide_cases(report)
     round4_cases(report)
+    round4b_cases(report)
     cost_volume_cases(report)
     with open(os.path.join(HERE, "PIN_REPORT.json"), "w") as f:
         json.dump(report, f, indent=1)

@@ -465,6 +465,43 @@ def test_mean_field_L32_golden(golden_dir):
         assert eq <= 5e-4 and ed <= 1e-4
 
 
+@pytest.mark.parametrize("arith", ["split", "f32"])
+def test_mean_field_L256_golden(golden_dir, monkeypatch, arith):
+    """Reference-generated vectors at L = 256, the label count of BASELINE's C2 / C3 (tests/golden/generate.py round4b: 16 x 24
+    Tsukuba crop = three 128-pixel tiles): the compatibility product takes the bf16 matrix cores with split operands
+    (phl_compat_softmax_split) or, with PHL_COMPAT_ARITH=f32, the f32 matrix cores -- both against the reference's Q and
+    disparity after 1 and 5 iterations."""
+    import phl
+    from crf.crf_module import charbonneir, compatibility_matrix, mean_field_infer
+    from crf.gaussian_matrix import LatticeGaussian
+
+    monkeypatch.setenv("PHL_COMPAT_ARITH", arith)
+    g = np.load(os.path.join(golden_dir, "meanfield_tsukuba_L256.npz"))
+    dev = torch.device("cuda")
+    E0 = torch.from_numpy(g["E0_f16"].astype(np.float32)).to(dev)
+    ref = torch.from_numpy(g["ref"]).to(dev)
+    labels = torch.from_numpy(g["labels"]).to(dev)
+    Mu = compatibility_matrix(lambda a, b: charbonneir(a, b, float(g["gamma"])), labels)
+    taken = []
+    lib = phl.load_library()
+    real = lib.phl_compat_softmax_split
+
+    class _Spy:                                   # (ctypes function objects take no attributes: wrap the call)
+        def __call__(self, *a):
+            taken.append("split")
+            return real(*a)
+    monkeypatch.setattr(lib, "phl_compat_softmax_split", _Spy())
+    W = LatticeGaussian(ref)
+    for it, key in ((1, "1"), (5, "5")):
+        Q = mean_field_infer(E0, W, Mu, it)
+        eq = rel(Q.cpu().numpy(), g["Q" + key])
+        disp = (Q @ labels).cpu().numpy()
+        ed = float((np.abs(disp - g["disp" + key]) / np.maximum(np.abs(g["disp" + key]), 1e-2)).max())
+        print(f"[measured] mean field L=256 ({arith}), {it} iteration(s): Q rel {eq:.2e}, disparity rel per pixel {ed:.2e}")
+        assert eq <= 5e-4 and ed <= 1e-4
+    assert (len(taken) == 6) if arith == "split" else not taken, taken
+
+
 def test_crf_as_rnn_nchw_golden(golden_dir):
     """CRFasRNN + charb over NCHW tensors with the lattice W (crf_module.py:66-104 with BatchedAdjacency as self.W),
     expected logits from the reference's own classes.  The no-grad path runs fused (pixel-major inside, one filter
