@@ -798,7 +798,8 @@ __global__ __launch_bounds__(512) void k_compat_split(const float *__restrict__ 
     // The same load, invisible to the compiler's wait counting (inline assembly): the loads of the NEXT tile's E0 go
     // straight into the accumulators in the first EPI_D slots of an epilogue half, and a compiler-made wait for them
     // would also drain the DMA pieces issued behind them (it cannot count those) -- a stalled slot per half.  The wait is
-    // ours: a counted one at the start of the matrix-core half.
+    // ours: a counted one at the start of the matrix-core half.  Sound only while the compiler leaves these registers alone
+    // between load and wait (no copy, spill or AGPR move): tools/check_split_isa.py verifies that on the generated code.
 #define PHL_E0_LOAD_HIDDEN(pg, T, wave_rows)                                                                              \
     do {                                                                                                                  \
         const float *p_ = (wave_rows) + (pg) * 16 * e_rs + 16 * (T);                                                      \

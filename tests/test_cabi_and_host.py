@@ -94,3 +94,19 @@ def test_exact_divide_recipe_matches_ieee_division():
         rem = (t.astype(np.float64) - q.astype(np.float64) * np.float64(c)).astype(np.float32)
         q2 = (q.astype(np.float64) + rem.astype(np.float64) * np.float64(rc)).astype(np.float32)
         assert np.array_equal(q2, t / c), d
+
+
+def test_split_compat_kernel_machine_code_leaves_hidden_loads_alone():
+    """k_compat_split loads the next tile's E_0 into its accumulators with inline-assembly loads and waits for them itself
+    (the compiler would drain the LDS-DMA queue with them).  That is sound only while the compiler never touches those
+    registers between load and wait: tools/check_split_isa.py compiles the file to gfx950 assembly (no GPU needed) and
+    checks every instance -- no scratch, no AGPRs, no accumulator named outside matrix slots, loads and stores."""
+    import importlib.util
+    import shutil
+
+    if not shutil.which("/opt/rocm/bin/hipcc"):
+        pytest.skip("hipcc not available")
+    spec = importlib.util.spec_from_file_location("check_split_isa", os.path.join(ROOT, "tools", "check_split_isa.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.main() == 0
