@@ -543,6 +543,8 @@ def _mu_transposed(Mu, device):
         Lp = (L + 31) // 32 * 32                 # the kernel's tile width: zero padding beyond L
         mt = torch.zeros((Lp, Lp), dtype=torch.float32, device=device)
         mt[:L, :L] = Mu.detach().to(device, torch.float32).t()
+        if not torch.cuda.is_current_stream_capturing():     # cached across calls: complete before another stream can use it
+            torch.cuda.current_stream(device).synchronize()
         hit = _mu_t_cache[key] = (mt, Mu)        # keeps Mu alive
     return hit[0]
 
@@ -561,6 +563,9 @@ def _mu_planes(Mu, mu_t, device):
         planes = torch.empty((lib.phl_compat_planes_bytes(Mu.shape[0]),), dtype=torch.uint8, device=device)
         with torch.cuda.device(device):
             _check(lib.phl_compat_prepare(C.c_void_p(mu_t.data_ptr()), Mu.shape[0], C.c_void_p(planes.data_ptr()), _stream(device)))
+            # cached across calls, and a later call may come on another stream: finished before anyone else can see it
+            if not torch.cuda.is_current_stream_capturing():
+                torch.cuda.current_stream(device).synchronize()
         hit = _mu_planes_cache[key] = (planes, Mu, mu_t)
     return hit[0]
 
