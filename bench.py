@@ -1027,12 +1027,12 @@ def mean_field_iteration(torch, phl, lat, Q, L, device):
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
     # the fused compatibility product + softmax alone, steady state (HIP events around `reps` back-to-back launches after
-    # the warm-up above), in both arithmetic forms: "split" (the default for 224 < L <= 256: bf16 matrix cores on operands
+    # the warm-up above), in both arithmetic forms: "split" (the default for 176 < L <= 256: bf16 matrix cores on operands
     # split three ways, six exact partial products, f32 accumulation -- a streaming pass by its bytes) and "f32" (the
     # f32-input matrix cores, an fma chain in k order -- MFMA-bound); errors of both against float64 on a row sample
     X = W(Q)
     n = Q.shape[0]
-    split_ok = 224 < L <= 256 and L % 4 == 0
+    split_ok = 128 < L <= 256 and L % 4 == 0
     times = {}
     for arith in (("split", "f32") if split_ok else ("f32",)):
         for _ in range(4):
@@ -1050,7 +1050,7 @@ def mean_field_iteration(torch, phl, lat, Q, L, device):
     for arith in times:
         got = phl.compat_softmax(E0, X, Mu, out=Qn, arith=arith, logits=True)
         errs[arith] = float((got[rows].double() - want).abs().max()) / float(want.abs().max())
-    used = "split" if split_ok and os.environ.get("PHL_COMPAT_ARITH", "split") == "split" else "f32"
+    used = (os.environ.get("PHL_COMPAT_ARITH") or ("split" if L > 176 else "f32")) if split_ok else "f32"
     cms = times[used]
     F32_MFMA_PEAK = 157.3      # MI355X_MICROARCH.md: dense fp32 matrix peak, TFLOP/s
     f32_tflops = 2.0 * n * L * L / (times["f32"] * 1e-3) / 1e12

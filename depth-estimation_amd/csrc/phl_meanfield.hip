@@ -644,7 +644,7 @@ __global__ __launch_bounds__(512) void k_compat_softmax(const float *__restrict_
 #undef PHL_WAIT_BUT
 
 // ------------------------------------------------------------------------------------------------------------
-// k_compat_split: the same fused step for L in (224, 256] on the bf16 matrix cores (v_mfma_f32_16x16x32_bf16, sixteen
+// k_compat_split: the same fused step for L in (128, 256] (a 256-label tile, padded above L) on the bf16 matrix cores (v_mfma_f32_16x16x32_bf16, sixteen
 // times the f32 rate), with BOTH operands split into three bf16 addends -- x = h + m + l, eight significant bits each,
 // by truncation: the split is exact, h + m + l == x bit for bit -- and the six products that matter:
 //     x mu  =  hH + hM + mH + hL + lH + mM   ( + mL + lM + lL  <=  2^-23 |x mu|, dropped )
@@ -688,24 +688,27 @@ constexpr int CSP_PIECE = 24576;                 // bytes of one slot's piece of
 #define PHL_CSP_XR 3
 #endif
 #ifndef PHL_CSP_TB
-#define PHL_CSP_TB 2
+#define PHL_CSP_TB 1
 #endif
 constexpr int CSP_XR = PHL_CSP_XR, CSP_TB = PHL_CSP_TB;
 constexpr int CSP_PLANES_BYTES = 16 * CSP_PIECE; // 16 pieces: (K chunk 0..7) x (label half 0..1)
 
-// MuT [256][256] f32 (zero beyond the real label count) -> planes: piece (kc, hf), label tile Tl of the half, plane P,
-// lane (i, g): eight bf16 = plane P of MuT[16 (8 hf + Tl) + i][32 kc + 8 g .. + 7]
-__global__ __launch_bounds__(256) void k_compat_planes(const float *__restrict__ MuT, u32x4 *__restrict__ planes)
+// MuT [Lp][Lp] f32 (Lp = the label count rounded up to 32, zero beyond the real label count; read as zero beyond Lp) ->
+// planes: piece (kc, hf), label tile Tl of the half, plane P, lane (i, g): eight bf16 = plane P of
+// MuT[16 (8 hf + Tl) + i][32 kc + 8 g .. + 7]
+__global__ __launch_bounds__(256) void k_compat_planes(const float *__restrict__ MuT, int Lp, u32x4 *__restrict__ planes)
 {
     const int t = blockIdx.x * 256 + threadIdx.x;           // one thread per (piece, Tl, lane): 16 * 8 * 64
     if (t >= 16 * 8 * 64) return;
     const int lane = t & 63, Tl = (t >> 6) & 7, piece = t >> 9, kc = piece >> 1, hf = piece & 1;
-    const float *src = MuT + (size_t)(16 * (8 * hf + Tl) + (lane & 15)) * 256 + 32 * kc + 8 * (lane >> 4);
+    const int label = 16 * (8 * hf + Tl) + (lane & 15), k0 = 32 * kc + 8 * (lane >> 4);
+    const bool in = label < Lp && k0 < Lp;                  // (Lp is a multiple of 32: a lane's eight values are all in or all out)
+    const float *src = MuT + (size_t)(in ? label : 0) * Lp + (in ? k0 : 0);
     u32x4 h, m, l;
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         unsigned a, b, c;
-        split3(src[2 * j], src[2 * j + 1], a, b, c);
+        split3(in ? src[2 * j] : 0.f, in ? src[2 * j + 1] : 0.f, a, b, c);
         h[j] = a; m[j] = b; l[j] = c;
     }
     u32x4 *dst = planes + (size_t)piece * (CSP_PIECE / 16) + (size_t)Tl * 3 * 64 + lane;
@@ -752,6 +755,8 @@ __global__ __launch_bounds__(512) void k_compat_split(const float *__restrict__ 
     // Returns whether X pieces were issued (the consuming group may have run out of tiles).
     auto feed = [&](auto sc, int ph, int xb) -> bool {
         constexpr int s = decltype(sc)::value;
+        int lr_now = Lr;                           // (opaque copy: the clamps of a padded tile are computed where they are used --
+        if (PAD) asm volatile("" : "+s"(lr_now));  //  hoisted out of the slot loop they would cost some twenty registers)
         if constexpr (s + 3 >= 0) {
             constexpr int t = s + 3;
             const unsigned char *src = planes + (size_t)(t & 15) * CSP_PIECE + (size_t)w4 * 6 * 1024;
@@ -770,10 +775,13 @@ __global__ __launch_bounds__(512) void k_compat_split(const float *__restrict__ 
                 const float *xw = X + (tile * 128 + w4 * 32) * x_rs;
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
-                    unsigned vo = (j & 1) ? xvoff1 : xvoff0;
-                    if (PAD && kc == NT - 1)
-                        vo = (unsigned)((lane >> 3) * x_rs + min(4 * ((j & 1) ? part1 : part0), Lr - 4 - 32 * kc)) * 4u;
-                    glds16(xw + (int64_t)8 * j * x_rs + 32 * kc, vo, lds_base + X_BASE + (xb * X_FLOATS + w4 * 1024 + j * 256) * 4);
+                    const unsigned dst = lds_base + X_BASE + (xb * X_FLOATS + w4 * 1024 + j * 256) * 4;
+                    if (PAD && kc >= NT / 2 && 32 * kc + 32 > lr_now) {  // a chunk with padded columns: every fetch clamped into the row
+                        const int col = min(32 * kc + 4 * ((j & 1) ? part1 : part0), lr_now - 4);   // (the consumer zeroes what is padding)
+                        glds16(xw + (int64_t)8 * j * x_rs, (unsigned)((lane >> 3) * x_rs + col) * 4u, dst);
+                    } else {
+                        glds16(xw + (int64_t)8 * j * x_rs + 32 * kc, (j & 1) ? xvoff1 : xvoff0, dst);
+                    }
                 }
             }
         }
@@ -787,9 +795,9 @@ __global__ __launch_bounds__(512) void k_compat_split(const float *__restrict__ 
     do {                                                                                                                  \
         const char *p_ = reinterpret_cast<const char *>((wave_rows) + (pg) * 16 * e_rs + 16 * (T));                       \
         unsigned lo_ = lo_e;                                                                                              \
-        if (PAD && (T) >= NL - 2) {                                                                                       \
+        if (PAD && (T) >= NL / 2 && 16 * (T) + 16 > lr_now) {                                                             \
             p_ = reinterpret_cast<const char *>((wave_rows) + (pg) * 16 * e_rs);                                          \
-            lo_ = (unsigned)(i * e_rs + min(16 * (T) + 4 * g4, Lr - 4)) * 4u;                                             \
+            lo_ = (unsigned)(i * e_rs + min(16 * (T) + 4 * g4, lr_now - 4)) * 4u;                                         \
         }                                                                                                                 \
         const float4 v_ = *reinterpret_cast<const float4 *>(p_ + lo_);                                                    \
         acc[pg][T] = f32x4{v_.x, v_.y, v_.z, v_.w};                                                                       \
@@ -804,9 +812,9 @@ __global__ __launch_bounds__(512) void k_compat_split(const float *__restrict__ 
     do {                                                                                                                  \
         const float *p_ = (wave_rows) + (pg) * 16 * e_rs + 16 * (T);                                                      \
         unsigned lo_ = lo_e;                                                                                              \
-        if (PAD && (T) >= NL - 2) {                                                                                       \
+        if (PAD && (T) >= NL / 2 && 16 * (T) + 16 > lr_now) {                                                             \
             p_ = (wave_rows) + (pg) * 16 * e_rs;                                                                          \
-            lo_ = (unsigned)(i * e_rs + min(16 * (T) + 4 * g4, Lr - 4)) * 4u;                                             \
+            lo_ = (unsigned)(i * e_rs + min(16 * (T) + 4 * g4, lr_now - 4)) * 4u;                                         \
         }                                                                                                                 \
         asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(acc[pg][T]) : "v"(lo_), "s"(p_) : "memory");                 \
     } while (0)
@@ -817,15 +825,18 @@ __global__ __launch_bounds__(512) void k_compat_split(const float *__restrict__ 
     f32x4 acc[2][NL];
     auto pad_e0 = [&]() {
         if (PAD) {
+            int lr_now = Lr;
+            asm volatile("" : "+s"(lr_now));
 #pragma unroll
-            for (int T = NL - 2; T < NL; T++)
-                if (16 * T + 4 * g4 >= Lr) {
+            for (int T = NL / 2; T < NL; T++)
+                if (16 * T + 4 * g4 >= lr_now) {
                     acc[0][T] = f32x4{INFINITY, INFINITY, INFINITY, INFINITY};
                     acc[1][T] = acc[0][T];
                 }
         }
     };
     if (valid) {
+        const int lr_now = Lr;
 #pragma unroll
         for (int pg = 0; pg < 2; pg++)
 #pragma unroll
@@ -932,6 +943,7 @@ __global__ __launch_bounds__(512) void k_compat_split(const float *__restrict__ 
 #ifdef __HIP_DEVICE_COMPILE__
 #pragma unroll
         for (int T = 0; T < NL; T++) asm volatile("" : "+v"(acc[0][T]), "+v"(acc[1][T]));
+        asm volatile("; CSP_E0_LANDED (tools/check_split_isa.py: accumulators may be touched from here to the slot's barrier)");
 #endif
         pad_e0();
         static_for<NS>([&](auto sc) {
@@ -953,9 +965,11 @@ __global__ __launch_bounds__(512) void k_compat_split(const float *__restrict__ 
                     for (int pg = 0; pg < 2; pg++) {
                         float4 v0 = *reinterpret_cast<const float4 *>(x_lane0 + x3 * X_FLOATS + pg * 16 * 32);
                         float4 v1 = *reinterpret_cast<const float4 *>(x_lane1 + x3 * X_FLOATS + pg * 16 * 32);
-                        if (PAD && kc == NT - 1) {
-                            if (32 * kc + 8 * g4 >= Lr) v0 = make_float4(0.f, 0.f, 0.f, 0.f);
-                            if (32 * kc + 8 * g4 + 4 >= Lr) v1 = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (PAD && kc >= NT / 2) {
+                            int lr_now = Lr;
+                            asm volatile("" : "+s"(lr_now));
+                            if (32 * kc + 8 * g4 >= lr_now) v0 = make_float4(0.f, 0.f, 0.f, 0.f);
+                            if (32 * kc + 8 * g4 + 4 >= lr_now) v1 = make_float4(0.f, 0.f, 0.f, 0.f);
                         }
                         unsigned h_[4], m_[4], l_[4];
                         split3(v0.x, v0.y, h_[0], m_[0], l_[0]);
@@ -999,7 +1013,9 @@ __global__ __launch_bounds__(512) void k_compat_split(const float *__restrict__ 
             const int64_t nxt = tile + G2;
             const bool has_next = nxt < ntiles;
             float *orows = out + (tile * 128 + w4 * 32) * o_rs;
-            const float *erows = E0 + ((has_next ? nxt : tile) * 128 + w4 * 32) * e_rs;
+            // (the loads are unconditional: without a next tile they fetch rows that certainly exist -- this tile's, or tile 0's
+            // if this group's tile itself lies beyond the end -- into registers nobody reads)
+            const float *erows = E0 + ((has_next ? nxt : (valid ? tile : 0)) * 128 + w4 * 32) * e_rs;
             bool xe = false;
             x_late = true;
             static_for<NS>([&](auto sc) {
@@ -1010,14 +1026,16 @@ __global__ __launch_bounds__(512) void k_compat_split(const float *__restrict__ 
                 if (s >= EPI_D && (s & 1) == 0) x_late = x_late && xp;
                 constexpr int U = 4 * NT, D = EPI_D;
                 constexpr int u_lo = s < D ? (U * s + D - 1) / D : U, u_hi = s + 1 < D ? (U * (s + 1) + D - 1) / D : U;
+                int lr_now = Lr;
+                if (PAD) asm volatile("" : "+s"(lr_now));
 #pragma unroll
                 for (int u = 0; u < U; u++) {
                     if (u < u_lo || u >= u_hi) continue;
                     const int pg = u / NL, T = u % NL;
-                    if (valid && (!PAD || T < NL - 2 || 16 * T + 4 * g4 < Lr))
+                    if (valid && (!PAD || T < NL / 2 || 16 * T + 4 * g4 < lr_now))
                         *reinterpret_cast<float4 *>(reinterpret_cast<char *>(orows + pg * 16 * o_rs + 16 * T) + lo_o) =
                             make_float4(acc[pg][T][0], acc[pg][T][1], acc[pg][T][2], acc[pg][T][3]);
-                    if (has_next) PHL_E0_LOAD_HIDDEN(pg, T, erows);
+                    PHL_E0_LOAD_HIDDEN(pg, T, erows);       // (no next tile: this one's rows again, never used -- no branch around the load)
                 }
                 // What slot s + 1 reads was requested in slot s - 2 or earlier.  vmcnt counts in issue order, so what this
                 // wave issued behind the DMAs of slot s - 2 may stay in flight: the units of slot s - 2, the DMAs and units
@@ -1029,15 +1047,11 @@ __global__ __launch_bounds__(512) void k_compat_split(const float *__restrict__ 
                 constexpr int DM = 6 + (s >= 1 ? 6 : 0);
                 constexpr int ST = PAD ? 0 : UN;
                 if (xe) {
-                    if (valid && has_next) PHL_VMCNT(DM + 4 + UN + ST);
-                    else if (has_next) PHL_VMCNT(DM + 4 + UN);
-                    else if (valid) PHL_VMCNT(DM + 4 + ST);
-                    else PHL_VMCNT(DM + 4);
+                    if (valid) PHL_VMCNT(DM + 4 + UN + ST);
+                    else PHL_VMCNT(DM + 4 + UN);
                 } else {
-                    if (valid && has_next) PHL_VMCNT(DM + UN + ST);
-                    else if (has_next) PHL_VMCNT(DM + UN);
-                    else if (valid) PHL_VMCNT(DM + ST);
-                    else PHL_VMCNT(DM);
+                    if (valid) PHL_VMCNT(DM + UN + ST);
+                    else PHL_VMCNT(DM + UN);
                 }
                 __builtin_amdgcn_s_barrier();
                 if (s & 1) next_chunk();
@@ -1225,14 +1239,14 @@ int phl_compat_softmax(const float *E0, int64_t e_rs, const float *X, int64_t x_
 
 size_t phl_compat_planes_bytes(int L)
 {
-    return (L > 224 && L <= 256 && L % 4 == 0) ? (size_t)CSP_PLANES_BYTES : 0;
+    return (L > 128 && L <= 256 && L % 4 == 0) ? (size_t)CSP_PLANES_BYTES : 0;
 }
 
 int phl_compat_prepare(const float *MuT, int L, void *planes, phl_stream stream)
 {
-    if (!phl_compat_planes_bytes(L)) { phl_set_error("phl_compat_prepare: the split kernel takes 224 < L <= 256, L %% 4 == 0 (L=%d)", L); return PHL_ERR_UNSUPPORTED; }
+    if (!phl_compat_planes_bytes(L)) { phl_set_error("phl_compat_prepare: the split kernel takes 128 < L <= 256, L %% 4 == 0 (L=%d)", L); return PHL_ERR_UNSUPPORTED; }
     if (!MuT || !planes || ((reinterpret_cast<uintptr_t>(MuT) | reinterpret_cast<uintptr_t>(planes)) & 15)) { phl_set_error("phl_compat_prepare: bad arguments"); return PHL_ERR_INVALID; }
-    k_compat_planes<<<dim3(16 * 8 * 64 / 256), dim3(256), 0, (hipStream_t)stream>>>(MuT, reinterpret_cast<u32x4 *>(planes));
+    k_compat_planes<<<dim3(16 * 8 * 64 / 256), dim3(256), 0, (hipStream_t)stream>>>(MuT, (L + 31) / 32 * 32, reinterpret_cast<u32x4 *>(planes));
     PHL_HIP(hipGetLastError());
     return PHL_OK;
 }
@@ -1245,7 +1259,7 @@ int phl_compat_softmax_split(const float *E0, int64_t e_rs, const float *X, int6
     if (!phl_compat_planes_bytes(L) || x_rs % 4 || e_rs % 4 || o_rs % 4 || x_rs >= (1 << 24) || e_rs >= (1 << 24) || o_rs >= (1 << 24) ||
         ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(MuT) | reinterpret_cast<uintptr_t>(planes) | reinterpret_cast<uintptr_t>(E0) |
           reinterpret_cast<uintptr_t>(out)) & 15)) {
-        phl_set_error("phl_compat_softmax_split: needs 224 < L <= 256, L %% 4 == 0 and 16-byte aligned E0 / X / out rows (L=%d)", L);
+        phl_set_error("phl_compat_softmax_split: needs 128 < L <= 256, L %% 4 == 0 and 16-byte aligned E0 / X / out rows (L=%d)", L);
         return PHL_ERR_UNSUPPORTED;
     }
     const bool pad = L != 256;
@@ -1275,8 +1289,9 @@ int phl_compat_softmax_split(const float *E0, int64_t e_rs, const float *X, int6
     }
 #undef PHL_CSP_LAUNCH
     if (n > n_main) {        // the last n % 128 pixels: the f32 chain of the other kernel's tail (at most 127 rows)
-        if (logits) k_compat_tail<true><<<dim3((unsigned)(n - n_main)), dim3(256), 0, st>>>(E0, e_rs, X, x_rs, MuT, 256, out, o_rs, n_main, L);
-        else k_compat_tail<false><<<dim3((unsigned)(n - n_main)), dim3(256), 0, st>>>(E0, e_rs, X, x_rs, MuT, 256, out, o_rs, n_main, L);
+        const int Lp = (L + 31) / 32 * 32;
+        if (logits) k_compat_tail<true><<<dim3((unsigned)(n - n_main)), dim3(256), 0, st>>>(E0, e_rs, X, x_rs, MuT, Lp, out, o_rs, n_main, L);
+        else k_compat_tail<false><<<dim3((unsigned)(n - n_main)), dim3(256), 0, st>>>(E0, e_rs, X, x_rs, MuT, Lp, out, o_rs, n_main, L);
     }
     PHL_HIP(hipGetLastError());
     return PHL_OK;

@@ -601,10 +601,11 @@ def compat_softmax(E0, X, Mu, out=None, logits=False, structure=True, arith=None
     (alpha * ones + beta * eye, detected once per Mu; ``structure=False`` switches that off) needs no product at all:
     phl_uniform_compat_softmax streams E0, X and Q once.  logits=True returns -(E0 + X @ Mu) instead (CRFasRNN's output).
     arith: "f32" = the f32-input matrix cores (bitwise an fma chain in k order), "split" = bf16 matrix cores on operands
-    split three ways, six partial products, f32 accumulation (phl_compat_softmax_split: 224 < L <= 256 only; the same
-    accuracy against float64, 3/8 of the matrix time); default: "split" where it applies unless PHL_COMPAT_ARITH=f32."""
+    split three ways, six partial products, f32 accumulation (phl_compat_softmax_split: a 256-label tile, 128 < L <= 256;
+    the same accuracy against float64, 3/8 of the matrix time).  Default: "split" for L > 176 -- below that the f32 kernel
+    is bound by its bytes as well and computes no padding -- unless PHL_COMPAT_ARITH names one of the two."""
     if arith is None:
-        arith = os.environ.get("PHL_COMPAT_ARITH", "split")
+        arith = os.environ.get("PHL_COMPAT_ARITH") or ("split" if E0.shape[-1] > 176 else "f32")
     if arith not in ("f32", "split"):
         raise ValueError(f"compat_softmax: arith must be 'f32' or 'split', got {arith!r}")
     if not (_rowmajor(E0) and _rowmajor(X) and X.shape == E0.shape and Mu.shape == (E0.shape[1], E0.shape[1])):

@@ -262,14 +262,15 @@ enum phl_compat_flags { PHL_COMPAT_SOFTMAX = 0, PHL_COMPAT_LOGITS = 1 };
 int phl_compat_softmax(const float *E0_dev, int64_t e0_row_stride, const float *X_dev, int64_t x_row_stride,
                        const float *mu_t_dev, float *out_dev, int64_t out_row_stride, int64_t n, int L, unsigned flags,
                        phl_stream stream);
-/* The same step for 224 < L <= 256 on the bf16 matrix cores (sixteen times the f32 rate) with both operands split
+/* The same step for 128 < L <= 256 (one 256-label tile, padded above L) on the bf16 matrix cores (sixteen times the f32
+ * rate; it pays from L ~ 176 on, below that the f32 kernel is bound by its bytes as well) with both operands split
  * into three bf16 addends each -- x = h + m + l, eight significant bits apiece, exact -- and the six partial products
  * that matter (hH + hM + mH + hL + lH + mM; the dropped ones are below 2^-23 |x mu|).  Products of bf16 pairs are exact
  * in f32 and the matrix cores accumulate in f32: the result carries the rounding of an f32 dot product (measured next
  * to phl_compat_softmax against float64: tests/test_gpu_meanfield.py), at 3/8 of the matrix time, which makes the step
  * the streaming pass over E0, X and Q that its bytes say.  The compatibility matrix is PREPARED once per Mu:
  *   phl_compat_planes_bytes(L)   size of the prepared planes, 0 if the split kernel does not take this L
- *   phl_compat_prepare           mu_t_dev ([256][256], as for phl_compat_softmax) -> planes_dev (16-byte aligned)
+ *   phl_compat_prepare           mu_t_dev ([Lp][Lp], as for phl_compat_softmax) -> planes_dev (16-byte aligned)
  *   phl_compat_softmax_split     the step; same arguments and flags as phl_compat_softmax plus the planes (mu_t_dev
  *                                serves the last n % 128 rows, which run the f32 chain)
  * PHL_ERR_UNSUPPORTED for other L / alignments (the caller stays with phl_compat_softmax). */

@@ -669,6 +669,9 @@ class _AsyncLoopbackDist(_LoopbackDist):
                         o.tensor.view(torch.uint8).copy_(t.view(torch.uint8))
                     else:
                         o.tensor.copy_(t)
+                    # `t` was allocated on the SENDER's communication stream and is read here on another one: without this the
+                    # caching allocator hands its block to the sender's next message while this (delayed) copy has not run yet
+                    t.record_stream(comm)
             done = torch.cuda.Event()
             done.record(comm)
         return [self._Req(done)]

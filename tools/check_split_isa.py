@@ -5,8 +5,9 @@ The kernel loads the next tile's E_0 straight into the accumulators with inline-
 those registers between the load and the wait -- no copy, no spill, no move to AGPRs.  This script compiles the file to
 assembly and verifies, for every instance of the kernel:
   * no scratch, no AGPRs, at most 256 VGPRs;
-  * every instruction that names an accumulator register and is neither a matrix instruction nor a global load / store
-    sits in the prologue (before the first barrier) or in a matrix slot (between a v_mfma and the slot's barrier: the softmax).
+  * in listing order, no instruction names an accumulator register between the hidden load into it and the kernel's own
+    counted wait for those loads (marked CSP_E0_LANDED in the assembly); the loads are unconditional, so they sit in the
+    loop's straight-line code -- if block placement ever moves one behind the last marker the script says so.
 Exit code 0 = ok.  Used by tests/test_cabi_and_host.py."""
 import os, re, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -26,27 +27,39 @@ def check(asm_text):
         if len(acc) != 128:
             problems.append(f'{name}: {len(acc)} accumulator registers found through the hidden loads, expected 128')
             continue
-        barriers, in_matrix = 0, False
-        for i, l in enumerate(lines):
-            t = l.strip()
-            if not t or t[0] in ';.':
-                continue
-            op = t.split()[0]
-            if op == 's_barrier':
-                barriers, in_matrix = barriers + 1, False
-                continue
-            if op.startswith('v_mfma'):
-                in_matrix = True
-                continue
-            if op.startswith('global_load') or op.startswith('global_store'):
-                continue
+        def names(t):
             regs = set()
             for r in re.finditer(r'v\[(\d+):(\d+)\]', t):
                 regs.update(range(int(r.group(1)), int(r.group(2)) + 1))
             for r in re.finditer(r'\bv(\d+)\b', t):
                 regs.add(int(r.group(1)))
-            if regs & acc and barriers > 0 and not in_matrix:
-                problems.append(f'{name}: line {i}: `{t}` touches an accumulator outside a matrix slot')
+            return regs
+
+        def walk(lo, hi, pending):           # listing order; returns the accumulators still in flight at `hi`
+            for i in range(lo, hi):
+                t = lines[i].strip()
+                if 'CSP_E0_LANDED' in t:     # the kernel's own counted wait for those loads
+                    pending = set()
+                    continue
+                if not t or t[0] in ';.':
+                    continue
+                h = re.search(r'global_load_dwordx4 v\[(\d+):(\d+)\], v\d+, s\[', t)
+                if h:
+                    pending = pending | set(range(int(h.group(1)), int(h.group(2)) + 1))
+                    continue
+                if names(t) & pending:
+                    problems.append(f'{name}: line {i}: `{t}` names an accumulator whose hidden load may still be in flight')
+            return pending
+
+        head = [i for i, l in enumerate(lines) if 'Loop Header: Depth=1' in l]
+        mark = [i for i, l in enumerate(lines) if 'CSP_E0_LANDED' in l]
+        if len(head) != 1 or len(mark) != 1 or mark[0] < head[0]:
+            problems.append(f'{name}: expected one tile loop with one CSP_E0_LANDED marker inside (found {len(head)} / {len(mark)})')
+            continue
+        left = walk(0, len(lines), set())
+        # the loads sit in the epilogue half, the wait at the top of the next iteration: around the back edge
+        if walk(head[0], mark[0] + 1, left):
+            problems.append(f'{name}: hidden loads not covered by the marker at the top of the loop')
         meta = asm_text[m.end():m.end() + 6000]
         for key, limit in (('ScratchSize', 0), ('NumAgprs', 0), ('NumVgprs', 256)):
             v = re.search(r'; %s: (\d+)' % key, meta)

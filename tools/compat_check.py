@@ -8,7 +8,7 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 128 * 1024 + 77
 dev = torch.device('cuda')
 g = torch.Generator(device=dev).manual_seed(1)
 bad = 0
-for L in (256, 252, 228):
+for L in (256, 252, 228, 224, 200, 192, 160, 132):
     E0 = torch.rand((n, L), device=dev, generator=g) * 10
     X = torch.rand((n, L), device=dev, generator=g) * 4 - 1
     Mu = (torch.rand((L, L), device=dev, generator=g) - 0.3) * 0.2

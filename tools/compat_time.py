@@ -24,7 +24,7 @@ ms = t(lambda: phl.compat_softmax(E0, X, Mu, out=out, arith='f32'))
 print(f"fused compat_softmax, f32 matrix cores      n={n} L={L}: {ms:.3f} ms  = {2 * n * L * L / ms / 1e9:.1f} TFLOP/s f32, {3 * n * L * 4 / ms / 1e6:.0f} GB/s of compulsory traffic")
 ms_l = t(lambda: phl.compat_softmax(E0, X, Mu, out=out, logits=True, arith='f32'))
 print(f"fused, logits epilogue   : {ms_l:.3f} ms")
-if 224 < L <= 256:
+if 128 < L <= 256:
     ms_s = t(lambda: phl.compat_softmax(E0, X, Mu, out=out, arith='split'))
     print(f"fused compat_softmax, bf16 matrix cores on three-way split operands: {ms_s:.3f} ms  = {3 * n * L * 4 / ms_s / 1e6:.0f} GB/s of compulsory traffic, "
           f"{6 * 2 * n * L * L / ms_s / 1e9:.0f} TFLOP/s bf16")
