@@ -629,8 +629,12 @@ class _AsyncLoopbackDist(_LoopbackDist):
     """_LoopbackDist with RCCL's stream semantics instead of a blocking exchange: a batch is ENQUEUED on the rank's
     communication stream behind the caller's current stream (as ProcessGroupNCCL orders its work), runs late (a spin kernel in
     front of every batch widens every race window), and Req.wait() only makes the caller's current stream wait for it -- the
-    host never blocks.  A schedule that reads a receive buffer, or overwrites a send buffer, without the stream dependency RCCL
-    needs shows up as wrong numbers here."""
+    host never blocks on the GPU.  A schedule that reads a receive buffer, or overwrites a send buffer, without the stream
+    dependency RCCL needs shows up as wrong numbers here.
+    Messages travel through PERSISTENT staging buffers, one per (sender, receiver, position in the batch), handed back and
+    forth with events: nothing is allocated after the first step (an allocation may synchronise the device, which would
+    hide exactly the races this harness is for, and a block freed on one stream while another still reads it is a race of
+    the harness's own)."""
 
     class _Req:
         def __init__(self, ev):
@@ -641,9 +645,13 @@ class _AsyncLoopbackDist(_LoopbackDist):
             return True
 
     def __init__(self, world, delay_cycles=2_000_000):
+        import queue
+
         super().__init__(world)
         self.comm = {}
         self.delay = delay_cycles
+        self.stage = {}                               # (src, dst, k) -> staging tensor
+        self.read_done = {(a, b): queue.Queue() for a in range(world) for b in range(world)}   # receiver -> sender: (k, event)
 
     def batch_isend_irecv(self, ops):
         me = self.local.rank
@@ -655,23 +663,33 @@ class _AsyncLoopbackDist(_LoopbackDist):
         comm.wait_event(ev)
         with torch.cuda.stream(comm):
             torch.cuda._sleep(self.delay)                        # the wire is slow
+            k_of = {}
             for o in ops:
                 if o.op == "isend":
-                    t = o.tensor.clone()
+                    k = k_of[o.peer] = k_of.get(o.peer, -1) + 1
+                    key = (me, o.peer, k)
+                    buf = self.stage.get(key)
+                    if buf is None:
+                        buf = self.stage[key] = torch.empty_like(o.tensor)
+                    else:                                       # its previous content has been read (the receiver says when)
+                        kk, rd = self.read_done[(me, o.peer)].get(timeout=300)
+                        assert kk == k and buf.shape == o.tensor.shape
+                        comm.wait_event(rd)
+                    buf.copy_(o.tensor)
                     e = torch.cuda.Event()
                     e.record(comm)
-                    self.q[(me, o.peer)].put((t, e))
+                    self.q[(me, o.peer)].put((k, buf, e))
             for o in ops:
                 if o.op == "irecv":
-                    t, e = self.q[(o.peer, me)].get(timeout=300)
+                    k, t, e = self.q[(o.peer, me)].get(timeout=300)
                     comm.wait_event(e)
                     if o.tensor.dtype == torch.uint8 or t.dtype == torch.uint8:
                         o.tensor.view(torch.uint8).copy_(t.view(torch.uint8))
                     else:
                         o.tensor.copy_(t)
-                    # `t` was allocated on the SENDER's communication stream and is read here on another one: without this the
-                    # caching allocator hands its block to the sender's next message while this (delayed) copy has not run yet
-                    t.record_stream(comm)
+                    rd = torch.cuda.Event()
+                    rd.record(comm)
+                    self.read_done[(o.peer, me)].put((k, rd))
             done = torch.cuda.Event()
             done.record(comm)
         return [self._Req(done)]
@@ -735,6 +753,7 @@ def test_edge_first_schedule_under_asynchronous_exchange(groups):
 
     if groups is not None:
         return          # (the control is shown once, on the default schedule; whether a race bites depends on timing)
-    bad = run_all(_NoWait(world))
+    # (a wire slow enough that the step's own work cannot cover for the missing wait: ~30 ms per batch against a step of < 1 ms)
+    bad = run_all(_NoWait(world, delay_cycles=60_000_000))
     assert any(not torch.equal(bad[r][s], want[r][s]) for r in range(world) for s in range(steps)), \
         "a missing stream dependency went unnoticed: the asynchronous loopback does not test what it claims"
