@@ -697,7 +697,8 @@ class _AsyncLoopbackDist(_LoopbackDist):
 
 @pytest.mark.parametrize("groups", [None, 2])
 def test_edge_first_schedule_under_asynchronous_exchange(groups):
-    """The default band step (two queues, ghost rows received in place, send buffer packed by the reduction) with an exchange
+    """The band step (groups=None: edge-first, ghost rows received in place, send buffer packed by the reduction; groups=2: the
+    channel groups pipelined) with an exchange
     that behaves like RCCL -- enqueued, late, never blocking the host -- over several back-to-back steps with changing inputs:
     every step's result equals the one computed with the blocking loopback exchange, bit for bit."""
     import threading
@@ -741,19 +742,33 @@ def test_edge_first_schedule_under_asynchronous_exchange(groups):
     for r in range(world):
         for s in range(steps):
             assert torch.equal(got[r][s], want[r][s]), f"rank {r} step {s}: the asynchronous exchange changes the result"
-    # the harness has teeth: the same run with a wait() that does not wait reads ghost rows before they arrive
+    # The harness is what it claims to be -- checked directly rather than through the outcome of a deliberately broken run
+    # (whether a missing wait shows in the numbers depends on which hardware queue the streams happen to share: with the
+    # communication stream's spin kernel ahead of the caller's kernels in one queue the broken run is accidentally ordered):
+    # a batch returns to the host while its exchange is still pending, and only wait() + the stream deliver the data.
+    probe = _AsyncLoopbackDist(2, delay_cycles=60_000_000)      # ~30 ms on the wire
+    seen, perr = {}, []
 
-    class _NoWait(_AsyncLoopbackDist):
-        class _Req:
-            def __init__(self, ev):
-                pass
+    def ping(rank):
+        try:
+            probe.local.rank = rank
+            mine = torch.full((1024,), float(rank + 1), device=dev)
+            theirs = torch.zeros((1024,), device=dev)
+            reqs = probe.batch_isend_irecv([probe.P2POp(probe.isend, mine, 1 - rank), probe.P2POp(probe.irecv, theirs, 1 - rank)])
+            pending = not reqs[0].ev.query()                    # the host is back, the exchange is not done
+            for r in reqs:
+                r.wait()
+            torch.cuda.current_stream().synchronize()
+            seen[rank] = (pending, float(theirs[0]), float(theirs[-1]))
+        except Exception:      # noqa: BLE001
+            import traceback
 
-            def wait(self):
-                return True
+            perr.append(traceback.format_exc())
 
-    if groups is not None:
-        return          # (the control is shown once, on the default schedule; whether a race bites depends on timing)
-    # (a wire slow enough that the step's own work cannot cover for the missing wait: ~30 ms per batch against a step of < 1 ms)
-    bad = run_all(_NoWait(world, delay_cycles=60_000_000))
-    assert any(not torch.equal(bad[r][s], want[r][s]) for r in range(world) for s in range(steps)), \
-        "a missing stream dependency went unnoticed: the asynchronous loopback does not test what it claims"
+    ts = [threading.Thread(target=ping, args=(r,)) for r in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=120)
+    assert not perr, perr
+    assert seen == {0: (True, 2.0, 2.0), 1: (True, 1.0, 1.0)}, seen
