@@ -50,6 +50,46 @@ def compatibility_matrix(compat, labels):
     return compat(labels[:, None], labels[None, :])
 
 
+# ---- label counts the fused kernels cannot take as they are ------------------------------------------------------
+# The reference takes max_disp = w // 6 (crf/depth.py:40): 231 labels at Middlebury's 1390 columns, 341 at 2048 -- rows
+# that are not made of 16-byte pieces.  The device loop then runs on L rounded up (to a multiple of 4; to 256 when that is
+# 32 labels away at most): the extra labels get an energy nothing else reaches, so their probability is exactly 0 in every
+# iteration (exp underflows), their rows and columns of Mu are 0, W maps a zero column to a zero column -- the first L
+# columns evolve exactly as without them.  One padded copy of E_0 on entry, one slice on exit.
+_PAD_ENERGY = 1.0e30
+_mu_pad_cache = {}
+
+
+def _label_pad(L):
+    if L % 4 == 0:
+        return L
+    return 256 if 224 < L < 256 else (L + 3) // 4 * 4
+
+
+def _padded_mu(Mu, Lp, device):
+    """Mu with zero rows / columns up to Lp, cached per (storage, version) like the kernels' own forms of it, plus the
+    Potts-family structure of the ORIGINAL matrix (the padded one no longer shows it)."""
+    import phl
+
+    key = (Mu.data_ptr(), Mu._version, tuple(Mu.shape), tuple(Mu.stride()), Lp, str(device))
+    hit = _mu_pad_cache.get(key)
+    if hit is None:
+        if len(_mu_pad_cache) > 8:
+            _mu_pad_cache.clear()
+        L = Mu.shape[0]
+        mp = torch.zeros((Lp, Lp), dtype=torch.float32, device=device)
+        mp[:L, :L] = Mu.detach().to(device, torch.float32)
+        hit = _mu_pad_cache[key] = (mp, phl._mu_uniform(Mu.detach()) or False, Mu)
+    return hit[0], hit[1]
+
+
+def _pad_energies(E_0, Lp):
+    n, L = E_0.shape
+    E0p = torch.full((n, Lp), _PAD_ENERGY, dtype=torch.float32, device=E_0.device)
+    E0p[:, :L] = E_0
+    return E0p
+
+
 def _fused_ok(E_0, Mu):
     return (E_0.is_cuda and E_0.dtype == torch.float32 and E_0.dim() == 2 and E_0.stride(1) == 1
             and not (torch.is_grad_enabled() and (E_0.requires_grad or Mu.requires_grad)))
@@ -79,6 +119,11 @@ def mean_field_infer(E_0, W, Mu, niters=10):
     if _fused_ok(E_0, Mu):
         import phl
 
+        L = E_0.shape[1]
+        Lp, uniform = _label_pad(L), None
+        if Lp != L:                          # (see _label_pad: w // 6 labels are rarely a multiple of 4)
+            E_0 = _pad_energies(E_0, Lp)
+            Mu, uniform = _padded_mu(Mu, Lp, E_0.device)
         Q = phl.softmax_neg_add(E_0)
         fused = True
         for _ in range(niters):
@@ -92,10 +137,10 @@ def mean_field_infer(E_0, W, Mu, niters=10):
                     continue
                 if not (X.is_cuda and X.dtype == torch.float32 and X.stride(1) == 1):
                     X = X.to(E_0.device, torch.float32).contiguous()
-                Q = phl.compat_softmax(E_0, X, Mu, out=Q)
+                Q = phl.compat_softmax(E_0, X, Mu, out=Q, uniform=uniform)
             else:
                 Q = F.softmax(-(E_0 + (W @ Q) @ Mu), dim=1)
-        return Q
+        return Q if Lp == L else Q[:, :L].contiguous()
     if _staged_ok(E_0, W, Mu):
         return _mean_field_infer_staged(E_0, W, Mu, niters)
     Q = F.softmax(-E_0, dim=1)
@@ -126,12 +171,17 @@ def _mean_field_infer_staged(E_0, W, Mu, niters):
     dev = W.ref.device if W.ref.is_cuda else torch.device("cuda", torch.cuda.current_device())
     lat = phl.lattice_for(W.ref.detach())                 # CPU ref: built on the current device; GPU ref: where it lives
     E0d = phl.to_device(E_0.detach().contiguous(), dev)
+    L = E0d.shape[1]
+    Lp, uniform, Mu = _label_pad(L), None, Mu.detach()
+    if Lp != L:
+        E0d = _pad_energies(E0d, Lp)
+        Mu, uniform = _padded_mu(Mu, Lp, dev)
     Q = phl.softmax_neg_add(E0d)
     X = torch.empty_like(Q) if niters > 0 else None
     for _ in range(niters):
         lat.filter(Q, subtract_input=True, out=X)
-        Q = phl.compat_softmax(E0d, X, Mu.detach(), out=Q)   # (Mu^T is cached per Mu tensor, wherever it lives)
-    return phl.to_host(Q)
+        Q = phl.compat_softmax(E0d, X, Mu, out=Q, uniform=uniform)   # (Mu^T is cached per Mu tensor, wherever it lives)
+    return phl.to_host(Q if Lp == L else Q[:, :L].contiguous())
 
 
 def potts(num_classes):
@@ -234,18 +284,23 @@ def _mean_field_nchw_fused(E0, refs, M, niters):
             e_b, r_b = E0[b], refs[b].detach()
             if dev != home:
                 e_b, r_b = e_b.to(dev, non_blocking=True), r_b.to(dev, non_blocking=True)
-            e0 = torch.empty((n, L), dtype=torch.float32, device=dev)
-            phl.copy2d(e0, e_b.reshape(L, n).t())                         # [L, n] channel-major -> [n, L]
+            Lp = _label_pad(L)               # (label counts that are not a multiple of 4 run padded: see _label_pad)
+            e0 = torch.empty((n, L), dtype=torch.float32, device=dev) if Lp == L else \
+                torch.full((n, Lp), _PAD_ENERGY, dtype=torch.float32, device=dev)
+            phl.copy2d(e0[:, :L], e_b.reshape(L, n).t())                  # [L, n] channel-major -> [n, L]
             lat = phl.lattice_for(r_b.reshape(d, n).t(), device=dev)      # strided [n, d] view, no copy
+            Mb, uniform = (M if M.device == dev else M.to(dev)), None
+            if Lp != L:
+                Mb, uniform = _padded_mu(M, Lp, dev)
             Q = phl.softmax_neg_add(e0)
             for it in range(niters):
                 X = lat.filter(Q, subtract_input=True)
-                Q = phl.compat_softmax(e0, X, M if M.device == dev else M.to(dev), out=Q, logits=it == niters - 1)
+                Q = phl.compat_softmax(e0, X, Mb, out=Q, logits=it == niters - 1, uniform=uniform)
             if dev == home:
-                phl.copy2d(out[b].reshape(L, n).t(), Q)
+                phl.copy2d(out[b].reshape(L, n).t(), Q[:, :L])
             else:
                 back = torch.empty((L, n), dtype=torch.float32, device=dev)
-                phl.copy2d(back.t(), Q)
+                phl.copy2d(back.t(), Q[:, :L])
                 out[b].reshape(L, n).copy_(back, non_blocking=True)
             for t in (e0, Q, e_b, r_b):
                 t.record_stream(st)

@@ -593,7 +593,7 @@ def _mu_uniform(Mu):
     return res
 
 
-def compat_softmax(E0, X, Mu, out=None, logits=False, structure=True, arith=None):
+def compat_softmax(E0, X, Mu, out=None, logits=False, structure=True, arith=None, uniform=None):
     """softmax(-(E0 + X @ Mu), dim=1): the whole non-lattice half of a mean-field iteration
     (crf/crf_module.py:51-52) for fp32 CUDA E0, X [n, L] and Mu [L, L], in one fused MFMA kernel
     (phl_compat_softmax) when L % 4 == 0 and L <= 256 (label counts that are not a multiple of 32 run on a padded
@@ -614,7 +614,12 @@ def compat_softmax(E0, X, Mu, out=None, logits=False, structure=True, arith=None
     if out is None:
         out = torch.empty((n, L), dtype=torch.float32, device=E0.device)
     aligned = L % 4 == 0 and all(t.stride(0) % 4 == 0 and t.data_ptr() % 16 == 0 for t in (X, E0, out))
-    uniform = _mu_uniform(Mu) if (structure and aligned and L <= 1024) else None
+    # uniform: None = look at Mu; (alpha, beta) = the caller knows it is alpha * ones + beta * eye on the labels that matter
+    # (a Mu padded with zero rows / columns for labels of probability 0: crf_module._padded_mu); False = it is not
+    if uniform is None:
+        uniform = _mu_uniform(Mu) if (structure and aligned and L <= 1024) else None
+    elif uniform is False or not (structure and aligned and L <= 1024):
+        uniform = None
     if uniform is not None:                      # Potts family: X @ Mu = alpha rowsum(X) + beta X, one streaming pass
         with torch.cuda.device(E0.device):
             _check(load_library().phl_uniform_compat_softmax(

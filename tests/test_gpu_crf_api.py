@@ -679,3 +679,67 @@ def test_cpu_tensor_call_shape_edge_cases(L, niters):
     # float64 operands are not the staged path's business: the reference's loop shape, still correct
     got64 = cm.mean_field_infer(E0, LatticeGaussian(ref), Mu.double(), niters) if niters == 0 else None
     assert got64 is None or got64.shape == E0.shape
+
+
+@pytest.mark.parametrize("L,potts_mu", [(231, False), (50, False), (253, True), (341, False), (7, True)])
+def test_mean_field_label_counts_that_are_not_a_multiple_of_four(L, potts_mu):
+    """The reference takes max_disp = w // 6 labels (crf/depth.py:40: 231 at Middlebury's 1390 columns, 341 at 2048): the
+    device loop runs those padded (crf_module._label_pad: extra labels with an unreachable energy, zero rows / columns of
+    Mu) -- results against the same iteration written out with torch ops on the unpadded tensors, for the flat API on GPU
+    tensors, the notebook's CPU-tensor call shape and CRFasRNN's NCHW path; the padded run takes the fused kernels."""
+    import crf.crf_module as cm
+    import phl
+    from crf.gaussian_matrix import LatticeGaussian
+
+    dev = torch.device("cuda")
+    g = torch.Generator(device="cpu").manual_seed(5 * L)
+    h, w, niters = 24, 40, 3
+    n = h * w
+    yy, xx = torch.meshgrid(torch.arange(h, dtype=torch.float32), torch.arange(w, dtype=torch.float32), indexing="ij")
+    ref = torch.stack([yy / 6, xx / 6, torch.rand((h, w), generator=g) * 3], dim=-1).reshape(n, 3)
+    E0 = torch.rand((n, L), generator=g) * 8
+    labels = torch.arange(L, dtype=torch.float32)
+    Mu = (1 - torch.eye(L)) * 0.7 if potts_mu else cm.compatibility_matrix(lambda a, b: cm.charbonneir(a, b, 2.0), labels) * 0.05
+    W = LatticeGaussian(ref.to(dev))
+    Q = torch.softmax(-E0.to(dev), dim=1)
+    for _ in range(niters):                                  # crf_module.py:49-52 on the unpadded tensors
+        Q = torch.softmax(-(E0.to(dev) + (W @ Q) @ Mu.to(dev)), dim=1)
+    want = Q
+    calls = []
+    real = phl.compat_softmax
+
+    def spy(E0_, X_, Mu_, **k):
+        calls.append(E0_.shape[1])
+        return real(E0_, X_, Mu_, **k)
+
+    cm_phl = phl
+    try:
+        cm_phl.compat_softmax = spy
+        got = cm.mean_field_infer(E0.to(dev), W, Mu.to(dev), niters)
+        got_cpu = cm.mean_field_infer(E0, LatticeGaussian(ref), Mu, niters)          # CPU tensors: staged once, device loop
+    finally:
+        cm_phl.compat_softmax = real
+    assert got.shape == (n, L) and got.is_contiguous() and not got_cpu.is_cuda and got_cpu.shape == (n, L)
+    assert calls and all(c % 4 == 0 and c >= L for c in calls), calls
+    for name, res in (("gpu tensors", got), ("cpu tensors", got_cpu.to(dev))):
+        err = float((res - want).abs().max())
+        print(f"[measured] mean field at L={L} ({name}): max abs diff to the unpadded torch iteration {err:.2e}")
+        assert err <= 4e-5           # two fp32 evaluations of energies of a few hundred (measured 5e-7 ... 1.5e-5)
+        assert float((res.sum(1) - 1).abs().max()) <= 1e-5
+    # NCHW: CRFasRNN over the lattice W returns the logits of the last iteration
+    if L <= 64:
+        mu_mod = cm.charb(2.0)
+        crf = cm.CRFasRNN(mu_mod, niters=2, lattice=True).to(dev)
+        refs = ref.t().reshape(1, 3, h, w).to(dev)
+        logits = -E0.t().reshape(1, L, h, w).to(dev)
+        with torch.no_grad():
+            fused = crf(refs, logits)
+            M = mu_mod.matrix(L, None, dev)
+            Wb = LatticeGaussian(ref.to(dev))
+            e0 = E0.to(dev)
+            Qb = torch.softmax(-e0, dim=1)
+            for _ in range(2):
+                Eb = e0 + (Wb @ Qb) @ M
+                Qb = torch.softmax(-Eb, dim=1)
+        ref_logits = (-Eb).t().reshape(1, L, h, w)
+        assert float((fused - ref_logits).abs().max()) <= 1e-4 * float(ref_logits.abs().max())
