@@ -760,7 +760,9 @@ int phl_slice(phl_lattice *lat, const float *vert, int vd, float *out, int64_t o
     return phl_launch_slice(lat, vert, vd, out, out_rs, sub, sub_rs, flags, (hipStream_t)st);
 }
 
-static int filter_on(phl_lattice *lat, phl_workspace *w, const float *src, int vd, int64_t src_rs, int64_t src_cs, float *out,
+// vdw: the width the kernels run at -- vd, or vd rounded up to a multiple of 4 when both sides are staged for that (the
+// extra channels hold whatever the staging buffer held: channels never mix, and they are not copied out)
+static int filter_on(phl_lattice *lat, phl_workspace *w, const float *src, int vd_user, int vdw, int64_t src_rs, int64_t src_cs, float *out,
                      int64_t out_rs, int64_t out_cs, unsigned flags, bool stage_src, bool stage_dst, hipStream_t st)
 {
     const int64_t n = lat->n;
@@ -769,15 +771,16 @@ static int filter_on(phl_lattice *lat, phl_workspace *w, const float *src, int v
     float *out_eff = out;
     int64_t out_eff_rs = out_rs;
     int rc = PHL_OK;
+    const int vd = vdw;
     if (stage_src) {
-        rc = phl_launch_copy2d(src, src_rs, src_cs, w->stage_in, vd, 1, n, vd, st);
+        rc = phl_launch_copy2d(src, src_rs, src_cs, w->stage_in, vdw, 1, n, vd_user, st);
         if (rc) return rc;
         src_eff = w->stage_in;
-        src_eff_rs = vd;
+        src_eff_rs = vdw;
     }
     if (stage_dst) {
         out_eff = w->stage_out;
-        out_eff_rs = vd;
+        out_eff_rs = vdw;
     }
     if (use_tiled_splat(lat, vd, flags, src_eff, w->buf[0], src_eff_rs)) rc = phl_launch_splat_tiled(lat, src_eff, src_eff_rs, vd, w->buf[0], w->partial, st);
     else rc = phl_launch_splat(lat, src_eff, src_eff_rs, vd, w->buf[0], st);
@@ -791,7 +794,7 @@ static int filter_on(phl_lattice *lat, phl_workspace *w, const float *src, int v
     else
         rc = phl_launch_slice(lat, w->buf[cur], vd, out_eff, out_eff_rs, sub, src_eff_rs, flags, st);
     if (rc) return rc;
-    if (stage_dst) rc = phl_launch_copy2d(w->stage_out, vd, 1, out, out_rs, out_cs, n, vd, st);
+    if (stage_dst) rc = phl_launch_copy2d(w->stage_out, vdw, 1, out, out_rs, out_cs, n, vd_user, st);
     return rc;
 }
 
@@ -808,13 +811,28 @@ int phl_filter(phl_lattice *lat, const float *src, int vd, int64_t src_rs, int64
 
     // pixel-major rows are consumed in place; anything else (e.g. the [n,L] view of an NCHW
     // tensor, gaussian_matrix.py:348) is staged through one coalesced transpose
-    const bool stage_src = (src_cs != 1) && vd > 1;
-    const bool stage_dst = (out_cs != 1) && vd > 1;
+    bool stage_src = (src_cs != 1) && vd > 1;
+    bool stage_dst = (out_cs != 1) && vd > 1;
+    // Rows the chunk kernels cannot take -- a channel count that is not a multiple of 4 (the reference's max_disp = w // 6:
+    // 231 at 1390 columns), a row stride or base address off the 16-byte grid (a column slice of a wider tensor) -- used to
+    // fall back to the gather kernels (2.4x slower at 1390x1110x231).  From 9 channels on they are staged instead: one
+    // copy into / out of a buffer with 16-byte rows, the kernels run at the width rounded up to a multiple of 4.
+    int vdw = vd;
+    if (vd > 8 && !(flags & (PHL_FILTER_EXACT | PHL_FILTER_NO_TILES))) {
+        auto off_grid = [](const void *p, int64_t rs) { return (reinterpret_cast<uintptr_t>(p) & 15) != 0 || rs % 4 != 0; };
+        if (vd % 4) {
+            vdw = (vd + 3) & ~3;
+            stage_src = stage_dst = true;
+        } else {
+            if (!stage_src && off_grid(src, src_rs)) stage_src = true;
+            if (!stage_dst && off_grid(out, out_rs)) stage_dst = true;
+        }
+    }
     phl_workspace *w = nullptr;
-    int rc = phl_ws_acquire(lat, st, lat->M * (int64_t)vd, need_partial(lat, vd, flags),
-                            (stage_src || stage_dst) ? n * (int64_t)vd : 0, &w);
+    int rc = phl_ws_acquire(lat, st, lat->M * (int64_t)vdw, need_partial(lat, vdw, flags),
+                            (stage_src || stage_dst) ? n * (int64_t)vdw : 0, &w);
     if (rc) return rc;
-    rc = filter_on(lat, w, src, vd, src_rs, src_cs, out, out_rs, out_cs, flags, stage_src, stage_dst, st);
+    rc = filter_on(lat, w, src, vd, vdw, src_rs, src_cs, out, out_rs, out_cs, flags, stage_src, stage_dst, st);
     phl_ws_release(lat, w, st, false);
     return rc;
 }

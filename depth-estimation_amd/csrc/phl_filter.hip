@@ -366,6 +366,34 @@ __global__ __launch_bounds__(256) void k_copy2d(const float *__restrict__ src, i
     }
 }
 
+// Both sides pixel-major (unit column stride), any row strides and any 4-byte-aligned base: rows copied in 16-byte pieces
+// that need no 16-byte alignment (gfx950 takes dword-aligned dwordx4 accesses) -- the repacking of rows that are off the
+// 16-byte grid (phl_filter: channel counts that are not a multiple of 4, column slices) runs at the streaming rate instead
+// of through the 64x64 transpose tile.  A wave takes four rows at a time, a lane one piece of each.
+struct __attribute__((packed, aligned(4))) phl_f4u { float x, y, z, w; };
+__global__ __launch_bounds__(256) void k_copy_rows(const float *__restrict__ src, int64_t srs, float *__restrict__ dst, int64_t drs,
+                                                   int64_t rows, int cols)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nw = (int64_t)gridDim.x * 4;
+    const int pieces = cols >> 2, rem = cols & 3;
+    for (int64_t r0 = wave * 4; r0 < rows; r0 += nw * 4) {
+        for (int c = lane; c < pieces; c += 64) {
+            phl_f4u v[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+                if (r0 + u < rows) v[u] = *reinterpret_cast<const phl_f4u *>(src + (r0 + u) * srs + 4 * c);
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+                if (r0 + u < rows) *reinterpret_cast<phl_f4u *>(dst + (r0 + u) * drs + 4 * c) = v[u];
+        }
+        if (lane < 4 * rem) {                    // the last cols % 4 floats of the four rows
+            const int u = lane / rem, c = 4 * pieces + lane % rem;
+            if (r0 + u < rows) dst[(r0 + u) * drs + c] = src[(r0 + u) * srs + c];
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // ------------------------------------------------------------------------------------------
 // Row-band exchange helpers (phl/rowtile.py): pack the boundary vertices' rows into one send
@@ -599,6 +627,13 @@ int phl_launch_copy2d(const float *src, int64_t srs, int64_t scs, float *dst, in
                       int cols, hipStream_t st)
 {
     if (rows == 0 || cols == 0) return PHL_OK;
+    if (scs == 1 && dcs == 1 && cols >= 4) {     // rows to rows: no transpose tile
+        int64_t blocks = (rows + 15) / 16;
+        if (blocks > 256 * 32) blocks = 256 * 32;
+        hipLaunchKernelGGL(k_copy_rows, dim3((unsigned)blocks), dim3(256), 0, st, src, srs, dst, drs, rows, cols);
+        PHL_HIP(hipGetLastError());
+        return PHL_OK;
+    }
     dim3 grid((unsigned)((rows + 63) / 64), (unsigned)((cols + 63) / 64));
     hipLaunchKernelGGL(k_copy2d, grid, dim3(256), 0, st, src, srs, scs, dst, drs, dcs, rows, cols);
     PHL_HIP(hipGetLastError());

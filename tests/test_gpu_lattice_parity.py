@@ -960,3 +960,42 @@ def test_side_stream_of_the_table_replay_is_kept_per_device(phl):
     t.start()
     t.join()
     assert seen["count"] == seen["devs"], seen
+
+
+@pytest.mark.parametrize("vd", [9, 10, 30, 50, 231])
+def test_widths_and_rows_off_the_sixteen_byte_grid(phl, vd):
+    """Value tensors the chunk kernels cannot take as they are -- a channel count that is not a multiple of 4 (the reference's
+    max_disp = w // 6: 231 at 1390 columns), rows whose stride or base address is off the 16-byte grid (a column slice of a
+    wider tensor) -- are staged into 16-byte rows and run on the chunk kernels at the width rounded up (phl_filter; they used
+    to fall back to the gather kernels): against the CPU oracle, with and without the fused subtraction, into an unaligned
+    output view, and equal to the gather kernels' result within rounding."""
+    from oracle import phl_oracle as po
+
+    rng = np.random.default_rng(100 + vd)
+    h, w, d = 40, 56, 5
+    n = h * w
+    yy, xx = np.mgrid[:h, :w].astype(np.float32)
+    ref = np.stack([yy / 5, xx / 5] + [rng.random((h, w), dtype=np.float32) * 2 for _ in range(d - 2)], axis=-1).reshape(n, d)
+    src = rng.standard_normal((n, vd)).astype(np.float32)
+    want = po.oracle_filter(src, ref)
+    dev = torch.device("cuda")
+    Lat = phl.Lattice(torch.from_numpy(ref).to(dev))
+    x = torch.from_numpy(src).to(dev)
+    got = Lat.filter(x)
+    assert scaled_err(got.cpu().numpy(), want) <= 1e-5
+    assert scaled_err(Lat.filter(x, no_tiles=True).cpu().numpy(), want) <= 1e-5
+    assert np.array_equal(Lat.filter(x, exact=True).cpu().numpy().view(np.uint32), want.view(np.uint32))
+    assert scaled_err(Lat.filter(x, subtract_input=True).cpu().numpy(), want - src) <= 1e-5
+    # a column slice of a wider tensor (base address 4 bytes off the grid), and an output view of the same kind
+    wide = torch.zeros((n, vd + 3), device=dev)
+    wide[:, 1:vd + 1] = x
+    out_wide = torch.full((n, vd + 5), -3.0, device=dev)
+    res = Lat.filter(wide[:, 1:vd + 1], out=out_wide[:, 2:vd + 2])
+    assert scaled_err(res.cpu().numpy(), want) <= 1e-5
+    assert float(out_wide[:, :2].min()) == -3.0 and float(out_wide[:, vd + 2:].max()) == -3.0      # nothing written beside the view
+    # repeatable (the staging buffers' extra channels never reach the result)
+    assert torch.equal(Lat.filter(x), got)
+    if vd % 4 == 2:       # a multiple of 4 channels inside a misaligned slice
+        v4 = vd - 2
+        res4 = Lat.filter(wide[:, 1:v4 + 1])
+        assert scaled_err(res4.cpu().numpy(), want[:, :v4]) <= 1e-5
