@@ -691,6 +691,8 @@ def main():
     mean_field = None
     if args.mean_field and rank == 0 and not rowtiled:
         mean_field = mean_field_iteration(torch, phl, lat, src, L, device)
+        if args.workload == "c3":
+            mean_field["reference_label_count"] = reference_label_count(torch, device)
     if args.mean_field and rowtiled and L % 4 == 0:
         # the whole mean-field iteration on row bands: only W @ Q exchanges anything, the compatibility product and the
         # softmax are per pixel -- every rank on its own rows (collective: every rank runs it)
@@ -1001,6 +1003,34 @@ def backward_pass(torch, lat, src, ref, workload):
     return {"ms": round(ms, 3), "workload": workload, "what": "grad wrt source and features, two fused passes of wide splat -> blur -> contracting slice",
             "wide_operand_GB_the_reference_formulation_would_move": round(2 * n * 2 * L * (1 + ref.shape[1]) * 4 / 1e9, 1),
             "lattice_plus_workspaces_GB": round(lat.device_bytes / 1e9, 2)}
+
+
+def reference_label_count(torch, device):
+    """The reference takes max_disp = w // 6 labels (crf/depth.py:40): 231 at configs[1]'s 1390 columns -- not a multiple of 4,
+    i.e. rows that are not made of 16-byte pieces.  mean_field_infer runs such counts padded with labels of probability
+    exactly 0 (crf_module._label_pad); timed here next to the neighbouring multiple of 4.  Extra key."""
+    import crf.crf_module as cm
+    from crf.gaussian_matrix import LatticeGaussian
+
+    H, W, _, _ = WORKLOADS["c2"]
+    ref = torch.from_numpy(synthetic_features(H, W).reshape(-1, 5)).to(device)
+    Wop = LatticeGaussian(ref)
+    res = {"workload": f"{W}x{H}, d=5, 5 mean-field iterations (mean_field_infer on device tensors)"}
+    for L in (W // 6, (W // 6 + 3) // 4 * 4):
+        E0 = torch.rand((H * W, L), device=device, generator=torch.Generator(device=device).manual_seed(L)) * 10.0
+        Mu = cm.compatibility_matrix(lambda a, b: cm.charbonneir(a, b, 3.0), torch.arange(L, dtype=torch.float32, device=device))
+        for _ in range(2):
+            cm.mean_field_infer(E0, Wop, Mu, 5)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(3):
+            Q = cm.mean_field_infer(E0, Wop, Mu, 5)
+        e1.record()
+        torch.cuda.synchronize()
+        assert Q.shape == (H * W, L)
+        res[f"L={L}_ms"] = round(e0.elapsed_time(e1) / 3, 2)
+        del E0, Q
+    return res
 
 
 def mean_field_iteration(torch, phl, lat, Q, L, device):
