@@ -116,6 +116,12 @@ struct phl_reftable_query {
                                     const std::vector<int32_t> &stale_clean, uint64_t cap,
                                     const std::vector<int32_t> &check) = 0;
     virtual int probe_paths_all_ok() = 0;
+    // The replay needs the key of a handful of vertices only (its hash: which half of a doubled table the key lands in).
+    // With the keys on the host (keys_clean != NULL in phl_reference_table_fast) it hashes them itself; without, it asks:
+    virtual uint64_t key_hash(int clean_vid) { (void)clean_vid; return 0; }
+    // ... and it announces the vid_at() / key_hash() questions it is likely to ask (candidate, or a vertex already known:
+    // known[i] >= 0), so that an implementation with a slow round trip can answer them in one
+    virtual void prefetch(const std::vector<int64_t> &cands, const std::vector<int32_t> &known) { (void)cands; (void)known; }
     int probe_paths_do_not_wrap(int64_t n_clean, const std::vector<int32_t> &extra_clean, const std::vector<int32_t> &stale_clean,
                                 uint64_t cap, const std::vector<int32_t> &check)
     {

@@ -427,11 +427,28 @@ static int reference_table_fast_impl(const int16_t *keys_clean, const int32_t *e
     struct extra_t { int64_t e; int clean; int32_t id; };
     std::vector<extra_t> extras;                         // creations that are not clean first touches, ascending e
     auto hash_of = [&](int clean) {
+        if (!keys_clean) return q.key_hash(clean);       // keys left on the device: asked for (a handful of vertices)
         uint64_t h = 0;
         const int16_t *k = keys_clean + (size_t)clean * d;
         for (int i = 0; i < d; i++) { h += (uint64_t)(int64_t)k[i]; h *= 2531011; }
         return h;
     };
+    {
+        // The questions of an undisturbed replay are known in advance: at the doubling behind the T-th creation the
+        // candidate right after that creation's first touch, for up to three extra creations before it.  One round trip.
+        std::vector<int64_t> pc;
+        std::vector<int32_t> pk;
+        for (uint64_t c = (uint64_t)1 << 15; (int64_t)(c / 2 - 1) <= M + 8 && pc.size() < 28; c <<= 1)
+            for (int x = 0; x < 4; x++) {
+                const int64_t idx = (int64_t)(c / 2 - 1) - 1 - x;
+                if (idx < 0 || idx >= M) continue;
+                const int64_t e = (int64_t)efirst[idx] + 1;
+                if (e >= N) continue;
+                pc.push_back(e);
+                pk.push_back(idx + 1 < M && efirst[idx + 1] == e ? (int32_t)(idx + 1) : -1);
+            }
+        if (!pc.empty()) q.prefetch(pc, pk);
+    }
     auto clean_before = [&](int64_t e) { return (int64_t)(std::lower_bound(efirst, efirst + M, (int32_t)std::min<int64_t>(e, 0x7FFFFFFF)) - efirst); };
     // reference id of clean vertex v: v plus the extra creations before its first touch
     auto ref_id = [&](int v) {
@@ -682,6 +699,61 @@ namespace {
 __global__ void k_vid_at(const int *__restrict__ table, const int *__restrict__ slot_of, int e, int *__restrict__ out)
 {
     *out = -(table[slot_of[e]] + 1);
+}
+
+// several questions in one launch: the clean vertex of a candidate (or a vertex the host knows already) and the hash of
+// its key (permutohedral.h:109-116), written where the host reads them
+struct vid_hash_q {
+    int n;
+    int cand[32], known[32];
+};
+__global__ void k_vid_hash_many(const int *__restrict__ table, const int *__restrict__ slot_of, const int16_t *__restrict__ vkeys,
+                                int d, vid_hash_q qs, int *__restrict__ out /* [n][3]: vertex, hash lo, hash hi */)
+{
+    const int i = threadIdx.x;
+    if (i >= qs.n) return;
+    const int v = qs.known[i] >= 0 ? qs.known[i] : -(table[slot_of[qs.cand[i]]] + 1);
+    unsigned long long h = 0;
+    if (v >= 0)
+        for (int k = 0; k < d; k++) {
+            h += (unsigned long long)(long long)vkeys[(size_t)v * d + k];
+            h *= 2531011ull;
+        }
+    out[3 * i] = v;
+    out[3 * i + 1] = (int)(unsigned)(h & 0xFFFFFFFFull);
+    out[3 * i + 2] = (int)(unsigned)(h >> 32);
+}
+
+// The questions of an undisturbed replay, asked before the host has seen anything: slot (j, x) = the doubling behind the
+// (2^(14+j) - 1)-th creation with x extra creations before it -> {candidate right after that creation's first touch, its
+// clean vertex, hash of that vertex's key} (candidate -1: no such doubling).  The host reads them with the first touches.
+constexpr int SPEC_J = 8, SPEC_X = 4;
+__global__ void k_spec_many(const int *__restrict__ efirst, int M, int N, const int *__restrict__ table,
+                            const int *__restrict__ slot_of, const int16_t *__restrict__ vkeys, int d, int *__restrict__ out /* [J*X][4] */)
+{
+    const int i = threadIdx.x;
+    if (i >= SPEC_J * SPEC_X) return;
+    const int j = i / SPEC_X, x = i % SPEC_X;
+    const long long T = ((long long)1 << (14 + j)) - 1;
+    const long long idx = T - 1 - x;
+    int e = -1, v = -1;
+    unsigned long long h = 0;
+    if (T <= (long long)M + 8 && idx >= 0 && idx < M) {
+        const long long ee = (long long)efirst[idx] + 1;
+        if (ee < N) {
+            e = (int)ee;
+            v = (idx + 1 < M && efirst[idx + 1] == e) ? (int)(idx + 1) : -(table[slot_of[e]] + 1);
+            if (v >= 0)
+                for (int k = 0; k < d; k++) {
+                    h += (unsigned long long)(long long)vkeys[(size_t)v * d + k];
+                    h *= 2531011ull;
+                }
+        }
+    }
+    out[4 * i] = e;
+    out[4 * i + 1] = v;
+    out[4 * i + 2] = (int)(unsigned)(h & 0xFFFFFFFFull);
+    out[4 * i + 3] = (int)(unsigned)(h >> 32);
 }
 
 // first candidate after `after` with the same key as candidate e_first (= the same table slot)
@@ -977,15 +1049,64 @@ __global__ void k_cluster_verdict(const int *__restrict__ last_empty, cl_homes h
 
 struct device_query : phl_reftable_query {
     const int16_t *vkeys_dev = nullptr;      // clean keys, clean order (device)
-    const int16_t *keys_host = nullptr;      // the same on the host
+    const int16_t *keys_host = nullptr;      // the same on the host, or null: hashes are fetched (key_hash)
     int d = 0;
     int *hist = nullptr;                     // [max capacity] device
     int *small = nullptr;                    // [256] device ints: homes in, results out
-    uint64_t hash_of(int clean) const
+    std::unordered_map<int, uint64_t> hcache;            // clean vertex -> hash of its key
+    std::unordered_map<int64_t, int> vcache;             // candidate -> clean vertex
+    int *answers = nullptr;                              // [32][3] ints the device can write and the host can read, or null
+    uint64_t hash_of(int clean)
     {
+        if (!keys_host) return key_hash(clean);
         uint64_t h = 0;
         for (int i = 0; i < d; i++) { h += (uint64_t)(int64_t)keys_host[(size_t)clean * d + i]; h *= 2531011; }
         return h;
+    }
+    // one launch, one synchronisation for up to 32 questions
+    bool ask(const vid_hash_q &qs)
+    {
+        int host[96];
+        int *dst = answers ? answers : small;
+        hipLaunchKernelGGL(k_vid_hash_many, dim3(1), dim3(32), 0, st, table, slot_of, vkeys_dev, d, qs, dst);
+        hipError_t r = hipGetLastError();
+        const int *res = answers;
+        if (r == hipSuccess && !answers) {
+            r = hipMemcpyAsync(host, small, sizeof(int) * 3 * (size_t)qs.n, hipMemcpyDeviceToHost, st);
+            res = host;
+        }
+        if (r == hipSuccess) r = hipStreamSynchronize(st);
+        if (r != hipSuccess) { err = r; return false; }
+        for (int i = 0; i < qs.n; i++) {
+            const int v = res[3 * i];
+            if (qs.known[i] < 0) vcache[qs.cand[i]] = v;
+            if (v >= 0) hcache[v] = (uint64_t)(unsigned)res[3 * i + 1] | ((uint64_t)(unsigned)res[3 * i + 2] << 32);
+        }
+        return true;
+    }
+    void prefetch(const std::vector<int64_t> &cands, const std::vector<int32_t> &known) override
+    {
+        if (!small || !table || !slot_of) return;
+        vid_hash_q qs;
+        qs.n = 0;
+        for (size_t i = 0; i < cands.size() && qs.n < 32; i++) {
+            if (known[i] >= 0 ? hcache.count(known[i]) != 0 : vcache.count(cands[i]) != 0) continue;     // answered already
+            qs.cand[qs.n] = (int)cands[i];
+            qs.known[qs.n] = known[i];
+            qs.n++;
+        }
+        if (qs.n) (void)ask(qs);
+    }
+    uint64_t key_hash(int clean) override
+    {
+        auto it = hcache.find(clean);
+        if (it != hcache.end()) return it->second;
+        vid_hash_q qs;
+        qs.n = 1;
+        qs.cand[0] = 0;
+        qs.known[0] = clean;
+        if (!small || !ask(qs)) return 0;
+        return hcache[clean];
     }
     // answers land in `verdicts` (pinned host memory where there is some, else device memory read back at the end)
     int *verdicts = nullptr;                 // [MAX_Q]
@@ -1056,6 +1177,17 @@ struct device_query : phl_reftable_query {
     int *mailbox = nullptr;                              // pinned host int (null: answers come back through pageable memory)
     int vid_at(int64_t e) override
     {
+        {
+            auto it = vcache.find(e);
+            if (it != vcache.end()) return it->second;
+        }
+        if (!keys_host && small) {           // its key's hash is the next thing the replay wants: both in one round trip
+            vid_hash_q qs;
+            qs.n = 1;
+            qs.cand[0] = (int)e;
+            qs.known[0] = -1;
+            return ask(qs) ? vcache[e] : -1;
+        }
         int v = -1;
         int *dst = mailbox ? mailbox : &v;
         hipLaunchKernelGGL(k_vid_at, dim3(1), dim3(1), 0, st, table, slot_of, (int)e, scratch);
@@ -1118,13 +1250,35 @@ int phl_apply_reference_table(phl_lattice *lat, hipStream_t st, void *arena, siz
     if (!efirst_dev) { phl_set_error("reference-table replay: first touches missing"); return PHL_ERR_INVALID; }
     PHL_HIP(tmp.get(&scratch, 1));
     // (pinned staging where there is some: a 4 MB copy into pageable memory goes through a bounce buffer)
+    // The first touches come to the host (the replay searches them); the KEYS stay on the device unless the simulation or
+    // a long list of extra creations needs them: the analytic replay wants the hash of a handful of keys only and asks
+    // for those (device_query::key_hash / prefetch) -- 3 of the 4.2 MB this copy used to move at C3.
     std::vector<int16_t> keys_pageable;
     std::vector<int32_t> efirst_pageable;
-    int16_t *keys = (int16_t *)phl_pinned_alloc(sizeof(int16_t) * (size_t)M * d);
+    int16_t *keys = nullptr;
     int32_t *efirst = (int32_t *)phl_pinned_alloc(sizeof(int32_t) * (size_t)M);
-    if (!keys) { keys_pageable.resize((size_t)M * d); keys = keys_pageable.data(); }
     if (!efirst) { efirst_pageable.resize((size_t)M); efirst = efirst_pageable.data(); }
-    PHL_HIP(hipMemcpyAsync(keys, lat->vkeys, sizeof(int16_t) * (size_t)M * d, hipMemcpyDeviceToHost, st));
+    const char *envf = getenv("PHL_REPLAY_FAST");
+    const bool try_fast = !(envf && atoi(envf) == 0);
+    auto fetch_keys = [&]() -> hipError_t {      // (blocking; vkeys still holds the clean keys until the result is applied)
+        if (keys) return hipSuccess;
+        keys = (int16_t *)phl_pinned_alloc(sizeof(int16_t) * (size_t)M * d);
+        if (!keys) { keys_pageable.resize((size_t)M * d); keys = keys_pageable.data(); }
+        hipError_t r = hipMemcpyAsync(keys, lat->vkeys, sizeof(int16_t) * (size_t)M * d, hipMemcpyDeviceToHost, st);
+        if (r == hipSuccess) r = hipStreamSynchronize(st);
+        return r;
+    };
+    if (!try_fast) {
+        keys = (int16_t *)phl_pinned_alloc(sizeof(int16_t) * (size_t)M * d);
+        if (!keys) { keys_pageable.resize((size_t)M * d); keys = keys_pageable.data(); }
+        PHL_HIP(hipMemcpyAsync(keys, lat->vkeys, sizeof(int16_t) * (size_t)M * d, hipMemcpyDeviceToHost, st));
+    }
+    // the replay's likely questions, answered on the device while the first touches travel (k_spec_many)
+    int *spec = (try_fast && lat->bt_slot_of && lat->bt_table) ? (int *)phl_pinned_alloc(sizeof(int) * 4 * SPEC_J * SPEC_X) : nullptr;
+    if (spec) {
+        hipLaunchKernelGGL(k_spec_many, dim3(1), dim3(64), 0, st, efirst_dev, (int)M, N, lat->bt_table, lat->bt_slot_of, lat->vkeys, d, spec);
+        PHL_HIP(hipGetLastError());
+    }
     PHL_HIP(hipMemcpyAsync(efirst, efirst_dev, sizeof(int32_t) * (size_t)M, hipMemcpyDeviceToHost, st));
     if (under_replay) {
         // wait for the copies only: what the caller launches now runs while the host replays
@@ -1140,7 +1294,7 @@ int phl_apply_reference_table(phl_lattice *lat, hipStream_t st, void *arena, siz
     } else {
         PHL_HIP(hipStreamSynchronize(st));
     }
-    if (dbg) fprintf(stderr, "[phl] reference table: keys + first touches on the host after %.2f ms\n", since());
+    if (dbg) fprintf(stderr, "[phl] reference table: first touches%s on the host after %.2f ms\n", keys ? " + keys" : "", since());
 
     device_query q;
     if (!lat->bt_slot_of || !lat->bt_table) { phl_set_error("reference-table replay: build tables missing"); return PHL_ERR_INVALID; }
@@ -1154,11 +1308,18 @@ int phl_apply_reference_table(phl_lattice *lat, hipStream_t st, void *arena, siz
     q.vkeys_dev = lat->vkeys;
     q.keys_host = keys;
     q.d = d;
+    q.answers = (int *)phl_pinned_alloc(sizeof(int) * 96);
+    if (spec)
+        for (int i = 0; i < SPEC_J * SPEC_X; i++) {
+            const int e = spec[4 * i], v = spec[4 * i + 1];
+            if (e < 0) continue;
+            q.vcache[e] = v;
+            if (v >= 0) q.hcache[v] = (uint64_t)(unsigned)spec[4 * i + 2] | ((uint64_t)(unsigned)spec[4 * i + 3] << 32);
+        }
     phl_reftable_result R;
     // the analytic replay first (counting, no table: phl_reference_table_fast); the simulation where it does not apply
     int rc = 1;
-    const char *envf = getenv("PHL_REPLAY_FAST");
-    if (!(envf && atoi(envf) == 0)) {
+    if (try_fast) {
         const uint64_t cap_max = replay_cap_max(M);
         q.verdicts = (int *)phl_pinned_alloc(sizeof(int) * device_query::MAX_Q);
         q.verdicts_on_host = q.verdicts != nullptr;
@@ -1171,12 +1332,19 @@ int phl_apply_reference_table(phl_lattice *lat, hipStream_t st, void *arena, siz
         if (dbg) fprintf(stderr, "[phl] reference table: analytic replay %s after %.2f ms\n", rc == 0 ? "done" : (rc == 1 ? "not applicable" : "failed"), since());
         if (rc == 1) R = phl_reftable_result();
     }
-    if (rc == 1) rc = phl_reference_table_sim(keys, efirst, M, d, N, q, R);
+    if (rc == 1) {
+        PHL_HIP(fetch_keys());
+        q.keys_host = keys;
+        rc = phl_reference_table_sim(keys, efirst, M, d, N, q, R);
+    }
     if (q.err != hipSuccess) return phl_hip_fail(q.err, "reference-table device query", __FILE__, __LINE__);
     if (rc) { phl_set_error("reference-table replay failed (inconsistent first-touch list)"); return rc; }
     if ((int)R.hidden.size() > PHL_MAX_HIDDEN) { phl_set_error("reference-table replay: too many duplicate vertices"); return PHL_ERR_UNSUPPORTED; }
 
-    if (R.compact && R.ex_id.size() > (size_t)PHL_MAX_EXTRAS) phl_reftable_expand(keys, M, d, R);
+    if (R.compact && R.ex_id.size() > (size_t)PHL_MAX_EXTRAS) {
+        PHL_HIP(fetch_keys());
+        phl_reftable_expand(keys, M, d, R);
+    }
     if (R.M_ref != M || !R.dup_clean.empty()) {
         int *remap_dev, *dup_ptr_dev, *seg_e_dev, *seg_id_dev;
         extras_t ex;
