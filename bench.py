@@ -974,7 +974,7 @@ def small_image(torch, phl, device):
     # on the device, Q copied back once (crf_module._mean_field_infer_staged): PCIe-inclusive wall time of the whole call.
     E0c, Muc, Wc = E0.cpu(), Mu.cpu(), LatticeGaussian(ref.cpu())
     res["mean_field_ms_cpu_tensors"] = round(wall(lambda: cm.mean_field_infer(E0c, Wc, Muc, niters), 20), 4)
-    res["cpu_tensors_what"] = (f"E_0 [{H * W}, {L}] pageable host memory -> device (pinned pieces), {niters} iterations on the "
+    res["cpu_tensors_what"] = (f"E_0 [{H * W}, {L}] pageable host memory -> device, {niters} iterations on the "
                                "device, Q -> host (pinned); includes both PCIe crossings")
     return res
 

@@ -127,19 +127,23 @@ def _stream(device):
     return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
-_STAGE_BYTES = 2 << 20       # pinned staging piece of the host <-> device copies below (small enough that a Tsukuba-sized
-                             # E_0 of 7 MB already overlaps its host memcpy with the DMA of the piece before)
+_STAGE_BYTES = 2 << 20       # piece size of the staged form below
 
 
 def to_device(t, device):
     """``t.to(device)`` for the reference's calling convention -- pageable CPU tensors (DenseCrf.ipynb:142-152 hands
-    CPU tensors to mean_field_infer): large contiguous fp32 tensors go through pinned staging pieces from torch's
-    caching host allocator, so that the host-side memcpy of piece k+1 runs under the DMA of piece k (a plain
-    ``.to(device)`` of pageable memory stages serially inside the runtime).  Enqueued on the current stream."""
+    CPU tensors to mean_field_infer).  Enqueued on the current stream.
+
+    The runtime's own pageable path is the fast one on this platform (tools/h2d_probe.py: 44-52 GB/s from pageable memory
+    at 7 MB ... 1 GB -- it pins the user's pages for the DMA); copying through pinned staging pieces first, as rounds 3-4 did,
+    is bound by the host memcpy and by the caching host allocator handing out fresh pinned blocks while earlier pieces are
+    still in flight (3-4 GB/s at 128 MB and up, 20 GB/s at 7 MB on the same box; box to box the notebook-sized call swung
+    between 1.2 and 5 ms).  PHL_H2D=staged brings the staged form back."""
     device = torch.device(device)
     if t.device == device:
         return t
-    if t.is_cuda or t.is_pinned() or not t.is_contiguous() or t.numel() * t.element_size() < (1 << 20):
+    if (os.environ.get("PHL_H2D") != "staged" or t.is_cuda or t.is_pinned() or not t.is_contiguous()
+            or t.numel() * t.element_size() < (1 << 20)):
         return t.to(device, non_blocking=(not t.is_cuda and t.is_pinned()))
     out = torch.empty(t.shape, dtype=t.dtype, device=device)
     src, dst = t.reshape(-1), out.view(-1)
