@@ -815,10 +815,12 @@ int phl_filter(phl_lattice *lat, const float *src, int vd, int64_t src_rs, int64
     bool stage_dst = (out_cs != 1) && vd > 1;
     // Rows the chunk kernels cannot take -- a channel count that is not a multiple of 4 (the reference's max_disp = w // 6:
     // 231 at 1390 columns), a row stride or base address off the 16-byte grid (a column slice of a wider tensor) -- used to
-    // fall back to the gather kernels (2.4x slower at 1390x1110x231).  From 9 channels on they are staged instead: one
-    // copy into / out of a buffer with 16-byte rows, the kernels run at the width rounded up to a multiple of 4.
+    // fall back to the gather kernels (2.4x slower at 1390x1110x231).  From 128 channels on they are staged instead: one
+    // copy into / out of a buffer with 16-byte rows, the kernels run at the width rounded up to a multiple of 4.  (Below
+    // that the two extra passes over the volume cost more than the gather kernels lose: tools/odd_narrow.py, 1390x1110 --
+    // 9 channels 0.46 vs 0.27 ms, 50: 0.87 vs 0.83, 110: 1.29 vs 1.20, 130: 1.48 vs 1.59, 231: 2.59 vs 3.14.)
     int vdw = vd;
-    if (vd > 8 && !(flags & (PHL_FILTER_EXACT | PHL_FILTER_NO_TILES))) {
+    if (vd >= 128 && !(flags & (PHL_FILTER_EXACT | PHL_FILTER_NO_TILES))) {
         auto off_grid = [](const void *p, int64_t rs) { return (reinterpret_cast<uintptr_t>(p) & 15) != 0 || rs % 4 != 0; };
         if (vd % 4) {
             vdw = (vd + 3) & ~3;

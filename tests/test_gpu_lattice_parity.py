@@ -962,12 +962,12 @@ def test_side_stream_of_the_table_replay_is_kept_per_device(phl):
     assert seen["count"] == seen["devs"], seen
 
 
-@pytest.mark.parametrize("vd", [9, 10, 30, 50, 231])
+@pytest.mark.parametrize("vd", [9, 10, 30, 50, 130, 231])
 def test_widths_and_rows_off_the_sixteen_byte_grid(phl, vd):
     """Value tensors the chunk kernels cannot take as they are -- a channel count that is not a multiple of 4 (the reference's
     max_disp = w // 6: 231 at 1390 columns), rows whose stride or base address is off the 16-byte grid (a column slice of a
-    wider tensor) -- are staged into 16-byte rows and run on the chunk kernels at the width rounded up (phl_filter; they used
-    to fall back to the gather kernels): against the CPU oracle, with and without the fused subtraction, into an unaligned
+    wider tensor) -- are, from 128 channels on, staged into 16-byte rows and run on the chunk kernels at the width rounded up
+    (phl_filter; narrower ones keep the gather kernels, which win there): against the CPU oracle, with and without the fused subtraction, into an unaligned
     output view, and equal to the gather kernels' result within rounding."""
     from oracle import phl_oracle as po
 
