@@ -664,8 +664,13 @@ __global__ __launch_bounds__(512) void k_compat_softmax(const float *__restrict_
 //    a fifth as long as the f32 kernel's, the latency to cover is the same.
 //  * the waves on the matrix cores split their X operands themselves (8 values a lane and pixel group per chunk:
 //    and / sub / and / sub + three byte permutes per pair), once per chunk, kept across the chunk's two slots.
-//  * row traffic (Q stores, next E0 loads) runs in the first EPI_D slots of the epilogue half, so that the E0 values
-//    have the remaining slots to land before the matrix cores take them as C input.
+//  * row traffic (Q stores, next E0 loads) is spread over the first EPI_D = 14 of the 16 epilogue slots; the E0 loads go
+//    into the accumulators through inline assembly and the kernel waits for them itself at the top of the matrix half
+//    (PHL_E0_LOAD_HIDDEN: a compiler-made wait would drain the DMA queue with them).  They are unconditional -- without a
+//    next tile they re-read rows that exist -- so that they sit in straight-line code (tools/check_split_isa.py).
+//  * one instance serves every L in (128, 256]: columns above L are padding (PAD: planes zero, E0 +inf, X fetches clamped
+//    into the row and zeroed when consumed, nothing stored); the clamp arithmetic works on an opaque copy of L per slot so
+//    that it is not hoisted out of the slot loop (its registers would spill).
 //  * a wave that goes from its epilogue half to the matrix cores still has the DMAs of its last two slots in flight
 //    (they feed slots 1 and 2 of the half it enters): counted waits at the end of its first two slots there.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
