@@ -621,16 +621,25 @@ int phl_reserve_ex(phl_lattice *lat, int vd, unsigned reserve_flags)
     if (!lat || vd < 0) { phl_set_error("phl_reserve: bad arguments"); return PHL_ERR_INVALID; }
     device_guard g(lat->device);
     const unsigned fflags = (reserve_flags & PHL_RESERVE_EXACT) ? PHL_FILTER_EXACT : 0;
-    const int64_t partial = need_partial(lat, vd, fflags);
+    // what phl_filter will do with this width: channel counts >= 128 that are not a multiple of 4 run staged at the width
+    // rounded up (both sides); rows off the 16-byte grid at a multiple of 4 cannot be known here -- PHL_RESERVE_STRIDED_IO
+    // sizes the staging buffers for those as for channel-major views
+    int vdw = vd;
+    bool staged = (reserve_flags & PHL_RESERVE_STRIDED_IO) != 0;
+    if (vd >= 128 && vd % 4 && !(fflags & PHL_FILTER_EXACT)) {
+        vdw = (vd + 3) & ~3;
+        staged = true;
+    }
+    const int64_t partial = need_partial(lat, vdw, fflags);
     // the gather splat (exact mode, or shapes the chunk splat does not take) needs its pixel-sorted lists
-    const bool gather = partial == 0 && !use_tiled_splat(lat, vd, fflags, nullptr, nullptr, 0);
+    const bool gather = partial == 0 && !use_tiled_splat(lat, vdw, fflags, nullptr, nullptr, 0);
     if (gather) {
         const int rc = phl_ensure_csr(lat, nullptr);
         if (rc) return rc;
     }
     phl_workspace *w = nullptr;
-    const int64_t stage = (reserve_flags & PHL_RESERVE_STRIDED_IO) ? lat->n * (int64_t)vd : 0;
-    int rc = phl_ws_acquire(lat, nullptr, lat->M * (int64_t)vd, partial, stage, &w);
+    const int64_t stage = staged ? lat->n * (int64_t)vdw : 0;
+    int rc = phl_ws_acquire(lat, nullptr, lat->M * (int64_t)vdw, partial, stage, &w);
     if (rc) return rc;
     phl_ws_release(lat, w, nullptr, /*idle=*/true);      // sized, carries no work: the next call on any stream takes it
     return PHL_OK;

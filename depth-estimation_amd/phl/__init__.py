@@ -269,7 +269,8 @@ class Lattice:
     def reserve(self, vd, strided_io=False, exact=False):
         """Pre-size everything a ``filter`` over ``vd`` channels needs, so that the next call -- on any stream,
         e.g. inside a HIP-graph capture -- allocates nothing.  strided_io: also the staging copies channel-major
-        (NCHW) views go through; exact: prepare for ``exact=True`` calls."""
+        (NCHW) views -- and, from 128 channels on, pixel-major rows off the 16-byte grid such as column slices -- go
+        through; exact: prepare for ``exact=True`` calls."""
         _check(load_library().phl_reserve_ex(self._h, int(vd), (1 if strided_io else 0) | (2 if exact else 0)))
 
     # ---- hot path ---------------------------------------------------------------------------

@@ -152,8 +152,10 @@ int phl_sub_lattice(phl_lattice **out, phl_lattice *whole, int64_t p0, int64_t p
  * phl_blur, phl_slice on one handle concurrently.  phl_add_vertices and phl_destroy are not concurrent with
  * anything. */
 int phl_reserve(phl_lattice *lat, int vd);
-/* phl_reserve with options: PHL_RESERVE_STRIDED_IO also sizes the staging copies that channel-major (NCHW) views
- * go through, PHL_RESERVE_EXACT prepares for PHL_FILTER_EXACT calls (builds the pixel-sorted lists). */
+/* phl_reserve with options: PHL_RESERVE_STRIDED_IO also sizes the staging copies that channel-major (NCHW) views -- and
+ * pixel-major rows whose stride or base address is off the 16-byte grid, from 128 channels on -- go through (channel
+ * counts >= 128 that are not a multiple of 4 are always staged, at the width rounded up: sized without the flag),
+ * PHL_RESERVE_EXACT prepares for PHL_FILTER_EXACT calls (builds the pixel-sorted lists). */
 enum phl_reserve_flags { PHL_RESERVE_STRIDED_IO = 1, PHL_RESERVE_EXACT = 2 };
 int phl_reserve_ex(phl_lattice *lat, int vd, unsigned reserve_flags);
 

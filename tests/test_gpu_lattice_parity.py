@@ -999,3 +999,32 @@ def test_widths_and_rows_off_the_sixteen_byte_grid(phl, vd):
         v4 = vd - 2
         res4 = Lat.filter(wide[:, 1:v4 + 1])
         assert scaled_err(res4.cpu().numpy(), want[:, :v4]) <= 1e-5
+
+
+@pytest.mark.parametrize("layout", ["odd_width", "column_slice"])
+def test_reserve_then_capture_rows_off_the_grid(phl, layout):
+    """phl_reserve's contract for the widths phl_filter stages: 231 channels (not a multiple of 4: sized by reserve() itself)
+    and a 160-channel column slice of a wider tensor (rows off the 16-byte grid: reserve(strided_io=True)) are captured
+    directly behind one reserve() call, no warm-up, and replay to the un-captured result."""
+    rng = np.random.default_rng(23)
+    n, d = 20000, 5
+    ref = np.cumsum(rng.random((n, d), dtype=np.float32) * 0.02, axis=0).astype(np.float32)
+    Lat = phl.Lattice(torch.from_numpy(ref).cuda())
+    if layout == "odd_width":
+        L = 231
+        Lat.reserve(L)
+        x = torch.rand((n, L), device="cuda")
+        out = torch.empty_like(x)
+    else:
+        L = 160
+        Lat.reserve(L, strided_io=True)
+        x = torch.rand((n, L + 3), device="cuda")[:, 1:L + 1]
+        out = torch.empty((n, L + 2), device="cuda")[:, 1:L + 1]
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        Lat.filter(x, out=out)
+    g.replay()
+    torch.cuda.synchronize()
+    want = phl.Lattice(torch.from_numpy(ref).cuda()).filter(x.contiguous())
+    assert float((out.contiguous() - want).abs().max()) <= 1e-6 * float(want.abs().max())
