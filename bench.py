@@ -890,7 +890,9 @@ def regime_sweep(torch, phl, H, W, L, d, src, out, base_ms, base_M):
     """SURVEY 8(d) "synthetic inputs": the same volume filtered under other feature distributions -- sigma_xy 3
     and 30, and natural-image features (the stored Tsukuba frame upsampled, DenseCrf.ipynb:142-146 scaling) -- so
     that the headline is not one operating point's speed.  Compact: M/n, ms per step, algorithmic GB/s (8d byte
-    counts) and that figure relative to the default features'.  The full sweep (both large workloads, stage times,
+    counts) and that figure relative to the default features', plus per stage the HIP-event time and the 8(d) bytes of the
+    stage / time / 8 TB/s (`per_stage.*.frac`; blur's byte count is the d+1 axis passes of 8(d), which the kernel runs as
+    (d+1)/2 fused launches -- the same convention as roofline.per_stage.blur.algorithmic_GBps).  The full sweep (both large workloads, stage times,
     gather-kernel comparison, iid stress case) is tools/regimes.py -> profiles/r03_regimes.json."""
     n = H * W
     alg = lambda M: sum(algorithmic_bytes(n, M, L, d).values())
@@ -915,8 +917,12 @@ def regime_sweep(torch, phl, H, W, L, d, src, out, base_ms, base_M):
         ms = e0.elapsed_time(e1) / 10
         gbs = alg(lat.M) / (ms * 1e-3) / 1e9
         st = lat.tile_stats(L)
+        # the three stages on their own (HIP events on the launch stream): 8(d) bytes of the stage / its time / 8 TB/s
+        stages = stage_times(torch, lat, src, out, {}, 3)
+        sb = algorithmic_bytes(n, lat.M, L, dd)
         rows[name] = {"M_over_n": round(lat.M / n, 4), "ms": round(ms, 4), "Mpixel_labels_per_s": round(n * L / (ms * 1e-3) / 1e6, 1),
                       "algorithmic_GBps": round(gbs, 1), "rel": round(gbs / base_gbs, 3),
+                      "per_stage": {k: {"ms": round(v, 4), "frac": round(sb[k] / (v * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)} for k, v in stages.items()},
                       "max_local_vertices": st["max_local_vertices"], "staged": [st["staged_splat"], st["staged_slice"]]}
         lat.close()
         del lat
