@@ -891,8 +891,9 @@ def regime_sweep(torch, phl, H, W, L, d, src, out, base_ms, base_M):
     and 30, and natural-image features (the stored Tsukuba frame upsampled, DenseCrf.ipynb:142-146 scaling) -- so
     that the headline is not one operating point's speed.  Compact: M/n, ms per step, algorithmic GB/s (8d byte
     counts) and that figure relative to the default features', plus per stage the HIP-event time and the 8(d) bytes of the
-    stage / time / 8 TB/s (`per_stage.*.frac`; blur's byte count is the d+1 axis passes of 8(d), which the kernel runs as
-    (d+1)/2 fused launches -- the same convention as roofline.per_stage.blur.algorithmic_GBps).  The full sweep (both large workloads, stage times,
+    stage / time / 8 TB/s (`per_stage.*.frac`; blur's byte count is what its (d+1)/2 two-axis launches move --
+    roofline.per_stage.blur.fused_pass_bytes -- and with few vertices those rows come out of L2 / the Infinity Cache,
+    so its fraction is not an HBM figure there).  The full sweep (both large workloads, stage times,
     gather-kernel comparison, iid stress case) is tools/regimes.py -> profiles/r03_regimes.json."""
     n = H * W
     alg = lambda M: sum(algorithmic_bytes(n, M, L, d).values())
@@ -920,6 +921,8 @@ def regime_sweep(torch, phl, H, W, L, d, src, out, base_ms, base_M):
         # the three stages on their own (HIP events on the launch stream): 8(d) bytes of the stage / its time / 8 TB/s
         stages = stage_times(torch, lat, src, out, {}, 3)
         sb = algorithmic_bytes(n, lat.M, L, dd)
+        # blur: what its (d+1)/2 two-axis launches move (as roofline.per_stage.blur.fused_pass_bytes), not 8(d)'s d+1 passes
+        sb["blur"] = ((dd + 2) // 2) * 8 * lat.M * L + ((dd + 1) // 2) * 32 * lat.M + ((dd + 1) % 2) * 8 * lat.M
         rows[name] = {"M_over_n": round(lat.M / n, 4), "ms": round(ms, 4), "Mpixel_labels_per_s": round(n * L / (ms * 1e-3) / 1e6, 1),
                       "algorithmic_GBps": round(gbs, 1), "rel": round(gbs / base_gbs, 3),
                       "per_stage": {k: {"ms": round(v, 4), "frac": round(sb[k] / (v * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)} for k, v in stages.items()},

@@ -50,7 +50,7 @@ def _ref_gradient(src, ref, g, wall):
 
 
 def _fused_shape_ok(src, ref, g):
-    return (g.shape == src.shape and src.shape[-1] % 4 == 0 and ref.shape[-1] <= 7 and torch.cuda.is_available()
+    return (g.shape == src.shape and src.shape[-1] > 0 and ref.shape[-1] <= 7 and torch.cuda.is_available()
             and src.dtype == torch.float32 and ref.dtype == torch.float32
             and os.environ.get("PHL_FUSED_GRAD", "1") != "0")         # A/B switch: the reference's formulation
 
@@ -60,18 +60,30 @@ def _fused_grad(src, ref, g, need_src):
     weights and the contraction happens inside the slice, so the 2L(1+d)-channel operand and result of :450-463
     (19 GB each at 1390x1110x256) never exist.  None when the fused path does not take the shape (then the caller
     filters the wide operand, as the reference does).  ``src`` / ``ref`` may be [n, .] (one image) or [bs, n, .]
-    (a batch: items dealt over the devices and lattices of the batched forward pass)."""
+    (a batch: items dealt over the devices and lattices of the batched forward pass).  Any label count: see the
+    padding below."""
     if not _fused_shape_ok(src, ref, g) or src.dim() != ref.dim() or src.dim() not in (2, 3):
         return None
+    # label counts off the kernels' 4-channel grid (the reference's own w // 6: 231, 341) run padded with channels
+    # that are exactly zero in src AND g: every term of the contraction carries a factor s or g, the source gradient
+    # of a padding channel is the filter of zeros -- the extra channels add exact zeros and are cut off again
+    L = src.shape[-1]
+    pad = (-L) % 4
+    if pad:
+        src, g = F.pad(src, (0, pad)), F.pad(g, (0, pad))
     try:
         if src.dim() == 3:
-            return phl.batched_filter_grad(src, ref, g, need_src=need_src)
-        gs, gr = phl.lattice_for(ref.detach()).filter_grad(src, g, ref, need_src=need_src)
+            gs, gr = phl.batched_filter_grad(src, ref, g, need_src=need_src)
+        else:
+            gs, gr = phl.lattice_for(ref.detach()).filter_grad(src, g, ref, need_src=need_src)
+            gs, gr = (gs.to(src.device) if gs is not None else None), gr.to(ref.device)
     except phl.PhlError as e:
         if e.status != 7:          # PHL_ERR_UNSUPPORTED: shape outside the fused path
             raise
         return None
-    return (gs.to(src.device) if gs is not None else None), gr.to(ref.device)
+    if pad and gs is not None:
+        gs = gs[..., :L].contiguous()
+    return gs, gr
 
 
 def _wide_operand(src, ref, g):

@@ -215,3 +215,36 @@ def test_channel_groups_under_a_small_workspace_budget(monkeypatch):
             lat.filter_grad(src, g, ref)
         assert ei.value.status == 7
     assert lat.device_bytes <= before
+
+
+@pytest.mark.parametrize("L", [231, 6, 1])
+def test_label_counts_off_the_four_channel_grid_take_the_fused_path_padded(L, monkeypatch):
+    """The reference's own label counts (w // 6 = 231 at 1390 columns, crf/depth.py:40) are not multiples of 4:
+    LatticeFilter.backward pads src and g with zero channels (exact zeros in every term of gaussian_matrix.py:450-463's
+    contraction) instead of materialising the 2L(1+d)-channel operand."""
+    import crf.gaussian_matrix as gm
+    import phl
+
+    rng = np.random.default_rng(100 + L)
+    n, d = 60 * 50, 5
+    f = _features("image", n, d, rng)
+    n = f.shape[0]
+    src = rng.random((n, L), dtype=np.float32)
+    gout = torch.from_numpy(rng.standard_normal((n, L)).astype(np.float32)).cuda()
+    widths = []
+    real = phl.Lattice.filter_grad
+    monkeypatch.setattr(phl.Lattice, "filter_grad", lambda self, s, g, r, **k: widths.append(s.shape[1]) or real(self, s, g, r, **k))
+
+    def grads():
+        ref = torch.from_numpy(f).cuda().requires_grad_(True)
+        s = torch.from_numpy(src).cuda().requires_grad_(True)
+        gm.LatticeFilter.apply(s, ref).backward(gout)
+        return s.grad, ref.grad
+
+    gs_f, gr_f = grads()
+    assert widths == [(L + 3) // 4 * 4], widths
+    assert gs_f.shape == (n, L) and gs_f.is_contiguous()
+    monkeypatch.setattr(gm, "_fused_grad", lambda *a: None)       # the reference's formulation through the same lattice
+    gs_c, gr_c = grads()
+    assert float((gs_f - gs_c).abs().max()) <= 1e-5 * float(gs_c.abs().max())
+    assert float((gr_f - gr_c).abs().max()) <= 2e-4 * float(gr_c.abs().max())

@@ -522,6 +522,44 @@ def test_randomised_shapes_against_oracle(phl):
         assert scaled_err(sub + src, want) <= 1e-5, (trial, n, d, vd)
 
 
+def float64_splat_truth(O, src):
+    """The filter with the splat's sums taken in float64 over the oracle's own (vertex, weight) entries, then the
+    oracle's blur and slice (sums of three and of d+1 terms: 1e-7): what both fp32 summation orders approximate."""
+    vid, w = O.replay()
+    V = np.zeros((O.M, src.shape[1]))
+    s64 = src.astype(np.float64)
+    for k in range(vid.shape[1]):
+        np.add.at(V, vid[:, k], w[:, k].astype(np.float64)[:, None] * s64)
+    return O.slice(O.blur(V.astype(np.float32)))
+
+
+def test_long_segments_default_arithmetic_is_nearer_float64_than_the_reference(phl):
+    """Found by tools/fuzz_filter.py (seed 9106, trial 6): constant features put all 50021 pixels on d+1 vertices.
+    The reference sums a vertex's pixels one after the other in fp32 (permutohedral.h:441-447) and carries that chain's
+    rounding -- 1.2e-5 of the largest output here; the default arithmetic sums per chunk and then across chunks, so it
+    sits at that distance from the reference and an order of magnitude nearer the float64 sums.  Exact mode reproduces
+    the reference's chain bit for bit."""
+    from oracle import phl_oracle as po
+
+    rng = np.random.default_rng(9106)
+    n, d, vd = 50021, 3, 64
+    ref = np.zeros((n, d), np.float32)
+    src = rng.random((n, vd), dtype=np.float32) - np.float32(0.25)
+    O = po.Oracle(ref)
+    want = O.filter(src)
+    L = phl.Lattice(torch.from_numpy(ref).cuda())
+    s = torch.from_numpy(src).cuda()
+    assert L.M == O.M == d + 1
+    assert np.array_equal(L.filter(s, exact=True).cpu().numpy().view(np.uint32), want.view(np.uint32))
+    fast = L.filter(s).cpu().numpy()
+    truth = float64_splat_truth(O, src)
+    e_ref, e_fast, dist = scaled_err(want, truth), scaled_err(fast, truth), scaled_err(fast, want)
+    print(f"[measured] {n} pixels on {d + 1} vertices: reference vs float64 sums {e_ref:.2e}, default vs float64 sums {e_fast:.2e}, "
+          f"default vs reference {dist:.2e}")
+    assert e_fast <= 2e-6 and e_fast <= e_ref
+    assert dist <= e_ref + e_fast + 1e-7 and dist <= RTOL
+
+
 @pytest.mark.parametrize("d", [1, 2, 3, 4, 5, 6])
 def test_fused_blur_equals_axis_by_axis(phl, d):
     """phl_blur takes the axes two per pass (k_blur2) and a last single one when d+1 is odd: same bits as

@@ -1,5 +1,6 @@
 """Seeded fuzz of phl.Lattice.filter against the CPU oracle (the logic of tests/test_gpu_lattice_parity.py::
-test_randomised_shapes_against_oracle over many seeds and a wider set of widths / row layouts): python tools/fuzz_filter.py SEED0 COUNT.
+test_randomised_shapes_against_oracle over many seeds and a wider set of widths / row layouts): python tools/fuzz_filter.py SEED0 COUNT
+[TRIAL: replay that one trial of SEED0 and print every check].
 Verification helper, not part of the product: it imports the oracle as the checker."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -12,7 +13,17 @@ def scaled_err(a, b):
     return float(np.abs(a.astype(np.float64) - b).max() / max(1e-30, np.abs(b).max()))
 
 
+def float64_truth(O, src):
+    vid, w = O.replay()
+    V = np.zeros((O.M, src.shape[1]))
+    s64 = src.astype(np.float64)
+    for k in range(vid.shape[1]):
+        np.add.at(V, vid[:, k], w[:, k].astype(np.float64)[:, None] * s64)
+    return O.slice(O.blur(V.astype(np.float32)))
+
+
 seed0, count = int(sys.argv[1]), int(sys.argv[2])
+only = int(sys.argv[3]) if len(sys.argv) > 3 else None      # replay ONE trial of seed0 (the draws of the others are consumed)
 bad = trials = 0
 for seed in range(seed0, seed0 + count):
     rng = np.random.default_rng(seed)
@@ -30,6 +41,9 @@ for seed in range(seed0, seed0 + count):
         O = po.Oracle(ref)
         if O.status == 1:
             continue
+        if only is not None and trial != only:
+            rng.choice([0, 1, 2, 4]), rng.choice([0, 1, 3, 4])
+            continue
         want = O.filter(src)
         L = phl.Lattice(torch.from_numpy(ref).cuda())
         lead, pad = int(rng.choice([0, 1, 2, 4])), int(rng.choice([0, 1, 3, 4]))
@@ -38,14 +52,31 @@ for seed in range(seed0, seed0 + count):
         s = buf[:, lead:lead + vd]
         outbuf = torch.full((n, vd + pad + lead), 7.0, device='cuda')
         trials += 1
-        ok = L.M == O.M
-        ok &= np.array_equal(L.filter(s, exact=True).cpu().numpy().view(np.uint32), want.view(np.uint32))
-        ok &= scaled_err(L.filter(s).cpu().numpy(), want) <= 1e-5
-        ok &= scaled_err(L.filter(s, subtract_input=True).cpu().numpy() + src, want) <= 1e-5
-        ok &= scaled_err(L.filter(s, out=outbuf[:, pad:pad + vd]).cpu().numpy(), want) <= 1e-5
-        ok &= float(outbuf[:, :pad].min() if pad else 7.0) == 7.0 and float(outbuf[:, pad + vd:].max() if lead else 7.0) == 7.0
+        checks = {'M': (L.M, O.M, L.M == O.M)}
+        truth = None
+        ex = L.filter(s, exact=True).cpu().numpy()
+        nbad = int((ex.view(np.uint32) != want.view(np.uint32)).sum())
+        checks['exact_bitwise'] = (nbad, scaled_err(ex, want), nbad == 0)
+        for name, got in (('default', lambda: L.filter(s).cpu().numpy()),
+                          ('subtract_input', lambda: L.filter(s, subtract_input=True).cpu().numpy() + src),
+                          ('out_view', lambda: L.filter(s, out=outbuf[:, pad:pad + vd]).cpu().numpy())):
+            res = got()
+            e = scaled_err(res, want)
+            if e > 1e-5:      # long vertex lists: the reference's sequential fp32 chain carries more rounding than that --
+                # arbitrate with the splat summed in float64 (test_long_segments_default_arithmetic_is_nearer_float64_...)
+                if truth is None:
+                    truth = float64_truth(O, src)
+                e_ref, e_got = scaled_err(want, truth), scaled_err(res, truth)
+                checks[name] = (e, 'vs float64 sums: reference', e_ref, 'ours', e_got, e_got <= 2e-6 and e_got <= e_ref and e <= 1e-4)
+            else:
+                checks[name] = (e, True)
+        guard = float(outbuf[:, :pad].min() if pad else 7.0) == 7.0 and float(outbuf[:, pad + vd:].max() if lead else 7.0) == 7.0
+        checks['guard_columns'] = (guard,)
+        ok = all(c[-1] for c in checks.values())
+        if only is not None:
+            print('REPLAY', dict(seed=seed, trial=trial, n=n, d=d, vd=vd, scale=scale, lead=lead, pad=pad, M=L.M), checks, L.tile_stats(vd), flush=True)
         if not ok:
             bad += 1
-            print('MISMATCH', dict(seed=seed, trial=trial, n=n, d=d, vd=vd, scale=scale, lead=lead, pad=pad), flush=True)
+            print('MISMATCH', dict(seed=seed, trial=trial, n=n, d=d, vd=vd, scale=scale, lead=lead, pad=pad), {k: c for k, c in checks.items() if not c[-1]}, flush=True)
 print(f'fuzz: {trials} trials over seeds {seed0}..{seed0 + count - 1}, {bad} mismatches')
 sys.exit(1 if bad else 0)
