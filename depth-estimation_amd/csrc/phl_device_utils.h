@@ -121,6 +121,46 @@ __global__ __launch_bounds__(SCAN_T) void k_scan_add(int *__restrict__ out, cons
         if ((base + i) < n) out[base + i] += add;
 }
 
+// Up to SCAN_FUSE_TILES tiles (2 M entries) the middle launch is not needed: a consumer of the tile-local scan adds up
+// the tile sums in front of its tile itself (four per thread and one block scan).  The build is a chain of dependent
+// few-microsecond launches, each of which costs the dispatch-to-dispatch minimum (profiles/r04g_build_timeline.txt):
+// every launch less is ~4.6 us off the critical path.  Integer sums: the results are the same bits.
+constexpr int SCAN_FUSE_TILES = 4 * SCAN_T;
+
+// exclusive prefix of tile_sums[0 .. ntiles), ntiles <= SCAN_FUSE_TILES, into pre[] (LDS); all SCAN_T threads call
+__device__ __forceinline__ void tile_prefix_to_lds(const int *__restrict__ tile_sums, int ntiles, int *pre)
+{
+    const int b4 = threadIdx.x * 4;
+    int v[4], s = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        v[i] = (b4 + i) < ntiles ? tile_sums[b4 + i] : 0;
+        s += v[i];
+    }
+    int tot;
+    int ex = block_exclusive_scan(s, &tot);
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        pre[b4 + i] = ex;
+        ex += v[i];
+    }
+    __syncthreads();
+}
+
+// k_scan_sums + k_scan_add in one launch (ntiles <= SCAN_FUSE_TILES): tile_sums stays as k_scan_tile wrote it
+__global__ __launch_bounds__(SCAN_T) void k_scan_add_tiles(int *__restrict__ out, const int *__restrict__ tile_sums, int n)
+{
+    int s = 0;
+    for (int i = threadIdx.x; i < (int)blockIdx.x; i += SCAN_T) s += tile_sums[i];
+    int add;
+    (void)block_exclusive_scan(s, &add);
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) out[n] = add + tile_sums[blockIdx.x];
+    const int base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_I;
+#pragma unroll
+    for (int i = 0; i < SCAN_I; i++)
+        if ((base + i) < n) out[base + i] += add;
+}
+
 __attribute__((unused)) int exclusive_scan(const int *in, int *out /* n+1 */, int n, int *tile_sums, hipStream_t st)
 {
     if (n <= 0) {
@@ -129,6 +169,11 @@ __attribute__((unused)) int exclusive_scan(const int *in, int *out /* n+1 */, in
     }
     const int ntiles = (n + SCAN_TILE - 1) / SCAN_TILE;
     hipLaunchKernelGGL(k_scan_tile, dim3(ntiles), dim3(SCAN_T), 0, st, in, out, tile_sums, n);
+    if (ntiles <= SCAN_FUSE_TILES) {
+        hipLaunchKernelGGL(k_scan_add_tiles, dim3(ntiles), dim3(SCAN_T), 0, st, out, tile_sums, n);
+        PHL_HIP(hipGetLastError());
+        return PHL_OK;
+    }
     hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(SCAN_T), 0, st, tile_sums, ntiles, out + n);
     hipLaunchKernelGGL(k_scan_add, dim3(ntiles), dim3(SCAN_T), 0, st, out, tile_sums, n);
     PHL_HIP(hipGetLastError());
@@ -194,11 +239,21 @@ __attribute__((unused)) __global__ __launch_bounds__(256) void k_radix_hist(cons
 
 __attribute__((unused)) __global__ __launch_bounds__(256) void k_radix_scatter(const int *__restrict__ keys, const int *__restrict__ idx, int n,
                                                        int shift, int nblocks, const int *__restrict__ base,
+                                                       const int *__restrict__ tile_sums, int ntiles,
                                                        int *__restrict__ keys_out, int *__restrict__ idx_out)
 {
     __shared__ int run[256];        // next output position of each digit for this block
     __shared__ int wcnt[4][256];    // digit counts of each wavefront in the current round
-    run[threadIdx.x] = base[threadIdx.x * nblocks + blockIdx.x];
+    __shared__ int pre[SCAN_FUSE_TILES];
+    // tile_sums given: `base` is the tile-local scan of k_scan_tile, the tiles in front are added here (no k_scan_sums /
+    // k_scan_add launch in a pass)
+    const int g = threadIdx.x * nblocks + blockIdx.x;
+    if (tile_sums) {
+        tile_prefix_to_lds(tile_sums, ntiles, pre);
+        run[threadIdx.x] = base[g] + pre[g / SCAN_TILE];
+    } else {
+        run[threadIdx.x] = base[g];
+    }
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     for (int r = 0; r < RS_TILE; r += 256) {
         for (int j = threadIdx.x; j < 4 * 256; j += 256) (&wcnt[0][0])[j] = 0;
@@ -283,9 +338,17 @@ __attribute__((unused)) int stable_sort_perm(const int *keys, int n, int64_t key
         int *iout = ((passes - 1 - p) & 1) ? iA : perm_out;     // the last pass lands in perm_out
         hipLaunchKernelGGL(k_radix_hist, dim3(nblocks), dim3(256), 0, st, kin, n, 8 * p, nblocks, hist);
         PHL_HIP(hipGetLastError());
-        const int rc = exclusive_scan(hist, base, 256 * nblocks, tile_sums, st);
-        if (rc) return rc;
-        hipLaunchKernelGGL(k_radix_scatter, dim3(nblocks), dim3(256), 0, st, kin, iin, n, 8 * p, nblocks, base, kout, iout);
+        const int nh = 256 * nblocks, ntiles = (nh + SCAN_TILE - 1) / SCAN_TILE;
+        if (ntiles <= SCAN_FUSE_TILES) {        // three launches a pass: histogram, tile-local scan, scatter
+            hipLaunchKernelGGL(k_scan_tile, dim3(ntiles), dim3(SCAN_T), 0, st, (const int *)hist, base, tile_sums, nh);
+            hipLaunchKernelGGL(k_radix_scatter, dim3(nblocks), dim3(256), 0, st, kin, iin, n, 8 * p, nblocks, (const int *)base,
+                               (const int *)tile_sums, ntiles, kout, iout);
+        } else {
+            const int rc = exclusive_scan(hist, base, nh, tile_sums, st);
+            if (rc) return rc;
+            hipLaunchKernelGGL(k_radix_scatter, dim3(nblocks), dim3(256), 0, st, kin, iin, n, 8 * p, nblocks, (const int *)base,
+                               (const int *)nullptr, 0, kout, iout);
+        }
         PHL_HIP(hipGetLastError());
         kin = kout;
         iin = iout;
