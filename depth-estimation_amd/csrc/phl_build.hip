@@ -340,24 +340,46 @@ __global__ __launch_bounds__(256) void k_assign(const unsigned long long *__rest
 
 // replay[e].vid, written once: clean vertex of the candidate's table slot -> reference vertex (remap; for a key with
 // several vertices the last segment that starts at or before e) -> locality numbering (int_of_ft).
+// (the kernel is three dependent gathers per candidate -- 96 % of its wave cycles are parked, profiles/r04h_build_pmc.json --
+// so a thread walks FV_PER candidates, 256 apart, with the gathers of each level issued together)
+constexpr int FV_PER = 4;
 __global__ __launch_bounds__(256) void k_final_vid(const int *__restrict__ table, const int *__restrict__ slot_of, int N,
                                                    const int *__restrict__ remap, const int *__restrict__ dup_ptr,
                                                    const int *__restrict__ seg_e, const int *__restrict__ seg_id,
                                                    const int *__restrict__ int_of_ft, phl_replay_t *__restrict__ replay)
 {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= N) return;
-    int r = -(table[slot_of[e]] + 1);
+    const int64_t e0 = (int64_t)blockIdx.x * (256 * FV_PER) + threadIdx.x;      // (64 bits: N may come within 1024 of 2^31)
+    int s[FV_PER], r[FV_PER];
+#pragma unroll
+    for (int j = 0; j < FV_PER; j++) {
+        const int64_t e = e0 + j * 256;
+        s[j] = slot_of[e < N ? e : (int64_t)N - 1];
+    }
+#pragma unroll
+    for (int j = 0; j < FV_PER; j++) r[j] = -(table[s[j]] + 1);
     if (remap) {
-        r = remap[r];
-        if (r < 0) {
-            const int k = -r - 1;
-            int id = seg_id[dup_ptr[k]];
-            for (int s = dup_ptr[k]; s < dup_ptr[k + 1] && seg_e[s] <= e; s++) id = seg_id[s];
-            r = id;
+#pragma unroll
+        for (int j = 0; j < FV_PER; j++) r[j] = remap[r[j]];
+#pragma unroll
+        for (int j = 0; j < FV_PER; j++) {
+            if (r[j] < 0) {
+                const int64_t e = e0 + j * 256;
+                const int k = -r[j] - 1;
+                int id = seg_id[dup_ptr[k]];
+                for (int q = dup_ptr[k]; q < dup_ptr[k + 1] && seg_e[q] <= e; q++) id = seg_id[q];
+                r[j] = id;
+            }
         }
     }
-    replay[e].vid = int_of_ft ? int_of_ft[r] : r;
+    if (int_of_ft) {
+#pragma unroll
+        for (int j = 0; j < FV_PER; j++) r[j] = int_of_ft[r[j]];
+    }
+#pragma unroll
+    for (int j = 0; j < FV_PER; j++) {
+        const int64_t e = e0 + j * 256;
+        if (e < N) replay[e].vid = r[j];
+    }
 }
 
 __global__ __launch_bounds__(256) void k_count_vid(const phl_replay_t *__restrict__ replay, int N, int *cnt)
@@ -734,7 +756,7 @@ int phl_write_final_vids(phl_lattice *lat, hipStream_t st)
     if (!lat->bt_slot_of || !lat->bt_table) { phl_set_error("phl_write_final_vids: no build tables"); return PHL_ERR_INVALID; }
     const int N = (int)lat->N;
     if (N > 0) {
-        hipLaunchKernelGGL(k_final_vid, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, lat->bt_table, lat->bt_slot_of, N,
+        hipLaunchKernelGGL(k_final_vid, dim3((unsigned)(((int64_t)N + 256 * FV_PER - 1) / (256 * FV_PER))), dim3(256), 0, st, lat->bt_table, lat->bt_slot_of, N,
                            lat->bt_remap, lat->bt_dup_ptr, lat->bt_seg_e, lat->bt_seg_id, lat->int_of_ft, lat->replay);
         PHL_HIP(hipGetLastError());
     }
