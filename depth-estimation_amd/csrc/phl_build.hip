@@ -207,9 +207,16 @@ __global__ __launch_bounds__(256) void k_elevate(const float *__restrict__ ref, 
         rw[pix_rec<D>::GW + i / 6] |= (uint32_t)rank[i] << (5 * (i % 6));
     }
     pix_rec<D>::store(recs + p * pix_rec<D>::W, rw);
+    // whole entries (vertex id 0 until k_final_vid writes it): full 16-byte stores instead of every other word of the rows
     phl_replay_t *rout = replay + p * (D + 1);
+    if constexpr ((D + 1) % 2 == 0) {
 #pragma unroll
-    for (int r = 0; r <= D; r++) rout[r].w = bary[r];
+        for (int r = 0; r <= D; r += 2)
+            reinterpret_cast<uint4 *>(rout)[r >> 1] = make_uint4(0u, __float_as_uint(bary[r]), 0u, __float_as_uint(bary[r + 1]));
+    } else {
+#pragma unroll
+        for (int r = 0; r <= D; r++) reinterpret_cast<uint2 *>(rout)[r] = make_uint2(0u, __float_as_uint(bary[r]));
+    }
     if (bad) atomicOr(err, 1);
 }
 
