@@ -751,11 +751,13 @@ int phl_rebuild_table_and_neighbors(phl_lattice *lat, hipStream_t st, void **scr
 
 void phl_release_build_tables(phl_lattice *lat)
 {
-    int32_t **p[] = {&lat->bt_slot_of, &lat->bt_table, &lat->bt_remap, &lat->bt_dup_ptr, &lat->bt_seg_e, &lat->bt_seg_id, &lat->bt_cell};
+    // (bt_seg_e / bt_seg_id point into bt_dup_ptr's block: phl_apply_reference_table)
+    int32_t **p[] = {&lat->bt_slot_of, &lat->bt_table, &lat->bt_remap, &lat->bt_dup_ptr, &lat->bt_cell};
     for (int32_t **q : p) {
         if (*q) (void)phl_dev_free(*q);
         *q = nullptr;
     }
+    lat->bt_seg_e = lat->bt_seg_id = nullptr;
 }
 
 int phl_write_final_vids(phl_lattice *lat, hipStream_t st)

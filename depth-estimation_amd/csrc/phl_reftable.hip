@@ -1038,13 +1038,14 @@ __global__ void k_add_homes_v(cl_homes h, int *__restrict__ hist)
 }
 
 // verdict of one question: every asked key's home at or before the last empty slot
-__global__ void k_cluster_verdict(const int *__restrict__ last_empty, cl_homes h, int *__restrict__ verdict)
+__global__ void k_cluster_verdict(int *__restrict__ last_empty, cl_homes h, int *__restrict__ verdict)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     const int le = *last_empty - 1;
     int ok = 1;
     for (int k = 0; k < h.n_chk; k++) ok &= (h.chk[k] <= le) ? 1 : 0;
     *verdict = ok;
+    *last_empty = 0;            // (for the next question on this stream: saves its memset launch)
 }
 
 struct device_query : phl_reftable_query {
@@ -1053,6 +1054,7 @@ struct device_query : phl_reftable_query {
     int d = 0;
     int *hist = nullptr;                     // [max capacity] device
     int *small = nullptr;                    // [256] device ints: homes in, results out
+    bool last_empty_zeroed = false;
     std::unordered_map<int, uint64_t> hcache;            // clean vertex -> hash of its key
     std::unordered_map<int64_t, int> vcache;             // candidate -> clean vertex
     int *answers = nullptr;                              // [32][3] ints the device can write and the host can read, or null
@@ -1129,9 +1131,12 @@ struct device_query : phl_reftable_query {
         for (int32_t v : stale_clean) h.add[h.n_add++] = (int)(hash_of(v) & (cap / 2 - 1));
         h.n_chk = 0;
         for (int32_t v : check) h.chk[h.n_chk++] = (int)(hash_of(v) & (cap - 1));
-        int *const last_empty = small;       // one device int
+        int *const last_empty = small + 200; // one device int (behind the 96 ints `ask` may use); zeroed once, then by k_cluster_verdict
         hipError_t r = hipMemsetAsync(hist, 0, sizeof(int) * (size_t)cap, st);
-        if (r == hipSuccess) r = hipMemsetAsync(last_empty, 0, sizeof(int), st);
+        if (r == hipSuccess && !last_empty_zeroed) {
+            r = hipMemsetAsync(last_empty, 0, sizeof(int), st);
+            last_empty_zeroed = (r == hipSuccess);
+        }
         if (r == hipSuccess) {
             if (n_clean > 0)
                 hipLaunchKernelGGL(k_home_hist, dim3((unsigned)((n_clean + 255) / 256)), dim3(256), 0, st, vkeys_dev, n_clean, d,
@@ -1346,25 +1351,48 @@ int phl_apply_reference_table(phl_lattice *lat, hipStream_t st, void *arena, siz
         phl_reftable_expand(keys, M, d, R);
     }
     if (R.M_ref != M || !R.dup_clean.empty()) {
-        int *remap_dev, *dup_ptr_dev, *seg_e_dev, *seg_id_dev;
+        int *remap_dev;
         extras_t ex;
         ex.n = 0;
         if (R.compact) {
             ex.n = (int)R.ex_id.size();
             for (int k = 0; k < ex.n; k++) { ex.id[k] = R.ex_id[(size_t)k]; ex.clean[k] = R.ex_clean[(size_t)k]; }
         }
+        // first touches in the reference's numbering (phl_build_device would otherwise have to find every vertex's home
+        // cell with an atomicMin over all N candidates: 1.1 ms at C3)
+        std::vector<int32_t> dv_id, dv_e;
+        for (size_t k = 0; k + 1 < R.dup_ptr.size(); k++)
+            for (int32_t sidx = R.dup_ptr[k]; sidx < R.dup_ptr[k + 1]; sidx++) {
+                size_t j = 0;
+                for (; j < dv_id.size(); j++)
+                    if (dv_id[j] == R.seg_id[(size_t)sidx]) break;
+                if (j == dv_id.size()) { dv_id.push_back(R.seg_id[(size_t)sidx]); dv_e.push_back(R.seg_e[(size_t)sidx]); }
+                else if (R.seg_e[(size_t)sidx] < dv_e[j]) dv_e[j] = R.seg_e[(size_t)sidx];
+            }
+        for (int32_t &e : dv_e) e = e < 0 ? 0 : (e >= N ? N - 1 : e);
+        // The replay's short lists go up in ONE copy into ONE block (each separate copy is a ~5 us launch of its own on
+        // both sides): [dup_ptr | seg_e | seg_id] are kept until the candidates' vertex ids are written (lat->bt_dup_ptr
+        // owns the block, bt_seg_e / bt_seg_id point into it: k_final_vid), the rest is read by the launches below.
+        // (tracked keys: -(k+1), resolved per candidate by k_final_vid)
+        const size_t n_dp = R.dup_ptr.size(), n_sg = R.seg_e.size(), n_dc = R.compact ? R.dup_clean.size() : 0, n_dv = dv_id.size();
+        const size_t o_se = n_dp, o_si = o_se + n_sg + 1, o_dc = o_si + n_sg + 1, o_dval = o_dc + n_dc, o_dvid = o_dval + n_dc,
+                     o_dve = o_dvid + n_dv, total = o_dve + n_dv + 1;
+        std::vector<int32_t> pack(total, 0);
+        std::copy(R.dup_ptr.begin(), R.dup_ptr.end(), pack.begin());
+        std::copy(R.seg_e.begin(), R.seg_e.end(), pack.begin() + (ptrdiff_t)o_se);
+        std::copy(R.seg_id.begin(), R.seg_id.end(), pack.begin() + (ptrdiff_t)o_si);
+        for (size_t k = 0; k < n_dc; k++) { pack[o_dc + k] = R.dup_clean[k]; pack[o_dval + k] = -(int32_t)(k + 1); }
+        std::copy(dv_id.begin(), dv_id.end(), pack.begin() + (ptrdiff_t)o_dvid);
+        std::copy(dv_e.begin(), dv_e.end(), pack.begin() + (ptrdiff_t)o_dve);
         // (kept until the candidates' vertex ids are written: lat->bt_*, k_final_vid)
         PHL_HIP(phl_dev_malloc((void **)&lat->bt_remap, sizeof(int) * (size_t)M));
-        PHL_HIP(phl_dev_malloc((void **)&lat->bt_dup_ptr, sizeof(int) * R.dup_ptr.size()));
-        PHL_HIP(phl_dev_malloc((void **)&lat->bt_seg_e, sizeof(int) * (R.seg_e.size() + 1)));
-        PHL_HIP(phl_dev_malloc((void **)&lat->bt_seg_id, sizeof(int) * (R.seg_id.size() + 1)));
+        PHL_HIP(phl_dev_malloc((void **)&lat->bt_dup_ptr, sizeof(int) * total));
+        lat->bt_seg_e = lat->bt_dup_ptr + o_se;
+        lat->bt_seg_id = lat->bt_dup_ptr + o_si;
         remap_dev = lat->bt_remap;
-        dup_ptr_dev = lat->bt_dup_ptr;
-        seg_e_dev = lat->bt_seg_e;
-        seg_id_dev = lat->bt_seg_id;
-        // Host vectors whose copies may still be queued, then the guard: on ANY early return it synchronises the stream
-        // first (it is destroyed before the vectors) and releases what the lattice does not own yet.
-        std::vector<int32_t> dup_val, dv_id, dv_e;
+        int *const blk = lat->bt_dup_ptr;
+        // The guard: on ANY early return it synchronises the stream first (the copies of the host vectors above may still
+        // be queued; it is destroyed before them) and releases what the lattice does not own yet.
         struct apply_guard {
             hipStream_t st;
             int16_t *vkeys_new = nullptr;
@@ -1379,25 +1407,14 @@ int phl_apply_reference_table(phl_lattice *lat, hipStream_t st, void *arena, siz
                 if (vfirst_clean) (void)phl_dev_free(vfirst_clean);
             }
         } guard{st};
+        PHL_HIP(hipMemcpyAsync(blk, pack.data(), sizeof(int32_t) * total, hipMemcpyHostToDevice, st));
         if (R.compact) {
             hipLaunchKernelGGL(k_ref_remap, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, st, (int)M, ex, remap_dev);
-            if (!R.dup_clean.empty()) {                   // tracked keys: -(k+1), resolved per candidate by k_relabel
-                int *di, *dv;
-                PHL_HIP(tmp.get(&di, R.dup_clean.size()));
-                PHL_HIP(tmp.get(&dv, R.dup_clean.size()));
-                for (size_t k = 0; k < R.dup_clean.size(); k++) dup_val.push_back(-(int32_t)(k + 1));
-                PHL_HIP(hipMemcpyAsync(di, R.dup_clean.data(), sizeof(int) * R.dup_clean.size(), hipMemcpyHostToDevice, st));
-                PHL_HIP(hipMemcpyAsync(dv, dup_val.data(), sizeof(int) * dup_val.size(), hipMemcpyHostToDevice, st));
-                hipLaunchKernelGGL(k_set_pairs, dim3((unsigned)((R.dup_clean.size() + 63) / 64)), dim3(64), 0, st, di, dv, (int)R.dup_clean.size(), remap_dev);
-            }
+            if (n_dc)
+                hipLaunchKernelGGL(k_set_pairs, dim3((unsigned)((n_dc + 63) / 64)), dim3(64), 0, st, blk + o_dc, blk + o_dval, (int)n_dc, remap_dev);
             PHL_HIP(hipGetLastError());
         } else {
             PHL_HIP(hipMemcpyAsync(remap_dev, R.remap.data(), sizeof(int) * (size_t)M, hipMemcpyHostToDevice, st));
-        }
-        PHL_HIP(hipMemcpyAsync(dup_ptr_dev, R.dup_ptr.data(), sizeof(int) * R.dup_ptr.size(), hipMemcpyHostToDevice, st));
-        if (!R.seg_e.empty()) {
-            PHL_HIP(hipMemcpyAsync(seg_e_dev, R.seg_e.data(), sizeof(int) * R.seg_e.size(), hipMemcpyHostToDevice, st));
-            PHL_HIP(hipMemcpyAsync(seg_id_dev, R.seg_id.data(), sizeof(int) * R.seg_id.size(), hipMemcpyHostToDevice, st));
         }
         int16_t *vkeys_new;
         PHL_HIP(phl_dev_malloc((void **)&vkeys_new, sizeof(int16_t) * (size_t)R.M_ref * d));
@@ -1406,31 +1423,14 @@ int phl_apply_reference_table(phl_lattice *lat, hipStream_t st, void *arena, siz
             hipLaunchKernelGGL(k_ref_keys, dim3((unsigned)((R.M_ref + 255) / 256)), dim3(256), 0, st, lat->vkeys, d, (int)R.M_ref, ex, vkeys_new);
         else
             PHL_HIP(hipMemcpyAsync(vkeys_new, R.keys.data(), sizeof(int16_t) * (size_t)R.M_ref * d, hipMemcpyHostToDevice, st));
-        // first touches in the reference's numbering (phl_build_device would otherwise have to find every vertex's home
-        // cell with an atomicMin over all N candidates: 1.1 ms at C3)
-        for (size_t k = 0; k + 1 < R.dup_ptr.size(); k++)
-            for (int32_t sidx = R.dup_ptr[k]; sidx < R.dup_ptr[k + 1]; sidx++) {
-                size_t j = 0;
-                for (; j < dv_id.size(); j++)
-                    if (dv_id[j] == R.seg_id[(size_t)sidx]) break;
-                if (j == dv_id.size()) { dv_id.push_back(R.seg_id[(size_t)sidx]); dv_e.push_back(R.seg_e[(size_t)sidx]); }
-                else if (R.seg_e[(size_t)sidx] < dv_e[j]) dv_e[j] = R.seg_e[(size_t)sidx];
-            }
-        for (int32_t &e : dv_e) e = e < 0 ? 0 : (e >= N ? N - 1 : e);
-        int *dv_id_dev, *dv_e_dev;
-        PHL_HIP(tmp.get(&dv_id_dev, dv_id.size() + 1));
-        PHL_HIP(tmp.get(&dv_e_dev, dv_e.size() + 1));
         int *vfirst_clean = lat->vfirst;              // (= efirst_dev: read by the launch below, released behind the sync)
         lat->vfirst = nullptr;
         guard.vfirst_clean = vfirst_clean;
         PHL_HIP(phl_dev_malloc((void **)&lat->vfirst, sizeof(int) * (size_t)R.M_ref));
         PHL_HIP(hipMemsetAsync(lat->vfirst, 0, sizeof(int) * (size_t)R.M_ref, st));
         hipLaunchKernelGGL(k_vfirst_ref, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, st, remap_dev, efirst_dev, (int)M, lat->vfirst);
-        if (!dv_id.empty()) {
-            PHL_HIP(hipMemcpyAsync(dv_id_dev, dv_id.data(), sizeof(int) * dv_id.size(), hipMemcpyHostToDevice, st));
-            PHL_HIP(hipMemcpyAsync(dv_e_dev, dv_e.data(), sizeof(int) * dv_e.size(), hipMemcpyHostToDevice, st));
-            hipLaunchKernelGGL(k_set_pairs, dim3((unsigned)((dv_id.size() + 63) / 64)), dim3(64), 0, st, dv_id_dev, dv_e_dev, (int)dv_id.size(), lat->vfirst);
-        }
+        if (n_dv)
+            hipLaunchKernelGGL(k_set_pairs, dim3((unsigned)((n_dv + 63) / 64)), dim3(64), 0, st, blk + o_dvid, blk + o_dve, (int)n_dv, lat->vfirst);
         PHL_HIP(hipGetLastError());
         PHL_HIP(hipStreamSynchronize(st));            // host vectors and pool temporaries die on return
         guard.done = true;                            // from here on the lattice owns vkeys_new; vfirst_clean goes now
