@@ -815,18 +815,7 @@ __global__ void k_set_pairs(const int *__restrict__ idx, const int *__restrict__
 
 // ---- occupancy of the reference's table, for the analytic replay's one assumption ---------------------------------
 // hist[x] = entries whose home is slot x (hash as permutohedral.h:109-116, size_t arithmetic; capacity a power of two)
-__global__ __launch_bounds__(256) void k_home_hist(const int16_t *__restrict__ vkeys, int64_t count, int d, uint32_t mask,
-                                                   int *__restrict__ hist)
-{
-    const int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (v >= count) return;
-    unsigned long long h = 0;
-    for (int i = 0; i < d; i++) {
-        h += (unsigned long long)(long long)vkeys[v * d + i];
-        h *= 2531011ull;
-    }
-    atomicAdd(&hist[(uint32_t)h & mask], 1);
-}
+// (k_home_hist_add, below cl_homes)
 
 // Is there an empty slot in [home, cap) for every key to check?  Linear probing fills slots from the left:
 // carry(x+1) = max(0, carry(x) + hist[x] - 1) entries arrive at slot x+1 still looking for a slot, and slot x is empty
@@ -1031,10 +1020,23 @@ struct cl_homes {
     int add[128], chk[64];
 };
 
-__global__ void k_add_homes_v(cl_homes h, int *__restrict__ hist)
+// The table's entries by home slot, and the extra homes of a question, in one launch (both only add into hist): the LAST
+// workgroup adds the extra homes
+__global__ __launch_bounds__(256) void k_home_hist_add(const int16_t *__restrict__ vkeys, int64_t count, int d, uint32_t mask,
+                                                       cl_homes hm, int *__restrict__ hist)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < h.n_add) atomicAdd(&hist[h.add[i]], 1);
+    if (blockIdx.x == gridDim.x - 1) {
+        if ((int)threadIdx.x < hm.n_add) atomicAdd(&hist[hm.add[threadIdx.x]], 1);     // (n_add <= 128)
+        return;
+    }
+    const int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= count) return;
+    unsigned long long h = 0;
+    for (int i = 0; i < d; i++) {
+        h += (unsigned long long)(long long)vkeys[v * d + i];
+        h *= 2531011ull;
+    }
+    atomicAdd(&hist[(uint32_t)h & mask], 1);
 }
 
 // verdict of one question: every asked key's home at or before the last empty slot
@@ -1138,10 +1140,9 @@ struct device_query : phl_reftable_query {
             last_empty_zeroed = (r == hipSuccess);
         }
         if (r == hipSuccess) {
-            if (n_clean > 0)
-                hipLaunchKernelGGL(k_home_hist, dim3((unsigned)((n_clean + 255) / 256)), dim3(256), 0, st, vkeys_dev, n_clean, d,
-                                   (uint32_t)(cap - 1), hist);
-            if (h.n_add > 0) hipLaunchKernelGGL(k_add_homes_v, dim3(1), dim3(128), 0, st, h, hist);
+            if (n_clean > 0 || h.n_add > 0)
+                hipLaunchKernelGGL(k_home_hist_add, dim3((unsigned)((n_clean + 255) / 256 + 1)), dim3(256), 0, st, vkeys_dev, n_clean, d,
+                                   (uint32_t)(cap - 1), h, hist);
             if (piece_map && cap <= ((uint64_t)1 << 22)) {
                 const int np = (int)(cap / CL_PIECE);
                 hipLaunchKernelGGL(k_cluster_fold, dim3(np), dim3(256), 0, st, hist, piece_map);
@@ -1553,7 +1554,7 @@ extern "C" int phl_debug_reference_table(const int16_t *keys_clean, const int32_
     return PHL_OK;
 }
 
-// Test entry: the occupancy check of the analytic replay (probe_paths_do_not_wrap) on the device (k_home_hist,
+// Test entry: the occupancy check of the analytic replay (probe_paths_do_not_wrap) on the device (k_home_hist_add,
 // k_add_homes, k_cluster_check) or on the host, for a caller-made key set.  result_out: 1 = no probe path wraps.
 extern "C" int phl_debug_probe_paths(const int16_t *keys_clean, int64_t n_clean, int d, const int32_t *extra_clean, int n_extra,
                                      const int32_t *stale_clean, int n_stale, uint64_t cap, const int32_t *check, int n_check,
